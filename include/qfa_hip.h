@@ -1,0 +1,141 @@
+/* qfa_hip.h -- C-ABI of libqfa_hip.so, the MI355X (gfx950) implementation of the QFA hot path.
+ *
+ * The reference (ZechangSun/QFA) is pure Python and has no FFI: the boundary it offers is the
+ * Python method surface of QFA/model.py and QFA/optimizer.py.  qfa_amd keeps that surface in
+ * Python and calls the functions below through ctypes (qfa_amd/_lib.py).  Every entry point
+ * names the reference interface it replaces (file:line in the reference tree).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (torch tensors: tensor.data_ptr());
+ *     the library allocates nothing, keeps no global mutable state and is re-entrant across
+ *     streams and devices;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - arrays are row-major, contiguous, float32; masks are 1 byte per pixel (torch.bool);
+ *   - return value: 0 = ok, negative = invalid argument (QFA_E_*), positive = hipError_t;
+ *     the library never throws and never calls exit();
+ *   - B spectra, Npix = Nb + Nr pixels (blue side first), Nh latent factors (1..32).
+ */
+#ifndef QFA_HIP_H
+#define QFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QFA_ABI_VERSION 1
+
+#define QFA_E_NULL      (-1)   /* a required pointer is NULL            */
+#define QFA_E_SIZE      (-2)   /* B/Npix/Nb/Nh out of range              */
+#define QFA_E_WORKSPACE (-3)   /* workspace smaller than qfa_workspace_bytes */
+#define QFA_E_TAU       (-4)   /* unknown tau model                      */
+
+/* Mean-optical-depth model tau(z) = (amp * ((1+z)*scale)^expo + offset) * series_coeff
+ * (reference QFA/utils.py:95-141, 149-171).  qfa_tau_model() fills it for the four built-ins. */
+typedef struct {
+    float amp;      /* already multiplied by the Lyman-series coefficient */
+    float scale;
+    float expo;
+    float offset;   /* already multiplied by the Lyman-series coefficient */
+} qfa_tau_t;
+
+enum { QFA_TAU_BECKER = 0, QFA_TAU_FG = 1, QFA_TAU_KAMBLE = 2, QFA_TAU_MOCK = 3 };
+
+/* Model parameters (reference QFA/model.py:37-55, property `parameters` :297-306). */
+typedef struct {
+    const float *F;      /* (Npix, Nh) */
+    const float *Psi;    /* (Npix,)    */
+    const float *omega;  /* (Nb,)      */
+    const float *tau0;   /* scalar on device */
+    const float *c0;     /* scalar on device */
+    const float *beta;   /* scalar on device */
+} qfa_params_t;
+
+/* Spectra batch (contract of Dataloader.next_batch, reference QFA/dataloader.py:124-138). */
+typedef struct {
+    const float   *delta;   /* (B, Npix)  delta = flux - mu*A for training; raw flux for predict */
+    const float   *error;   /* (B, Npix)  */
+    const float   *zabs;    /* (B, Nb)    */
+    const uint8_t *mask;    /* (B, Npix)  1 = pixel is used; masked pixels may hold -999 */
+    const float   *A_blue;  /* optional (B, Nb): host-supplied exp(-tau(zabs)) for a custom tau
+                               callable (reference QFA/model.py:26,43); NULL = use `tau` */
+} qfa_batch_t;
+
+int qfa_abi_version(void);
+
+/* fills `out` for which in QFA_TAU_*, series 1..30 (reference QFA/utils.py:149-171,
+ * coefficients QFA/Lyman_series.csv:2-31). */
+int qfa_tau_model(int which, int series, qfa_tau_t *out);
+
+/* bytes of scratch needed by qfa_nll_grad_f32 / qfa_predict_f32 for this shape */
+size_t qfa_workspace_bytes(int B, int Npix, int Nh);
+
+/* number of floats in the packed accumulation buffer used by qfa_nll_grad_f32 and
+ * qfa_finalize_grads_f32:  [accF Npix*Nh | sumA Npix | gPsi Npix | gOmega Nb | cnt Npix | 8 scalars]
+ * scalars = {g_tau0, g_c0, g_beta, n_spectra_with_blue, sum_nll, n_spectra, 0, 0}.
+ * This is the buffer a data-parallel job all-reduces (sum) across ranks once per step. */
+size_t qfa_accum_floats(int Npix, int Nb, int Nh);
+
+/* Replaces the loop body of QFA.forward (reference QFA/model.py:98-103) and
+ * QFA.loglikelihood_and_gradient_for_single_spectra (:107-158) together with MatrixInverse /
+ * MatrixLogDet (QFA/utils.py:12-54) for a whole batch.
+ *   nll   (B,)  per-spectrum negative log-likelihood (out, may be NULL)
+ *   accum qfa_accum_floats() floats, ADDED to (caller zeroes it once per step).
+ * The per-spectrum sums are raw (not normalised): see qfa_finalize_grads_f32. */
+int qfa_nll_grad_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau,
+                     int B, int Npix, int Nb, int Nh,
+                     float *nll, float *accum, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
+/* Replaces the normalisation of QFA.forward (reference QFA/model.py:104): elementwise
+ * grad = sum / count (0/0 = NaN), loss = sum_nll / n_spectra (model.py:100).  Reads `accum`
+ * (after the optional all-reduce) and writes gradients with the reference's shapes.
+ * normalize = 0 returns the raw sums instead (the per-spectrum gradient of
+ * loglikelihood_and_gradient_for_single_spectra when accum holds one spectrum). */
+int qfa_finalize_grads_f32(const float *accum, const float *F, int Npix, int Nb, int Nh,
+                           int normalize, float *gF, float *gPsi, float *gOmega, float *gTau0,
+                           float *gC0, float *gBeta, float *loss, void *stream);
+
+/* Replaces QFA.prediction_for_single_spectra (reference QFA/model.py:160-180) for a batch:
+ * b->delta holds the raw flux.  Outputs: ll (B,), hmean (B,Nh), hcov (B,Nh,Nh), cont (B,Npix),
+ * unc (B,Npix). */
+int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b,
+                    const qfa_tau_t *tau, int B, int Npix, int Nb, int Nh,
+                    float *ll, float *hmean, float *hcov, float *cont, float *unc,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces Adam.update (reference QFA/optimizer.py:37-52) followed by the clamp of QFA.clip
+ * (QFA/model.py:233-241) for ONE tensor of n elements:
+ *   g' = g + wd*p; m = (1-b1) g' + b1 m; v = (1-b2) g'^2 + b2 v;
+ *   p_out = clamp(p - lr * (m/bc1) / (sqrt(v/bc2) + eps), lo, hi),  bc = 1 - b^(i+1).
+ * m and v are updated in place; pass lo > hi to skip the clamp.  NaN propagates as in torch. */
+int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float *p_out, size_t n,
+                      float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                      float lo, float hi, void *stream);
+
+/* Replaces QFA.clip for one tensor (reference QFA/model.py:233-241): y = clamp(x, lo, hi), NaN kept. */
+int qfa_clip_f32(const float *x, float *y, size_t n, float lo, float hi, void *stream);
+
+/* Replaces QFA.smooth (reference QFA/model.py:243-252): edge-aware moving average of
+ * (2*half+1) rows along axis 0 of an (n, cols) array, divisor = in-range sample count. */
+int qfa_smooth_f32(const float *x, float *y, int n, int cols, int half, void *stream);
+
+/* Replace tau(), tauHI(), omega_func() (reference QFA/utils.py:57-92, 149-171), elementwise on n. */
+int qfa_tau_f32(const float *z, float *out, size_t n, const qfa_tau_t *tau, void *stream);
+int qfa_tauhi_f32(const float *z, const float *tau0, const float *beta, float *out, size_t n,
+                  void *stream);
+int qfa_omega_func_f32(const float *z, const float *tau0, const float *beta, const float *c0,
+                       float *out, size_t n, void *stream);
+
+/* Replace MatrixInverse / MatrixLogDet (reference QFA/utils.py:12-54) for one (n,k) M and (n,) D:
+ * inv (n,n) dense, logdet scalar (Cholesky-free Gauss-Jordan on the k x k core, finite where the
+ * reference's float32 det overflows). workspace: qfa_workspace_bytes(1, n, k). */
+int qfa_woodbury_f32(const float *M, const float *D, int n, int k, float *inv, float *logdet,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QFA_HIP_H */

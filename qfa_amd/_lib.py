@@ -1,0 +1,116 @@
+"""ctypes binding of libqfa_hip.so (C-ABI declared in include/qfa_hip.h).
+
+There is deliberately no fallback: if the shared library is missing, cannot be loaded, or a
+tensor is not a contiguous float32/bool tensor on a HIP device, a ``QFAHipError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqfa_hip.so")
+
+EXPORTS = (
+    "qfa_abi_version", "qfa_tau_model", "qfa_workspace_bytes", "qfa_accum_floats",
+    "qfa_nll_grad_f32", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_adam_clip_f32",
+    "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32",
+)
+
+TAU_IDS = {"becker": 0, "fg": 1, "kamble": 2, "mock": 3}
+
+
+class QFAHipError(RuntimeError):
+    pass
+
+
+class TauModel(C.Structure):
+    _fields_ = [("amp", C.c_float), ("scale", C.c_float), ("expo", C.c_float), ("offset", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("F", "Psi", "omega", "tau0", "c0", "beta")]
+
+
+class Batch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("delta", "error", "zabs", "mask", "A_blue")]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises QFAHipError when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QFAHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C qfa_amd/csrc` (hipcc --offload-arch=gfx950). qfa_amd has no CPU fallback.")
+    try:
+        h = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise QFAHipError(f"cannot load {LIB_PATH}: {e}") from e
+    p, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    sigs = {
+        "qfa_abi_version": (i, []),
+        "qfa_tau_model": (i, [i, i, C.POINTER(TauModel)]),
+        "qfa_workspace_bytes": (sz, [i, i, i]),
+        "qfa_accum_floats": (sz, [i, i, i]),
+        "qfa_nll_grad_f32": (i, [C.POINTER(Params), C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i, p, p, p, sz, p]),
+        "qfa_finalize_grads_f32": (i, [p, p, i, i, i, i, p, p, p, p, p, p, p, p]),
+        "qfa_predict_f32": (i, [C.POINTER(Params), p, C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i,
+                                p, p, p, p, p, p, sz, p]),
+        "qfa_adam_clip_f32": (i, [p, p, p, p, p, sz, f, f, f, f, f, f, f, f, f, p]),
+        "qfa_clip_f32": (i, [p, p, sz, f, f, p]),
+        "qfa_smooth_f32": (i, [p, p, i, i, i, p]),
+        "qfa_tau_f32": (i, [p, p, sz, C.POINTER(TauModel), p]),
+        "qfa_tauhi_f32": (i, [p, p, p, p, sz, p]),
+        "qfa_omega_func_f32": (i, [p, p, p, p, p, sz, p]),
+        "qfa_woodbury_f32": (i, [p, p, i, i, p, p, p, sz, p]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
+    if h.qfa_abi_version() != 1:
+        raise QFAHipError("libqfa_hip.so ABI version mismatch")
+    _lib = h
+    return h
+
+
+def check(status, what):
+    if status == 0:
+        return
+    if status < 0:
+        names = {-1: "QFA_E_NULL", -2: "QFA_E_SIZE", -3: "QFA_E_WORKSPACE", -4: "QFA_E_TAU"}
+        raise QFAHipError(f"{what}: invalid argument ({names.get(status, status)})")
+    raise QFAHipError(f"{what}: hipError_t {status}")
+
+
+def tau_model(which="becker", series=1):
+    if which not in TAU_IDS:
+        raise NotImplementedError("currently available mean optical depth function: ['becker', 'fg', 'kamble']")
+    t = TauModel()
+    check(lib().qfa_tau_model(TAU_IDS[which], int(series), C.byref(t)), "qfa_tau_model")
+    return t
+
+
+def require_device_tensor(t, dtype, name):
+    """Raw pointer of a contiguous tensor on a HIP device, or a loud error."""
+    import torch
+    if not isinstance(t, torch.Tensor):
+        raise QFAHipError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if t.device.type != "cuda":
+        raise QFAHipError(f"{name}: tensor is on {t.device}; qfa_amd runs on a HIP device only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise QFAHipError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise QFAHipError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

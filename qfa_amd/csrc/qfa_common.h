@@ -1,0 +1,91 @@
+// qfa_common.h -- shared device helpers and compile-time layout of the QFA hot path (gfx950).
+//
+// Notation: per spectrum s and pixel i (blue side = first Nb pixels)
+//   A   = exp(-tau(zabs))            (1 on the red side)            reference QFA/model.py:125
+//   zd  = (1 - c0 - exp(-tau0 (1+z)^beta))^2  (0 on the red side)   QFA/utils.py:91-92
+//   D   = A^2 Psi + omega zd + sigma^2                              QFA/model.py:128-131
+//   wD  = mask / D
+//   C   = I + sum_i wD A^2 f_i f_i^T,  T = sum_i wD A^3 f_i f_i^T   (k x k, symmetric)
+//   b   = sum_i wD A delta f_i,        b2 = sum_i wD A^2 delta f_i
+// The k(k+1)/2 distinct products f_a f_b of every pixel are tabulated once per step in the
+// "PF image" (row i = [f_i | P_i], P_i[pair(a,b)] = f_ia f_ib), so that C/T/b/b2 of 16 spectra
+// are plain GEMMs against it and map onto v_mfma_f32_16x16x4_f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qfa_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define QFA_LOG2PI 1.8378770664093453f
+#define QFA_LOG2E 1.4426950408889634f
+#define QFA_LN2 0.6931471805599453f
+
+template <int KP>
+struct Cfg {
+    static constexpr int FW = KP < 16 ? 16 : KP;       // width of the F part of a PF row
+    static constexpr int KK2 = KP * (KP + 1) / 2;       // distinct pairs (a <= b)
+    static constexpr int NT = (KK2 + 15) / 16;          // 16-column tiles of the pair part
+    static constexpr int PW = NT * 16;                  // padded pair width
+    static constexpr int NFT = FW / 16;                 // 16-column tiles of the F part
+    static constexpr int NCP = FW + PW;                 // PF row stride (floats)
+    static constexpr int NCT = KP + KK2;                // rows of the transposed image PFT
+    // per-spectrum moment record: [C PW][T PW][b FW][b2 FW][qd, ld, n, nblue]
+    static constexpr int NMOM = 2 * PW + 2 * FW + 4;
+    static constexpr int MOM_T = PW, MOM_B = 2 * PW, MOM_B2 = 2 * PW + FW, MOM_S = 2 * PW + 2 * FW;
+    // per-spectrum solve record: [y KP][Cinv' KK2 (off-diagonals doubled)][Z KP*KP][p KP]
+    static constexpr int NSOL = 2 * KP + KK2 + KP * KP;
+    static constexpr int SOL_CI = KP, SOL_Z = KP + KK2, SOL_P = KP + KK2 + KP * KP;
+};
+
+// packed index of the pair (a, b), a <= b < KP: row-major upper triangle
+__host__ __device__ constexpr int pair_index(int a, int b, int KP) {
+    return a * KP - (a * (a - 1)) / 2 + (b - a);
+}
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// scalars the kernels need, read once from device memory
+struct DevConsts {
+    float tau0, c0, beta;
+    float t_amp, t_lscale, t_expo, t_off;   // tau(z) = t_amp * 2^(t_expo (log2(1+z) + t_lscale)) + t_off
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return fast_exp2(x * QFA_LOG2E); }
+__device__ __forceinline__ float fast_log(float x) { return fast_log2(x) * QFA_LN2; }
+
+// blue-side per-element terms.  l2 = log2(1+z)
+struct BlueTerms {
+    float A, zd, pw, l2;
+};
+
+__device__ __forceinline__ BlueTerms blue_terms(float z, const DevConsts &k) {
+    BlueTerms t;
+    t.l2 = fast_log2(1.0f + z);
+    float tau = k.t_amp * fast_exp2(k.t_expo * (t.l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
+    t.A = fast_exp(-tau);                                                         // QFA/model.py:125
+    t.pw = fast_exp2(k.beta * t.l2);                                              // (1+z)^beta, utils.py:73
+    float re = 1.0f - k.c0 - fast_exp(-k.tau0 * t.pw);                            // utils.py:91
+    t.zd = re * re;
+    return t;
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ DevConsts load_consts(const qfa_params_t &p, const qfa_tau_t &tau) {
+    DevConsts k;
+    k.tau0 = *p.tau0;
+    k.c0 = *p.c0;
+    k.beta = *p.beta;
+    k.t_amp = tau.amp;
+    k.t_lscale = __log2f(tau.scale);
+    k.t_expo = tau.expo;
+    k.t_off = tau.offset;
+    return k;
+}

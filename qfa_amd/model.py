@@ -1,0 +1,341 @@
+"""QFA model with the reference's Python surface (reference QFA/model.py:24-316) on HIP kernels.
+
+Same constructor, attributes, method names, argument order and return shapes as the reference
+class ``QFA``; ``QFAModel`` / ``fit`` / ``predict`` are the aliases BASELINE.json's north_star
+names.  Every method that computes something calls the C-ABI in ``include/qfa_hip.h``; nothing
+here falls back to torch arithmetic when the library or the GPU is missing.
+
+Additions over the reference (none changes a reference call's result):
+  * ``predict`` -- batched ``prediction_for_single_spectra``;
+  * ``step`` -- forward + Adam + clip without a host sync (what ``train`` and bench.py run);
+  * data parallelism: ``enable_data_parallel()`` all-reduces the packed sum/count buffer over
+    RCCL once per step before the normalisation;
+  * ``load_from_npz(path, reference_c0_quirk=True)``: the reference loader sets c0 <- beta
+    (model.py:295); that stays the default because the shipped known answers need it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from functools import partial
+from typing import Callable, Dict
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import utils as _utils
+
+f32 = torch.float32
+log2pi = 1.8378770664093453
+default_tau = partial(_utils.tau, which="becker")
+
+PARAM_KEYS = ("F", "Psi", "omega", "tau0", "c0", "beta")
+
+
+def _resolve_tau(tau):
+    """Map the reference's ``tau`` argument (a callable, model.py:26) onto a kernel tau model.
+    Returns (TauModel or None, callable or None): built-ins run in-kernel, anything else is
+    evaluated by calling it on zabs and handing exp(-tau) to the kernels as A_blue."""
+    if isinstance(tau, str):
+        return _lib.tau_model(tau, 1), None
+    if isinstance(tau, partial) and tau.func is _utils.tau and not tau.args:
+        kw = dict(tau.keywords or {})
+        return _lib.tau_model(kw.get("which", "becker"), kw.get("series", 1)), None
+    if tau is _utils.tau:
+        return _lib.tau_model("becker", 1), None
+    if callable(tau):
+        return _lib.tau_model("becker", 1), tau
+    raise TypeError("tau must be a name, qfa_amd.utils.tau (partial) or a callable")
+
+
+class QFA(object):
+
+    def __init__(self, Nb: int, Nr: int, Nh: int, device: torch.device,
+                 tau: Callable[[torch.Tensor], torch.Tensor] = default_tau,
+                 model_params: Dict[str, np.ndarray] = None) -> None:
+        self.Nb = int(Nb)
+        self.Nr = int(Nr)
+        self.Nh = int(Nh)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.QFAHipError(f"QFA(device={device}): qfa_amd needs a HIP device (torch device 'cuda'); "
+                                   "there is no CPU path")
+        _lib.lib()
+        self.Npix = self.Nb + self.Nr
+        self.Nparams = self.Npix * self.Nh + self.Npix + self.Nb + 3
+        self.tau = tau
+        self._tau_model, self._tau_callable = _resolve_tau(tau)
+        self.min_value = 1e-3
+        self.max_value = 2.
+        if model_params is not None:
+            for k in PARAM_KEYS:
+                setattr(self, k, torch.tensor(np.asarray(model_params[k]), dtype=f32).to(self.device).contiguous())
+        else:
+            self.random_init_func()
+        self.mu = None
+        self._ws = {}
+        self._dp_group = None
+        self._dp = False
+
+    # ------------------------------------------------------------------ parameters
+    def random_init_func(self) -> None:
+        """reference QFA/model.py:57-72"""
+        self.F = (torch.rand((self.Npix, self.Nh), dtype=f32) - 0.5).to(self.device)
+        self.Psi = torch.ones((self.Npix,), dtype=f32, device=self.device)
+        self.omega = torch.ones((self.Nb,), dtype=f32, device=self.device)
+        self.tau0 = torch.tensor(0.02, dtype=f32, device=self.device)
+        self.c0 = torch.tensor(0.3, dtype=f32, device=self.device)
+        self.beta = torch.tensor(2., dtype=f32, device=self.device)
+
+    @property
+    def parameters(self):
+        return {k: getattr(self, k) for k in PARAM_KEYS}
+
+    @parameters.setter
+    def parameters(self, params_dict):
+        for k in PARAM_KEYS:
+            setattr(self, k, params_dict[k])
+        self.clip()
+
+    def _clip_table(self):
+        return {"omega": (self.min_value, self.max_value), "Psi": (self.min_value, self.max_value),
+                "tau0": (0., 1.), "beta": (0.1, 5.), "c0": (-5., 5.)}
+
+    def clip(self):
+        """reference QFA/model.py:233-241"""
+        h = _lib.lib()
+        st = _lib.current_stream(self.device)
+        for k, (lo, hi) in self._clip_table().items():
+            x = getattr(self, k).to(f32).contiguous()
+            y = torch.empty_like(x)
+            _lib.check(h.qfa_clip_f32(_lib.require_device_tensor(x, f32, k), C.c_void_p(y.data_ptr()), x.numel(),
+                                      lo, hi, st), "qfa_clip_f32")
+            setattr(self, k, y)
+
+    def smooth(self):
+        """reference QFA/model.py:243-252: 15-px windows on omega/Psi, 31-px on F along pixels."""
+        h = _lib.lib()
+        st = _lib.current_stream(self.device)
+        for k, half in (("omega", 7), ("Psi", 7), ("F", 15)):
+            x = getattr(self, k).to(f32).contiguous()
+            y = torch.empty_like(x)
+            n = x.shape[0]
+            cols = x.numel() // max(n, 1)
+            _lib.check(h.qfa_smooth_f32(_lib.require_device_tensor(x, f32, k), C.c_void_p(y.data_ptr()), n, cols,
+                                        half, st), "qfa_smooth_f32")
+            setattr(self, k, y)
+
+    # ------------------------------------------------------------------ plumbing
+    def _params_struct(self):
+        ps = _lib.Params()
+        self._keep = []
+        for k in PARAM_KEYS:
+            t = getattr(self, k)
+            if t.dtype != f32 or not t.is_contiguous() or t.device != self.device:
+                t = t.to(device=self.device, dtype=f32).contiguous()
+                setattr(self, k, t)
+            setattr(ps, k, _lib.require_device_tensor(t, f32, k).value)
+        return ps
+
+    def _batch_struct(self, delta, error, zabs, mask):
+        if mask.dtype != torch.bool:
+            raise _lib.QFAHipError(f"mask: dtype {mask.dtype}, expected torch.bool (reference model.py:124)")
+        bs = _lib.Batch()
+        delta = delta if (delta.dtype == f32 and delta.is_contiguous()) else delta.to(f32).contiguous()
+        error = error if (error.dtype == f32 and error.is_contiguous()) else error.to(f32).contiguous()
+        zabs = zabs if (zabs.dtype == f32 and zabs.is_contiguous()) else zabs.to(f32).contiguous()
+        mask = mask if mask.is_contiguous() else mask.contiguous()
+        keep = [delta, error, zabs, mask]
+        bs.delta = _lib.require_device_tensor(delta, f32, "delta").value
+        bs.error = _lib.require_device_tensor(error, f32, "error").value
+        bs.zabs = _lib.require_device_tensor(zabs, f32, "zabs").value if self.Nb > 0 else None
+        bs.mask = _lib.require_device_tensor(mask, torch.bool, "mask").value
+        bs.A_blue = None
+        if self._tau_callable is not None and self.Nb > 0:
+            a = torch.exp(-1. * self._tau_callable(zabs)).to(f32).contiguous()   # user code (model.py:125)
+            keep.append(a)
+            bs.A_blue = _lib.require_device_tensor(a, f32, "A_blue").value
+        return bs, keep
+
+    def _workspace(self, B):
+        need = _lib.lib().qfa_workspace_bytes(int(B), self.Npix, self.Nh)
+        if need == 0:
+            raise _lib.QFAHipError(f"unsupported shape B={B} Npix={self.Npix} Nh={self.Nh}")
+        ws = self._ws.get("ws")
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws["ws"] = ws
+        return ws
+
+    def _accum(self):
+        n = _lib.lib().qfa_accum_floats(self.Npix, self.Nb, self.Nh)
+        acc = self._ws.get("accum")
+        if acc is None or acc.numel() != n:
+            acc = torch.empty(n, dtype=f32, device=self.device)
+            self._ws["accum"] = acc
+        acc.zero_()
+        return acc
+
+    def _check_batch_shapes(self, delta, error, zabs, mask):
+        B = delta.shape[0]
+        if tuple(delta.shape) != (B, self.Npix) or tuple(error.shape) != (B, self.Npix) \
+                or tuple(mask.shape) != (B, self.Npix) or tuple(zabs.shape) != (B, self.Nb):
+            raise _lib.QFAHipError(
+                f"batch shapes {tuple(delta.shape)}, {tuple(error.shape)}, {tuple(zabs.shape)}, {tuple(mask.shape)} "
+                f"do not match (B,{self.Npix}), (B,{self.Npix}), (B,{self.Nb}), (B,{self.Npix})")
+        return B
+
+    # ------------------------------------------------------------------ data parallel
+    def enable_data_parallel(self, group=None):
+        """Shard spectra across ranks: every rank calls forward/step on its own shard; the packed
+        [sums | counts | sum NLL | B] buffer is all-reduced (RCCL) before sum/count."""
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._dp = True
+        self._dp_group = group
+
+    def accumulate(self, delta, error, zabs, mask, accum=None, nll=None):
+        """Raw sums of one (shard of a) batch into the packed buffer; no normalisation."""
+        B = self._check_batch_shapes(delta, error, zabs, mask)
+        ps = self._params_struct()
+        bs, keep = self._batch_struct(delta, error, zabs, mask)
+        ws = self._workspace(B)
+        acc = self._accum() if accum is None else accum
+        _lib.check(_lib.lib().qfa_nll_grad_f32(
+            C.byref(ps), C.byref(bs), C.byref(self._tau_model), B, self.Npix, self.Nb, self.Nh,
+            C.c_void_p(nll.data_ptr()) if nll is not None else None, C.c_void_p(acc.data_ptr()),
+            C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream(self.device)), "qfa_nll_grad_f32")
+        return acc
+
+    def _finalize(self, acc, normalize=True):
+        g = {"F": torch.empty((self.Npix, self.Nh), dtype=f32, device=self.device),
+             "Psi": torch.empty((self.Npix,), dtype=f32, device=self.device),
+             "omega": torch.empty((self.Nb,), dtype=f32, device=self.device),
+             "tau0": torch.empty((), dtype=f32, device=self.device),
+             "c0": torch.empty((), dtype=f32, device=self.device),
+             "beta": torch.empty((), dtype=f32, device=self.device)}
+        loss = torch.empty((1, 1), dtype=f32, device=self.device)
+        _lib.check(_lib.lib().qfa_finalize_grads_f32(
+            C.c_void_p(acc.data_ptr()), C.c_void_p(self.F.data_ptr()), self.Npix, self.Nb, self.Nh,
+            1 if normalize else 0, C.c_void_p(g["F"].data_ptr()), C.c_void_p(g["Psi"].data_ptr()),
+            C.c_void_p(g["omega"].data_ptr()) if self.Nb > 0 else None, C.c_void_p(g["tau0"].data_ptr()),
+            C.c_void_p(g["c0"].data_ptr()), C.c_void_p(g["beta"].data_ptr()), C.c_void_p(loss.data_ptr()),
+            _lib.current_stream(self.device)), "qfa_finalize_grads_f32")
+        return loss, g
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, delta: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor):
+        """Batch loss (1,1) and count-normalised gradient dict (reference QFA/model.py:74-105)."""
+        acc = self.accumulate(delta, error, zabs, mask)
+        if self._dp:
+            import torch.distributed as dist
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self._dp_group)
+        return self._finalize(acc, True)
+
+    def loglikelihood_and_gradient_for_single_spectra(self, delta, error, zabs, mask):
+        """One spectrum: NLL (1,1) and the six un-normalised gradients, zeros at masked pixels
+        (reference QFA/model.py:107-158)."""
+        acc = self.accumulate(delta[None, :], error[None, :], zabs[None, :], mask[None, :])
+        return self._finalize(acc, False)
+
+    def predict(self, flux: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor):
+        """Batched posterior prediction: ll (B,), hmean (B,Nh), hcov (B,Nh,Nh), cont (B,Npix),
+        unc (B,Npix) (reference QFA/model.py:160-180 applied to every row)."""
+        if self.mu is None:
+            raise _lib.QFAHipError("predict needs model.mu (load_from_npz or train first)")
+        B = self._check_batch_shapes(flux, error, zabs, mask)
+        ps = self._params_struct()
+        bs, keep = self._batch_struct(flux, error, zabs, mask)
+        mu = self.mu.to(device=self.device, dtype=f32).contiguous()
+        ws = self._workspace(B)
+        dev = self.device
+        ll = torch.empty((B,), dtype=f32, device=dev)
+        hmean = torch.empty((B, self.Nh), dtype=f32, device=dev)
+        hcov = torch.empty((B, self.Nh, self.Nh), dtype=f32, device=dev)
+        cont = torch.empty((B, self.Npix), dtype=f32, device=dev)
+        unc = torch.empty((B, self.Npix), dtype=f32, device=dev)
+        _lib.check(_lib.lib().qfa_predict_f32(
+            C.byref(ps), C.c_void_p(mu.data_ptr()), C.byref(bs), C.byref(self._tau_model), B, self.Npix, self.Nb,
+            self.Nh, C.c_void_p(ll.data_ptr()), C.c_void_p(hmean.data_ptr()), C.c_void_p(hcov.data_ptr()),
+            C.c_void_p(cont.data_ptr()), C.c_void_p(unc.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+            _lib.current_stream(dev)), "qfa_predict_f32")
+        return ll, hmean, hcov, cont, unc
+
+    def prediction_for_single_spectra(self, flux, error, zabs, mask):
+        """reference QFA/model.py:160-180: ll (1,1), hmean (Nh,1), hcov (Nh,Nh), cont (Npix,), unc (Npix,)."""
+        ll, hmean, hcov, cont, unc = self.predict(flux[None, :], error[None, :], zabs[None, :], mask[None, :])
+        return ll.reshape(1, 1), hmean.reshape(self.Nh, 1), hcov[0], cont[0], unc[0]
+
+    def step(self, optimizer, delta, error, zabs, mask):
+        """forward -> Adam.update -> clip, all on device, no host sync (model.py:212-214, 316).
+        Returns the (1,1) loss tensor."""
+        loss, grads = self.forward(delta, error, zabs, mask)
+        new = optimizer.update(self.parameters, grads, clip=self._clip_table())
+        for k in PARAM_KEYS:
+            setattr(self, k, new[k])
+        return loss
+
+    def train(self, optimizer, dataloader, n_epochs, output_dir="./result", save_interval=5, smooth_interval=5,
+              quiet=False, logger=None):
+        """Training loop with the reference's control flow (reference QFA/model.py:183-231):
+        Niter = data_size // batch_size (quirk Q5), optimizer.step() once per epoch (Q4), early
+        stop the first time the epoch-mean NLL is negative (Q6), smooth / save cadence."""
+        os.makedirs(output_dir, exist_ok=True)
+        output_dir = os.path.join(output_dir, "checkpoints")
+        os.makedirs(output_dir, exist_ok=True)
+        self.mu = torch.tensor(np.asarray(dataloader.mu), dtype=f32).to(self.device)
+        Niter = dataloader.data_size // dataloader.batch_size
+        for epoch in range(n_epochs):
+            dataloader.rewind()
+            total = torch.zeros((), dtype=torch.float64, device=self.device)
+            t0 = time.time()
+            while dataloader.have_next_batch():
+                d, e, z, m = dataloader.next_batch()
+                loss = self.step(optimizer, d, e, z, m)
+                total += loss.reshape(()).double()
+            optimizer.step()
+            total_loss = total.item() / Niter          # one host sync per epoch; ZeroDivisionError if Niter == 0
+            msg = "epoch: {:03d}/{:03d}  ;  loss:  {:.2f}  ;  time:  {:.2f} s ".format(
+                epoch, n_epochs, total_loss, time.time() - t0)
+            if not quiet:
+                print(msg)
+            if logger is not None:
+                logger.info(msg)
+            if total_loss < 0.:
+                self.smooth()
+                self.save_to_npz(output_dir, "model_parameters_epoch_%02i.npz" % (epoch + 1))
+                break
+            if (epoch + 1) % smooth_interval == 0:
+                self.smooth()
+            if (epoch + 1) % save_interval == 0:
+                self.save_to_npz(output_dir, "model_parameters_epoch_%02i.npz" % (epoch + 1))
+
+    fit = train
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_to_npz(self, output_dir: str, file_name: str):
+        """reference QFA/model.py:254-280: keys mu, F, Psi, omega, tau0, c0, beta."""
+        os.makedirs(output_dir, exist_ok=True)
+        arrs = {k: getattr(self, k).detach().cpu().numpy() for k in PARAM_KEYS}
+        arrs["mu"] = self.mu.detach().cpu().numpy()
+        np.savez(os.path.join(output_dir, file_name), **arrs)
+
+    def load_from_npz(self, path: str, reference_c0_quirk: bool = True):
+        """reference QFA/model.py:282-295.  With ``reference_c0_quirk`` (default) c0 is read from
+        the file's ``beta`` entry exactly as the reference does (model.py:295, quirk Q1)."""
+        f = np.load(path)
+        def T(x):
+            return torch.tensor(np.asarray(x), dtype=f32, device=self.device).contiguous()
+        self.mu = T(f["mu"])
+        self.F = T(f["F"])
+        self.omega = T(f["omega"])
+        self.Psi = T(f["Psi"])
+        self.tau0 = T(f["tau0"])
+        self.beta = T(f["beta"])
+        self.c0 = T(f["beta"] if reference_c0_quirk else f["c0"])
+
+
+QFAModel = QFA

@@ -1,0 +1,94 @@
+"""Adam with the reference's surface and quirks (reference QFA/optimizer.py:11-99).
+
+* L2 regularisation is folded into the gradient (optimizer.py:47);
+* the bias-correction exponent and the learning-rate schedule use ``self.i``, which only
+  advances in ``step()`` -- once per epoch in ``QFA.train`` (model.py:215), quirk Q4;
+* ``update`` is functional: it returns a new parameter dict and leaves its input untouched.
+The arithmetic runs in ``qfa_adam_clip_f32`` (one launch per tensor).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+f32 = torch.float32
+
+
+class Adam(object):
+
+    def __init__(self, params: Dict[str, torch.Tensor], device: torch.device, scheduler=None,
+                 learning_rate: float = 1e-2, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8,
+                 weight_decay: float = 1e-3) -> None:
+        self.learning_rate = learning_rate
+        self.b1 = b1
+        self.b2 = b2
+        self.eps = eps
+        self.device = device
+        self.weight_decay = weight_decay
+        self.scheduler = scheduler
+        self.reset(params)
+
+    def reset(self, params):
+        """reference QFA/optimizer.py:54-63"""
+        self.m = {k: torch.zeros_like(params[k], dtype=f32, device=self.device) for k in params}
+        self.v = {k: torch.zeros_like(params[k], dtype=f32, device=self.device) for k in params}
+        self.i = 0
+
+    def step(self):
+        """reference QFA/optimizer.py:65-69"""
+        self.i += 1
+
+    @property
+    def scheduled_lr(self):
+        """reference QFA/optimizer.py:71-76"""
+        if callable(self.scheduler):
+            return self.scheduler(self.i, self.learning_rate)
+        return self.learning_rate
+
+    def update(self, params, g, clip: Optional[Dict[str, Tuple[float, float]]] = None):
+        """reference QFA/optimizer.py:37-52.  ``clip`` (key -> (lo, hi)) optionally fuses the
+        clamp of QFA.clip into the same launch; the plain reference call leaves it out and the
+        ``QFA.parameters`` setter clips afterwards."""
+        h = _lib.lib()
+        lr = float(self.scheduled_lr)
+        bc1 = 1.0 - self.b1 ** (self.i + 1)
+        bc2 = 1.0 - self.b2 ** (self.i + 1)
+        out = {}
+        for k in params:
+            p = params[k]
+            if p.dtype != f32 or not p.is_contiguous():
+                p = p.to(f32).contiguous()
+            grad = g[k]
+            if grad.dtype != f32 or not grad.is_contiguous():
+                grad = grad.to(f32).contiguous()
+            pp = _lib.require_device_tensor(p, f32, f"params[{k}]")
+            gp = _lib.require_device_tensor(grad, f32, f"g[{k}]")
+            q = torch.empty_like(p)
+            lo, hi = clip[k] if (clip is not None and k in clip) else (1.0, 0.0)
+            _lib.check(h.qfa_adam_clip_f32(pp, gp, C.c_void_p(self.m[k].data_ptr()), C.c_void_p(self.v[k].data_ptr()),
+                                           C.c_void_p(q.data_ptr()), p.numel(), lr, self.b1, self.b2, self.eps,
+                                           self.weight_decay, bc1, bc2, lo, hi, _lib.current_stream(p.device)),
+                       "qfa_adam_clip_f32")
+            out[k] = q
+        return out
+
+    # checkpoint support for the optimiser state (absent in the reference)
+    def state_dict(self):
+        return {"i": self.i, "m": {k: v.clone() for k, v in self.m.items()},
+                "v": {k: v.clone() for k, v in self.v.items()}}
+
+    def load_state_dict(self, sd):
+        self.i = int(sd["i"])
+        self.m = {k: v.to(self.device, f32).clone() for k, v in sd["m"].items()}
+        self.v = {k: v.to(self.device, f32).clone() for k, v in sd["v"].items()}
+
+
+def step_scheduler(alpha: float, step: int) -> Callable[[int, float], float]:
+    """lr * alpha ** ((i+1)//step)  (reference QFA/optimizer.py:79-99)."""
+    def scheduler(i, lr):
+        return lr * alpha ** ((i + 1) // step)
+    return scheduler

@@ -1,0 +1,357 @@
+"""GPU parity: the HIP path, called through the C-ABI behind the reference's Python surface,
+against the golden fixtures of the imported reference and against the CPU oracle on the same
+seeded inputs.  Tolerances (float32 HIP vs float64 oracle / float32 reference):
+  NLL / loss 1e-5 rel (north_star), posterior continuum 1e-4 rel (north_star),
+  gradients 2e-4 rel-L2 (F), 5e-5 (Psi, omega, scalars), hmean/hcov 1e-4."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("F", "Psi", "omega", "tau0", "c0", "beta")
+TOL_NLL = 1e-5
+TOL_G = {"F": 2e-4, "Psi": 5e-5, "omega": 5e-5, "tau0": 5e-5, "c0": 5e-5, "beta": 5e-5}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def T(x, dev, dt=None):
+    import torch
+    x = np.asarray(x)
+    if x.dtype == bool:
+        return torch.tensor(x, dtype=torch.bool, device=dev)
+    return torch.tensor(x, dtype=dt or torch.float32, device=dev)
+
+
+def make_model(dev, p, mu=None, tau="becker", nb=None):
+    from qfa_amd import QFA
+    npix, nh = p["F"].shape
+    nb = len(p["omega"]) if nb is None else nb
+    m = QFA(nb, npix - nb, nh, dev, tau=tau, model_params=p)
+    if mu is not None:
+        m.mu = T(mu, dev)
+    return m
+
+
+def batch_t(b, dev, key="delta"):
+    return T(b[key], dev), T(b["error"], dev), T(b["zabs"], dev), T(b["mask"], dev)
+
+
+def test_g1_g2_predict_shipped_spectrum(dev, shipped, grid):
+    import torch
+    from qfa_amd import QFA
+    wav, nb, nr = grid
+    m = QFA(nb, nr, 8, dev)
+    import os
+    from conftest import GOLDEN
+    m.load_from_npz(os.path.join(GOLDEN, "model_parameters.npz"))
+    g = golden("g1_g2_predict.npz")
+    sp = golden("sdss_spectrum.npz")
+    for tag, sfx in (("full", ""), ("red", "_red")):
+        ll, hm, hc, cont, unc = m.prediction_for_single_spectra(
+            T(sp["flux"], dev), T(sp["error"], dev), T(g["zabs"], dev), T(g[f"mask_{tag}"], dev))
+        assert ll.shape == (1, 1) and hm.shape == (8, 1) and hc.shape == (8, 8)
+        assert cont.shape == (1913,) and unc.shape == (1913,)
+        ll, hm, hc, cont, unc = [x.cpu().numpy() for x in (ll, hm, hc, cont, unc)]
+        # the reference's own stored answers
+        assert abs(ll.item() - float(sp["ll" + sfx])) / abs(float(sp["ll" + sfx])) < TOL_NLL
+        assert np.max(np.abs(cont - sp["our" + sfx]) / np.abs(sp["our" + sfx])) < 1e-4
+        assert rel_l2(hm.squeeze(), sp["h" + sfx].squeeze()) < 1e-4
+        # outputs of the imported reference
+        assert rel_l2(hc, g[f"hcov_{tag}"]) < 1e-4
+        assert rel_l2(unc, g[f"unc_{tag}"]) < 1e-4
+        assert rel_l2(cont, g[f"cont_{tag}"]) < 1e-5
+
+
+def test_g3_single_spectrum(dev, shipped, grid):
+    from qfa_amd import synthetic
+    p, mu = shipped
+    wav, nb, nr = grid
+    g = golden("g3_single.npz")
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 4, seed=int(g["seed"]))
+    m = make_model(dev, p, mu)
+    for s in range(4):
+        nll, gr = m.loglikelihood_and_gradient_for_single_spectra(
+            T(b["delta"][s], dev), T(b["error"][s], dev), T(b["zabs"][s], dev), T(b["mask"][s], dev))
+        assert nll.shape == (1, 1)
+        assert abs(nll.item() - g["nll"][s]) / abs(g["nll"][s]) < TOL_NLL
+        for k in KEYS:
+            assert rel_l2(gr[k].cpu().numpy(), g[f"g_{k}"][s]) < TOL_G[k], (s, k)
+        assert (gr["F"].cpu().numpy()[~b["mask"][s]] == 0).all()
+        assert (gr["Psi"].cpu().numpy()[~b["mask"][s]] == 0).all()
+
+
+def test_g4_forward_nan_and_red_only(dev, shipped, grid):
+    from qfa_amd import synthetic
+    p, mu = shipped
+    wav, nb, nr = grid
+    g = golden("g4_forward.npz")
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 8, seed=int(g["seed"]), red_only=(3,), dead_range=(900, 910))
+    m = make_model(dev, p, mu)
+    loss, gr = m.forward(*batch_t(b, dev))
+    assert loss.shape == (1, 1)
+    assert abs(loss.item() - float(g["loss"].squeeze())) / abs(float(g["loss"].squeeze())) < TOL_NLL
+    for k in KEYS:
+        ours, ref = gr[k].cpu().numpy(), g[f"g_{k}"]
+        assert ours.shape == ref.shape, k
+        assert np.array_equal(np.isnan(ours), np.isnan(ref)), k
+        ok = ~np.isnan(ref)
+        assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
+
+
+def test_g5_full_step(dev, shipped, grid):
+    from qfa_amd import Adam, step_scheduler, synthetic
+    p, mu = shipped
+    wav, nb, nr = grid
+    g = golden("g5_step.npz")
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 128, seed=int(g["seed"]))
+    m = make_model(dev, p, mu)
+    opt = Adam(params=m.parameters, device=dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3,
+               weight_decay=1e-1)
+    loss, gr = m.forward(*batch_t(b, dev))
+    assert abs(loss.item() - float(g["loss"].squeeze())) / abs(float(g["loss"].squeeze())) < TOL_NLL
+    for k in KEYS:
+        assert rel_l2(gr[k].cpu().numpy(), g[f"g_{k}"]) < TOL_G[k], k
+    m.parameters = opt.update(m.parameters, gr)          # reference call sequence (model.py:214)
+    for k in KEYS:
+        assert rel_l2(m.parameters[k].cpu().numpy(), g[f"p_{k}"]) < 1e-5, k
+    # fused step gives the same parameters
+    m2 = make_model(dev, p, mu)
+    opt2 = Adam(params=m2.parameters, device=dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3,
+                weight_decay=1e-1)
+    m2.step(opt2, *batch_t(b, dev))
+    for k in KEYS:
+        assert rel_l2(m2.parameters[k].cpu().numpy(), g[f"p_{k}"]) < 1e-5, k
+
+
+def test_g6_smooth_clip(dev, shipped):
+    p, mu = shipped
+    g = golden("g6_smooth_clip.npz")
+    m = make_model(dev, p, mu)
+    m.smooth()
+    for k in ("F", "Psi", "omega"):
+        assert rel_l2(getattr(m, k).cpu().numpy(), g[f"smooth_{k}"]) < 2e-6, k
+    m2 = make_model(dev, {k: g[f"preclip_{k}"] for k in KEYS}, mu)
+    m2.clip()
+    for k in KEYS:
+        assert np.array_equal(getattr(m2, k).cpu().numpy(), g[f"clip_{k}"]), k
+    import torch
+    m2.Psi = torch.full_like(m2.Psi, float("nan"))
+    m2.clip()
+    assert torch.isnan(m2.Psi).all()         # torch.clip keeps NaN; so do we
+
+
+def test_g7_adam_trace(dev):
+    from qfa_amd import Adam, step_scheduler
+    g = golden("g7_adam.npz")
+    params = {k: T(g[f"init_{k}"], dev) for k in KEYS}
+    opt = Adam(params=params, device=dev, scheduler=step_scheduler(0.9, 2), learning_rate=1e-2, weight_decay=1e-3)
+    it = 0
+    for epoch in range(3):
+        for _ in range(2):
+            before = {k: v.clone() for k, v in params.items()}
+            new = opt.update(params, {k: T(g[f"grad{it}_{k}"], dev) for k in KEYS})
+            for k in KEYS:
+                assert (params[k] == before[k]).all()        # functional update: input untouched
+                assert rel_l2(new[k].cpu().numpy(), g[f"p{it}_{k}"]) < 5e-6, (it, k)
+            params = new
+            it += 1
+        opt.step()
+
+
+def test_g8_woodbury(dev):
+    from qfa_amd import utils
+    g = golden("g8_woodbury.npz")
+    inv = utils.MatrixInverse(T(g["M"], dev), T(g["D"], dev), dev)
+    ld = utils.MatrixLogDet(T(g["M"], dev), T(g["D"], dev), dev)
+    assert rel_l2(inv.cpu().numpy(), g["inv"]) < 1e-5
+    assert abs(ld.item() - float(g["logdet"])) / abs(float(g["logdet"])) < 1e-5
+
+
+def test_g9_tau(dev):
+    from qfa_amd import utils
+    g = golden("g9_tau.npz")
+    z = T(g["z"], dev)
+    for which in ("becker", "fg", "kamble", "mock"):
+        for series in (1, 2, 5):
+            assert rel_l2(utils.tau(z, which=which, series=series).cpu().numpy(), g[f"tau_{which}_{series}"]) < 2e-6
+    assert rel_l2(utils.tauHI(z, 0.0123, 3.1).cpu().numpy(), g["tauHI"]) < 2e-6
+    assert rel_l2(utils.omega_func(z, 0.0123, 3.1, 0.27).cpu().numpy(), g["omega_func"]) < 5e-6
+    with pytest.raises(NotImplementedError):
+        utils.tau(z, which="nope")
+
+
+def test_g10_k16_finite_where_reference_overflows(dev):
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    g = golden("g10_k16.npz")
+    n_pix = int(g["n_pix"])
+    wav, nb, nr = synthetic.wavelength_grid(n_pix)
+    r16 = np.random.default_rng(16)
+    p16 = {"F": (r16.random((n_pix, 16)) - 0.5).astype(np.float32), "Psi": np.ones(n_pix, np.float32),
+           "omega": np.ones(nb, np.float32), "tau0": np.float32(0.02), "c0": np.float32(0.3),
+           "beta": np.float32(2.0)}
+    _, mu16 = synthetic.mock_parameters(n_pix, nb, 16, seed=16)
+    b = synthetic.make_batch_numpy(p16, mu16, wav, nb, 2, seed=int(g["seed"]))
+    m = make_model(dev, p16, mu16)
+    loss, gr = m.forward(*batch_t(b, dev))
+    oloss, ogr = O.forward(p16, b["delta"], b["error"], b["zabs"], b["mask"])
+    assert np.isinf(g["loss"]).all() and np.isfinite(loss.item())
+    assert abs(loss.item() - oloss) / abs(oloss) < TOL_NLL
+    for k in KEYS:
+        ref = g[f"g_{k}"]
+        ok = ~np.isnan(ref)
+        assert rel_l2(gr[k].cpu().numpy()[ok], ref[ok]) < 5e-4, k
+        assert rel_l2(gr[k].cpu().numpy()[ok], np.asarray(ogr[k])[ok]) < TOL_G[k], k
+
+
+CASES = [
+    # (B, Npix, Nh, masks, seed)   ragged / edge shapes
+    (1, 64, 1, False, 1),
+    (3, 50, 3, True, 2),
+    (17, 333, 5, True, 3),
+    (16, 1024, 8, True, 4),
+    (33, 777, 12, True, 5),
+    (40, 1200, 16, True, 6),
+    (130, 256, 16, False, 7),
+]
+
+
+@pytest.mark.parametrize("B,npix,nh,masks,seed", CASES)
+def test_forward_vs_oracle_ragged_shapes(dev, B, npix, nh, masks, seed):
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=seed)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=100 + seed, masks=masks)
+    m = make_model(dev, p, mu)
+    import torch
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    acc = m.accumulate(*batch_t(b, dev), nll=nll)
+    loss, gr = m._finalize(acc, True)
+    oloss, ogr = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
+    per = [O.nll_and_grads_single(p, b["delta"][s], b["error"][s], b["zabs"][s], b["mask"][s])[0] for s in range(B)]
+    assert np.max(np.abs(nll.cpu().numpy() - per) / np.abs(per)) < TOL_NLL
+    assert abs(loss.item() - oloss) / abs(oloss) < TOL_NLL
+    for k in KEYS:
+        ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
+        assert np.array_equal(np.isnan(ours), np.isnan(ref)), k
+        ok = ~np.isnan(ref)
+        if ok.any():
+            assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
+
+
+@pytest.mark.parametrize("B,npix,nh,seed", [(5, 200, 4, 11), (20, 900, 8, 12), (18, 640, 16, 13)])
+def test_predict_vs_oracle(dev, B, npix, nh, seed):
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=seed)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=200 + seed)
+    m = make_model(dev, p, mu)
+    ll, hm, hc, cont, unc = [x.cpu().numpy() for x in m.predict(*batch_t(b, dev, "flux"))]
+    for s in range(B):
+        o = O.predict_single(p, mu, b["flux"][s], b["error"][s], b["zabs"][s], b["mask"][s])
+        assert abs(ll[s] - o[0]) / abs(o[0]) < TOL_NLL
+        assert rel_l2(hm[s], o[1]) < 1e-4
+        assert rel_l2(hc[s], o[2]) < 1e-4
+        assert np.max(np.abs(cont[s] - o[3]) / np.abs(o[3])) < 1e-4
+        assert rel_l2(unc[s], o[4]) < 1e-4
+
+
+def test_all_spectra_masked_pixel_and_fully_masked_spectrum(dev):
+    """A spectrum with every pixel masked contributes NLL 0 (n = 0, C = I) and no gradient."""
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(300)
+    p, mu = synthetic.mock_parameters(300, nb, 8, seed=3)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 4, seed=31)
+    b["mask"][2, :] = False
+    m = make_model(dev, p, mu)
+    import torch
+    nll = torch.empty(4, dtype=torch.float32, device=dev)
+    acc = m.accumulate(*batch_t(b, dev), nll=nll)
+    assert nll[2].item() == 0.0
+    loss, gr = m._finalize(acc, True)
+    oloss, ogr = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
+    assert abs(loss.item() - oloss) / abs(oloss) < TOL_NLL
+    assert rel_l2(gr["Psi"].cpu().numpy(), ogr["Psi"]) < TOL_G["Psi"]
+
+
+def test_custom_tau_callable_goes_through_A_blue(dev, shipped, grid):
+    """An arbitrary tau callable (reference model.py:26,43) is evaluated on zabs and handed to the
+    kernels as exp(-tau): same answer as the built-in when the callable IS becker."""
+    import torch
+    from qfa_amd import synthetic
+    p, mu = shipped
+    wav, nb, nr = grid
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 6, seed=77)
+
+    def my_tau(z):
+        return 0.751 * ((1 + z) / 4.5) ** 2.90 - 0.132
+
+    m1 = make_model(dev, p, mu)
+    m2 = make_model(dev, p, mu, tau=my_tau)
+    l1, g1 = m1.forward(*batch_t(b, dev))
+    l2, g2 = m2.forward(*batch_t(b, dev))
+    assert abs(l1.item() - l2.item()) / abs(l1.item()) < 1e-5
+    for k in KEYS:
+        assert rel_l2(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-4, k
+    m3 = make_model(dev, p, mu, tau="kamble")
+    l3, _ = m3.forward(*batch_t(b, dev))
+    from oracle import qfa_oracle as O
+    ol3, _ = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"], tau_which="kamble")
+    assert abs(l3.item() - ol3) / abs(ol3) < TOL_NLL
+
+
+def test_loud_failures(dev):
+    import torch
+    from qfa_amd import QFA
+    from qfa_amd._lib import QFAHipError
+    with pytest.raises(QFAHipError):
+        QFA(10, 10, 4, torch.device("cpu"))
+    m = QFA(10, 10, 4, dev)
+    z = torch.zeros(2, 10, device=dev)
+    x = torch.ones(2, 20, device=dev)
+    with pytest.raises(QFAHipError):
+        m.forward(x, x, z, torch.ones(2, 20, device=dev))            # float mask (Q11)
+    with pytest.raises(QFAHipError):
+        m.forward(x, x, z[:, :5], torch.ones(2, 20, dtype=torch.bool, device=dev))
+    with pytest.raises(QFAHipError):
+        m.forward(x.cpu(), x, z, torch.ones(2, 20, dtype=torch.bool, device=dev))
+
+
+def test_full_size_properties_config2(dev):
+    """BASELINE config 2 size (10k x 2000, Nh=8, no masks): size-independent checks --
+    additivity of the packed sums over a split of the batch, per-spectrum NLL independent of
+    batch composition, and the oracle on a sample of spectra."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    npix, nh, B = 2000, 8, 10000
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=2)
+    d, e, z, mk = synthetic.make_batch_torch(p, mu, wav, nb, B, 20220702, dev, masks=False)
+    m = make_model(dev, p, mu)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    acc = m.accumulate(d, e, z, mk, nll=nll).clone()
+    h = B // 2 + 7
+    nll_a = torch.empty(h, dtype=torch.float32, device=dev)
+    acc_a = m.accumulate(d[:h], e[:h], z[:h], mk[:h], nll=nll_a).clone()
+    acc_b = m.accumulate(d[h:], e[h:], z[h:], mk[h:]).clone()
+    assert torch.equal(nll[:h], nll_a)                                   # bitwise: no cross-spectrum coupling
+    tot = acc_a + acc_b
+    assert rel_l2(tot.cpu().numpy(), acc.cpu().numpy()) < 2e-5          # atomics re-associate sums
+    assert acc[-3].item() == B
+    idx = [0, 1, 4999, 9999]
+    for s in idx:
+        o, _ = O.nll_and_grads_single(p, d[s].cpu().numpy(), e[s].cpu().numpy(), z[s].cpu().numpy(),
+                                      mk[s].cpu().numpy())
+        assert abs(nll[s].item() - o) / abs(o) < TOL_NLL
