@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the QFA hot path on MI355X: spectra/s per training ("EM") step.
+
+A step = QFA.forward (NLL + six gradient sums + counts over every resident spectrum) + the
+data-parallel all-reduce of the packed sum/count buffer (N > 1) + Adam.update + clip -- the
+reference's model.py:212-214 / :316 for one batch -- with the spectra already resident in HBM.
+
+Workload (BASELINE.json metric "spectra/sec per EM step (N_pix=4000, N_h=16)", configs[2]):
+100 000 synthetic spectra PER GPU (weak scaling), N_pix=4000 (N_b=1506), N_h=16, random pixel
+masks, per-z absorption noise; synthetic data drawn from the model itself (qfa_amd/synthetic.py,
+SURVEY.md 8(d)), seeds 20220702 + rank.  `--config c2` selects configs[1] (10k x 2000, N_h=8,
+no masks).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (pass 2, k_grads): its
+algorithmic flops over its mean duration measured with HIP events recorded by
+the library on the launch stream inside the timed region.  `cpu_baseline` times the dense
+O(N_pix^3) CPU port of the reference's per-spectrum step (oracle/dense_port.py) on a bounded
+sample of the same batch (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+CONFIGS = {
+    #        B/GPU   Npix  Nh  masks cpu_sample
+    "c2": (10000, 2000, 8, False, 32),
+    "c3": (100000, 4000, 16, True, 12),
+    "c1": (128, 1913, 8, True, 32),
+}
+PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def alg_flops(npix, k):
+    """7 n k^2 + 14 n k + 65 n + 3 k^3 per spectrum, split per kernel:
+    pass 1 (C, T, b, b2): 4nk^2 + 7nk + 30n + 3k^3; pass 2 (diag Sigma^-1, M Z, u): 3nk^2 + 7nk + 35n."""
+    p1 = 4 * npix * k * k + 7 * npix * k + 30 * npix + 3 * k ** 3
+    p2 = 3 * npix * k * k + 7 * npix * k + 35 * npix
+    return p1, p2
+
+
+def alg_bytes(npix, nb):
+    """delta, sigma (4 B), mask (1 B) per pixel, zabs (4 B) per blue pixel, NLL out."""
+    return npix * 9 + nb * 4 + 4
+
+
+def cpu_baseline(params, batch, n_sample, npix):
+    """Dense CPU port of the reference step on the first n_sample spectra of the batch."""
+    import numpy as np
+    import torch
+    from oracle import dense_port as DP
+    from oracle import qfa_oracle as O
+    d, e, z, m = [x[:n_sample].cpu() for x in batch]
+    P = DP.to_torch_params(params)
+    DP.dense_forward(P, d[:1], e[:1], z[:1], m[:1])                 # warm the thread pool
+    t0 = time.perf_counter()
+    loss, _ = DP.dense_forward(P, d, e, z, m)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    n_lr = min(n_sample, 8)
+    O.forward(params, d[:n_lr].numpy(), e[:n_lr].numpy(), z[:n_lr].numpy(), m[:n_lr].numpy())
+    dt_lr = (time.perf_counter() - t1) / n_lr
+    return {
+        "value": n_sample / dt, "unit": "spectra/s", "cores": int(torch.get_num_threads()), "kind": "port",
+        "sample": f"first {n_sample} spectra of the rank-0 batch, dense O(Npix^3) torch-CPU float32 port of "
+                  f"model.py:107-158 (oracle/dense_port.py), {dt:.1f} s wall, host has {os.cpu_count()} cpus",
+        "lowrank_oracle_spectra_per_s": 1.0 / dt_lr,
+        "loss_finite": bool(np.isfinite(float(loss))),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="spectra per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, npix, nh, masks, n_cpu = CONFIGS[args.config]
+    if args.batch:
+        B = args.batch
+    wav, nb, nr = synthetic.wavelength_grid(None if args.config == "c1" else npix)
+    npix = len(wav)
+    params, mu = synthetic.mock_parameters(npix, nb, nh, seed=20220700)
+    cfg_index = {"c1": 1, "c2": 2, "c3": 3}[args.config]
+    # generate in slabs to bound temporary memory
+    parts = []
+    slab = 25000
+    for i, s0 in enumerate(range(0, B, slab)):
+        n = min(slab, B - s0)
+        parts.append(synthetic.make_batch_torch(params, mu, wav, nb, n, 20220700 + cfg_index + 1000 * rank + 17 * i,
+                                                dev, masks=masks))
+    batch = tuple(torch.cat([p[j] for p in parts]) for j in range(4))
+    del parts
+    torch.cuda.empty_cache()
+
+    model = QFA(nb, nr, nh, dev, model_params=params)
+    model.mu = torch.tensor(mu, device=dev)
+    if world > 1:
+        model.enable_data_parallel()
+    opt = Adam(model.parameters, dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3, weight_decay=1e-1)
+
+    for _ in range(args.warmup):
+        model.step(opt, *batch)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    for es in evs:
+        for e in es:
+            e.record()          # creates the underlying hipEvent_t; re-recorded by the library
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = []
+    for i in range(args.steps):
+        losses.append(model.step(opt, *batch, events=evs[i]))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stage = np.array([[es[j].elapsed_time(es[j + 1]) for j in range(4)] for es in evs]).mean(axis=0)   # ms
+    ms_prep, ms_p1, ms_solve, ms_p2 = [float(x) for x in stage]
+    f1, f2 = alg_flops(npix, nh)
+    by = alg_bytes(npix, nb)
+    rate = world * B * args.steps / dt
+    rate_gpu = B * args.steps / dt
+    dominant = "k_grads" if ms_p2 >= ms_p1 else "k_moments"
+    dom_ms, dom_flops = (ms_p2, f2) if dominant == "k_grads" else (ms_p1, f1)
+    ach = dom_flops * B / (dom_ms * 1e-3) / 1e12
+    traffic = None
+    tfile = os.path.join(REPO, "profiles", f"traffic_{args.config}.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("B") == B:
+                traffic = tj.get(dominant + "_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "spectra/sec per EM step", "value": rate, "unit": "spectra/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {B} spectra/GPU x N_pix={npix} (N_b={nb}), N_h={nh}, "
+                               f"{'random pixel masks' if masks else 'no masks'}, becker tau, "
+                               f"forward + {'RCCL all-reduce + ' if world > 1 else ''}Adam + clip",
+                   "spectra_per_gpu": B, "n_pix": npix, "n_b": nb, "n_h": nh, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
+                     "kernel_ms": dom_ms, "alg_flops_per_spectrum": dom_flops},
+        "stage_ms": {"pf_image": ms_prep, "pass1_moments": ms_p1, "solve": ms_solve, "pass2_grads": ms_p2,
+                     "rest_of_step": dt / args.steps * 1e3 - float(stage.sum())},
+        "step_roofline": {"achieved_fp32_frac": rate_gpu * (f1 + f2) / (PEAK_FP32_TFLOPS * 1e12),
+                          "achieved_hbm_frac": rate_gpu * by / (PEAK_HBM_GBS * 1e9),
+                          "alg_flops_per_spectrum": f1 + f2, "alg_bytes_per_spectrum": by,
+                          "binding_roof": "fp32 (VALU + MFMA); HBM ceiling at this config is "
+                                          f"{100.0 * (PEAK_FP32_TFLOPS * 1e12 / (f1 + f2)) * by / (PEAK_HBM_GBS * 1e9):.1f}%"},
+        "loss": float(losses[-1].item()),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(params, batch, n_cpu, npix)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

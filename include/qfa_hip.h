@@ -89,6 +89,14 @@ int qfa_nll_grad_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_
                      float *nll, float *accum, void *workspace, size_t workspace_bytes,
                      void *stream);
 
+/* Same call with stage timing for benchmarks: `events` is NULL or an array of 5 hipEvent_t
+ * (entries may be NULL) recorded on `stream` at {start, after PF-image build, after pass 1
+ * (moments), after the k x k solve, after pass 2 (gradients)}. */
+int qfa_nll_grad_events_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau,
+                            int B, int Npix, int Nb, int Nh,
+                            float *nll, float *accum, void *workspace, size_t workspace_bytes,
+                            void *stream, void *const *events);
+
 /* Replaces the normalisation of QFA.forward (reference QFA/model.py:104): elementwise
  * grad = sum / count (0/0 = NaN), loss = sum_nll / n_spectra (model.py:100).  Reads `accum`
  * (after the optional all-reduce) and writes gradients with the reference's shapes.
@@ -109,10 +117,13 @@ int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b
 /* Replaces Adam.update (reference QFA/optimizer.py:37-52) followed by the clamp of QFA.clip
  * (QFA/model.py:233-241) for ONE tensor of n elements:
  *   g' = g + wd*p; m = (1-b1) g' + b1 m; v = (1-b2) g'^2 + b2 v;
- *   p_out = clamp(p - lr * (m/bc1) / (sqrt(v/bc2) + eps), lo, hi),  bc = 1 - b^(i+1).
- * m and v are updated in place; pass lo > hi to skip the clamp.  NaN propagates as in torch. */
+ *   p_out = clamp(p - lr * (m/bc1) / (sqrt(v/bc2) + eps), lo, hi),  bc = 1 - b^(i+1),
+ * with i = Adam.i (advanced by Adam.step(), once per epoch in QFA.train).  The hyper-parameters
+ * are doubles because the reference holds them as Python floats and rounds (1-b), b^(i+1) etc.
+ * to float32 only when they meet a tensor.  m and v are updated in place; pass lo > hi to skip
+ * the clamp.  NaN propagates as in torch. */
 int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float *p_out, size_t n,
-                      float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                      double lr, double b1, double b2, double eps, double wd, int i,
                       float lo, float hi, void *stream);
 
 /* Replaces QFA.clip for one tensor (reference QFA/model.py:233-241): y = clamp(x, lo, hi), NaN kept. */

@@ -9,11 +9,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqfa_hip.so")
+LIB_PATH = os.environ.get("QFA_HIP_LIB", os.path.join(_HERE, "libqfa_hip.so"))
 
 EXPORTS = (
     "qfa_abi_version", "qfa_tau_model", "qfa_workspace_bytes", "qfa_accum_floats",
-    "qfa_nll_grad_f32", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_adam_clip_f32",
+    "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_adam_clip_f32",
     "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32",
 )
 
@@ -52,17 +52,19 @@ def lib():
         h = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise QFAHipError(f"cannot load {LIB_PATH}: {e}") from e
-    p, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    p, i, f, d, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
     sigs = {
         "qfa_abi_version": (i, []),
         "qfa_tau_model": (i, [i, i, C.POINTER(TauModel)]),
         "qfa_workspace_bytes": (sz, [i, i, i]),
         "qfa_accum_floats": (sz, [i, i, i]),
         "qfa_nll_grad_f32": (i, [C.POINTER(Params), C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i, p, p, p, sz, p]),
+        "qfa_nll_grad_events_f32": (i, [C.POINTER(Params), C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i, p, p, p, sz,
+                                        p, C.POINTER(C.c_void_p)]),
         "qfa_finalize_grads_f32": (i, [p, p, i, i, i, i, p, p, p, p, p, p, p, p]),
         "qfa_predict_f32": (i, [C.POINTER(Params), p, C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i,
                                 p, p, p, p, p, p, sz, p]),
-        "qfa_adam_clip_f32": (i, [p, p, p, p, p, sz, f, f, f, f, f, f, f, f, f, p]),
+        "qfa_adam_clip_f32": (i, [p, p, p, p, p, sz, d, d, d, d, d, i, f, f, p]),
         "qfa_clip_f32": (i, [p, p, sz, f, f, p]),
         "qfa_smooth_f32": (i, [p, p, i, i, i, p]),
         "qfa_tau_f32": (i, [p, p, sz, C.POINTER(TauModel), p]),

@@ -52,9 +52,15 @@ struct DevConsts {
     float t_amp, t_lscale, t_expo, t_off;   // tau(z) = t_amp * 2^(t_expo (log2(1+z) + t_lscale)) + t_off
 };
 
+#ifdef QFA_PRECISE_MATH   // accuracy experiments only: libm-grade exp2/log2 and IEEE division
+__device__ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return log2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
 __device__ __forceinline__ float fast_exp(float x) { return fast_exp2(x * QFA_LOG2E); }
 __device__ __forceinline__ float fast_log(float x) { return fast_log2(x) * QFA_LN2; }
 

@@ -72,9 +72,13 @@ __global__ __launch_bounds__(256) void k_moments(qfa_params_t p, qfa_batch_t bt,
     for (int t = 0; t < C::NT; ++t) accC[t] = accT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < C::NFT; ++t) accb[t] = accb2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float qd = 0.f, ld = 0.f, cn = 0.f, cblue = 0.f;
+    // scalar sums: float32 inside a 4-pixel group, float64 across groups (a 1000-term float32
+    // chain of log D costs ~1e-5 of the NLL; this keeps it at the 1e-7 level for 1 DADD / 4 px)
+    double qd = 0.0, ld = 0.0;
+    float cn = 0.f, cblue = 0.f;
 
     for (int base = 0; base < Npix; base += 16) {
+        float qd4 = 0.f, ld4 = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int px = base + 4 * j + e;
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(256) void k_moments(qfa_params_t p, qfa_batch_t bt,
             d = w ? d : 0.f;
             const float wDA = wD * A;
             const float c2 = wDA * A, c3 = c2 * A, cb = wDA * d, cb2 = c2 * d;
-            qd += wD * d * d;
-            ld += w ? fast_log(D) : 0.f;
+            qd4 += wD * d * d;
+            ld4 += w ? fast_log(D) : 0.f;
             cn += w ? 1.f : 0.f;
             cblue += (w && blue) ? 1.f : 0.f;
             const float *pfrow = PF + (size_t)px * C::NCP + sl;     // px < NpixPad always
@@ -115,6 +119,8 @@ __global__ __launch_bounds__(256) void k_moments(qfa_params_t p, qfa_batch_t bt,
                 accT[t] = mfma4(c3, pb, accT[t]);
             }
         }
+        qd += (double)qd4;
+        ld += (double)ld4;
     }
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4j + r, column 16t + sl
 #pragma unroll
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void k_moments(qfa_params_t p, qfa_batch_t bt,
     cblue += __shfl_xor(cblue, 16); cblue += __shfl_xor(cblue, 32);
     if (j == 0 && svalid) {
         float *m = MOM + (size_t)s * C::NMOM + C::MOM_S;
-        m[0] = qd; m[1] = ld; m[2] = cn; m[3] = cblue;
+        m[0] = (float)qd; m[1] = (float)ld; m[2] = cn; m[3] = cblue;
     }
 }
 
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256) void k_grads(qfa_params_t p, qfa_batch_t bt, q
         rowN[r] = (size_t)(sv[r] ? s : B - 1) * Npix;
         rowB[r] = (size_t)(sv[r] ? s : B - 1) * Nb;
     }
-    float s_tau0 = 0.f, s_c0 = 0.f, s_beta = 0.f;
+    double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;   // float32 per tile, float64 across tiles
     const int ntiles = NpixPad / 16;
     const int rot = (int)(((unsigned)tile * 2654435761u) % (unsigned)ntiles);   // de-phase the atomics
 
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(256) void k_grads(qfa_params_t p, qfa_batch_t bt, q
         const float om = blue ? p.omega[pxc] : 0.f;
         float betaR[4], gamR[4];
         float gPsi = 0.f, gOm = 0.f, sA = 0.f, cnt = 0.f;
+        float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float d = bt.delta[rowN[r] + pxc];
@@ -382,14 +389,17 @@ __global__ __launch_bounds__(256) void k_grads(qfa_params_t p, qfa_batch_t bt, q
             gOm += dG * zd;                                        // :140
             const float root = 1.0f - k.tau0 * pw - k.c0;          // :141
             const float e = dG * (om * zd) * zd * 2.0f * root;
-            s_tau0 -= e * pw;                                      // :142
-            s_beta -= e * (k.tau0 * pw * (l2 * QFA_LN2));          // :143
-            s_c0 -= e;                                             // :144
+            t_tau0 -= e * pw;                                      // :142
+            t_beta -= e * (k.tau0 * pw * (l2 * QFA_LN2));          // :143
+            t_c0 -= e;                                             // :144
             cnt += w ? 1.f : 0.f;
             betaR[r] = wDA * A;
             sA += betaR[r] * A;
             gamR[r] = A * u;
         }
+        s_tau0 += (double)t_tau0;
+        s_c0 += (double)t_c0;
+        s_beta += (double)t_beta;
         // ---- stage 3
         f32x4 aG = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -423,9 +433,9 @@ __global__ __launch_bounds__(256) void k_grads(qfa_params_t p, qfa_batch_t bt, q
         s_beta += __shfl_xor(s_beta, o);
     }
     if (lane == 0) {
-        atomicAdd(accS + 0, s_tau0);
-        atomicAdd(accS + 1, s_c0);
-        atomicAdd(accS + 2, s_beta);
+        atomicAdd(accS + 0, (float)s_tau0);
+        atomicAdd(accS + 1, (float)s_c0);
+        atomicAdd(accS + 2, (float)s_beta);
     }
 }
 
@@ -509,16 +519,16 @@ __global__ void k_finalize(const float *__restrict__ accum, const float *__restr
 // ------------------------------------------------------------------------------------------------
 __global__ void k_adam_clip(const float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, float *__restrict__ pout, size_t n, float lr, float b1, float b2,
-                            float eps, float wd, float bc1, float bc2, float lo, float hi) {
+                            float omb1, float omb2, float eps, float wd, float bc1, float bc2, float lo, float hi) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float pi = p[i];
     const float gi = g[i] + wd * pi;
-    const float mi = (1.f - b1) * gi + b1 * m[i];
-    const float vi = (1.f - b2) * gi * gi + b2 * v[i];
+    const float mi = omb1 * gi + b1 * m[i];
+    const float vi = omb2 * gi * gi + b2 * v[i];
     m[i] = mi;
     v[i] = vi;
-    float q = pi - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    float q = pi - lr * (mi / bc1) / (__fsqrt_rn(vi / bc2) + eps);
     if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);   // NaN stays NaN, like torch.clip
     pout[i] = q;
 }
@@ -689,22 +699,30 @@ inline int hip_status() {
 
 template <int KP>
 int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                 float *nll, float *accum, float *ws, hipStream_t st) {
+                 float *nll, float *accum, float *ws, hipStream_t st, void *const *events) {
     using C = Cfg<KP>;
     const Layout L = make_layout_t<KP>(B, Npix);
     float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL;
     float *nllbuf = nll ? nll : ws + L.oNLL;
     const size_t accS = (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
+    auto mark = [&](int i) {
+        if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
+    };
+    mark(0);
     {
         dim3 blk(64, 4);
         k_prep_pf<KP><<<(L.NpixPad + 3) / 4, blk, 0, st>>>(p.F, Npix, Nh, L.NpixPad, PF, PFT);
     }
+    mark(1);
     const int tiles = (B + 15) / 16;
     k_moments<KP, false><<<(tiles + 3) / 4, 256, 0, st>>>(p, b, tau, nullptr, B, Npix, Nb, PF, MOM);
+    mark(2);
     constexpr int G = 64 / KP;
     k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, B, Nh, nullptr, nullptr);
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, MOM, C::NMOM, C::MOM_S + 3, B, accum + accS);
+    mark(3);
     k_grads<KP><<<(tiles + 3) / 4, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.NpixPad, PF, PFT, SOL, accum);
+    mark(4);
     return hip_status();
 }
 
@@ -760,8 +778,18 @@ size_t qfa_accum_floats(int Npix, int Nb, int Nh) {
     return (size_t)Npix * Nh + 3 * (size_t)Npix + (size_t)Nb + 8;
 }
 
+int qfa_nll_grad_events_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix,
+                            int Nb, int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes,
+                            void *stream, void *const *events);
+
 int qfa_nll_grad_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix, int Nb,
                      int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes, void *stream) {
+    return qfa_nll_grad_events_f32(p, b, tau, B, Npix, Nb, Nh, nll, accum, workspace, workspace_bytes, stream, nullptr);
+}
+
+int qfa_nll_grad_events_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix,
+                            int Nb, int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes,
+                            void *stream, void *const *events) {
     if (!p || !b || !tau || !accum || !workspace) return QFA_E_NULL;
     if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
     if (!b->delta || !b->error || !b->mask || (Nb > 0 && !b->zabs)) return QFA_E_NULL;
@@ -769,8 +797,8 @@ int qfa_nll_grad_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_
     if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st);
-    return run_nll_grad<16>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st);
+    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events);
+    return run_nll_grad<16>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events);
 }
 
 int qfa_finalize_grads_f32(const float *accum, const float *F, int Npix, int Nb, int Nh, int normalize, float *gF,
@@ -798,12 +826,17 @@ int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b
     return run_predict<16>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st);
 }
 
-int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float *p_out, size_t n, float lr, float b1,
-                      float b2, float eps, float wd, float bc1, float bc2, float lo, float hi, void *stream) {
+int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float *p_out, size_t n, double lr, double b1,
+                      double b2, double eps, double wd, int i, float lo, float hi, void *stream) {
     if (!p || !g || !m || !v || !p_out) return QFA_E_NULL;
     if (n == 0) return 0;
-    k_adam_clip<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, p_out, n, lr, b1, b2, eps,
-                                                                             wd, bc1, bc2, lo, hi);
+    if (i < 0) return QFA_E_SIZE;
+    // The reference mixes Python floats (double) with float32 tensors: every scalar below is
+    // formed in double and rounded to float32 once, exactly where torch would round it.
+    const float bc1 = (float)(1.0 - pow(b1, (double)(i + 1))), bc2 = (float)(1.0 - pow(b2, (double)(i + 1)));
+    k_adam_clip<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        p, g, m, v, p_out, n, (float)lr, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps,
+        (float)wd, bc1, bc2, lo, hi);
     return hip_status();
 }
 

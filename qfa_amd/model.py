@@ -197,17 +197,22 @@ class QFA(object):
         self._dp = True
         self._dp_group = group
 
-    def accumulate(self, delta, error, zabs, mask, accum=None, nll=None):
-        """Raw sums of one (shard of a) batch into the packed buffer; no normalisation."""
+    def accumulate(self, delta, error, zabs, mask, accum=None, nll=None, events=None):
+        """Raw sums of one (shard of a) batch into the packed buffer; no normalisation.
+        ``events``: optional list of 5 recorded torch.cuda.Event(enable_timing=True) that the library
+        re-records at {start, PF image, pass 1, solve, pass 2} on the current stream (bench.py)."""
         B = self._check_batch_shapes(delta, error, zabs, mask)
         ps = self._params_struct()
         bs, keep = self._batch_struct(delta, error, zabs, mask)
         ws = self._workspace(B)
         acc = self._accum() if accum is None else accum
-        _lib.check(_lib.lib().qfa_nll_grad_f32(
+        evs = None
+        if events is not None:
+            evs = (C.c_void_p * 5)(*[C.c_void_p(e.cuda_event) for e in events])
+        _lib.check(_lib.lib().qfa_nll_grad_events_f32(
             C.byref(ps), C.byref(bs), C.byref(self._tau_model), B, self.Npix, self.Nb, self.Nh,
             C.c_void_p(nll.data_ptr()) if nll is not None else None, C.c_void_p(acc.data_ptr()),
-            C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream(self.device)), "qfa_nll_grad_f32")
+            C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream(self.device), evs), "qfa_nll_grad_f32")
         return acc
 
     def _finalize(self, acc, normalize=True):
@@ -227,9 +232,10 @@ class QFA(object):
         return loss, g
 
     # ------------------------------------------------------------------ reference surface
-    def forward(self, delta: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor):
+    def forward(self, delta: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor,
+                events=None):
         """Batch loss (1,1) and count-normalised gradient dict (reference QFA/model.py:74-105)."""
-        acc = self.accumulate(delta, error, zabs, mask)
+        acc = self.accumulate(delta, error, zabs, mask, events=events)
         if self._dp:
             import torch.distributed as dist
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self._dp_group)
@@ -269,10 +275,10 @@ class QFA(object):
         ll, hmean, hcov, cont, unc = self.predict(flux[None, :], error[None, :], zabs[None, :], mask[None, :])
         return ll.reshape(1, 1), hmean.reshape(self.Nh, 1), hcov[0], cont[0], unc[0]
 
-    def step(self, optimizer, delta, error, zabs, mask):
+    def step(self, optimizer, delta, error, zabs, mask, events=None):
         """forward -> Adam.update -> clip, all on device, no host sync (model.py:212-214, 316).
         Returns the (1,1) loss tensor."""
-        loss, grads = self.forward(delta, error, zabs, mask)
+        loss, grads = self.forward(delta, error, zabs, mask, events=events)
         new = optimizer.update(self.parameters, grads, clip=self._clip_table())
         for k in PARAM_KEYS:
             setattr(self, k, new[k])

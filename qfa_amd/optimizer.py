@@ -55,8 +55,6 @@ class Adam(object):
         ``QFA.parameters`` setter clips afterwards."""
         h = _lib.lib()
         lr = float(self.scheduled_lr)
-        bc1 = 1.0 - self.b1 ** (self.i + 1)
-        bc2 = 1.0 - self.b2 ** (self.i + 1)
         out = {}
         for k in params:
             p = params[k]
@@ -71,7 +69,7 @@ class Adam(object):
             lo, hi = clip[k] if (clip is not None and k in clip) else (1.0, 0.0)
             _lib.check(h.qfa_adam_clip_f32(pp, gp, C.c_void_p(self.m[k].data_ptr()), C.c_void_p(self.v[k].data_ptr()),
                                            C.c_void_p(q.data_ptr()), p.numel(), lr, self.b1, self.b2, self.eps,
-                                           self.weight_decay, bc1, bc2, lo, hi, _lib.current_stream(p.device)),
+                                           self.weight_decay, int(self.i), lo, hi, _lib.current_stream(p.device)),
                        "qfa_adam_clip_f32")
             out[k] = q
         return out

@@ -52,7 +52,7 @@ def test_host_only_entry_points():
     assert h.qfa_workspace_bytes(4, 100, 33) == 0
     # argument validation happens before any device work
     assert h.qfa_nll_grad_f32(None, None, None, 1, 1, 1, 1, None, None, None, 0, None) == -1
-    assert h.qfa_adam_clip_f32(None, None, None, None, None, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, None) == -1
+    assert h.qfa_adam_clip_f32(None, None, None, None, None, 4, 0, 0, 0, 0, 0, 0, 0, 0, None) == -1
 
 
 def test_python_surface_matches_reference_names():
@@ -63,7 +63,7 @@ def test_python_surface_matches_reference_names():
                  "train", "clip", "smooth", "save_to_npz", "load_from_npz", "random_init_func", "parameters",
                  "fit", "predict"):
         assert hasattr(model.QFA, name), name
-    assert list(inspect.signature(model.QFA.forward).parameters)[1:] == ["delta", "error", "zabs", "mask"]
+    assert list(inspect.signature(model.QFA.forward).parameters)[1:5] == ["delta", "error", "zabs", "mask"]
     assert list(inspect.signature(model.QFA.train).parameters)[1:] == [
         "optimizer", "dataloader", "n_epochs", "output_dir", "save_interval", "smooth_interval", "quiet", "logger"]
     assert model.QFAModel is model.QFA
