@@ -237,8 +237,8 @@ class QFA(object):
         """Batch loss (1,1) and count-normalised gradient dict (reference QFA/model.py:74-105)."""
         acc = self.accumulate(delta, error, zabs, mask, events=events)
         if self._dp:
-            import torch.distributed as dist
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self._dp_group)
+            from .distributed import all_reduce_accum
+            all_reduce_accum(acc, self._dp_group)
         return self._finalize(acc, True)
 
     def loglikelihood_and_gradient_for_single_spectra(self, delta, error, zabs, mask):
