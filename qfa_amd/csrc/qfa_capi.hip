@@ -1,0 +1,292 @@
+// qfa_capi.hip -- C-ABI of libqfa_hip.so (include/qfa_hip.h): argument checks, workspace layout,
+// launch geometry.  Kernels live in qfa_step_kernels.h (hot path) and qfa_small_kernels.h.
+#include "qfa_step_kernels.h"
+#include "qfa_small_kernels.h"
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+namespace {
+
+const double kLymanF[30] = {4.1620e-01, 7.9140e-02, 2.9010e-02, 1.3950e-02, 7.8030e-03, 4.8160e-03, 3.1850e-03,
+                            2.2170e-03, 1.6060e-03, 1.2010e-03, 9.2190e-04, 7.2310e-04, 5.7770e-04, 4.6890e-04,
+                            3.8580e-04, 3.2120e-04, 2.7030e-04, 2.2970e-04, 1.9680e-04, 1.6990e-04, 1.4770e-04,
+                            1.2930e-04, 1.1370e-04, 1.0060e-04, 8.9360e-05, 7.9780e-05, 7.1480e-05, 6.4350e-05,
+                            5.8120e-05, 5.2640e-05};
+const double kLymanLam[30] = {1215.6701, 1025.7222, 972.5367, 949.7430, 937.8034, 930.7482, 926.2256, 923.1503,
+                              920.9630,  919.3513,  918.1293, 917.1805, 916.4291, 915.8238, 915.3289, 914.9192,
+                              914.5762,  914.2861,  914.0385, 913.8256, 913.6411, 913.4803, 913.3391, 913.2146,
+                              913.1042,  913.0059,  912.9179, 912.8389, 912.7676, 912.7032};
+
+inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
+
+// Pixel-axis segmentation (grid.y): both passes run (#spectra tiles / 4) x nseg workgroups.  nseg is
+// the smallest split that fills the resident-workgroup slots of the chip to >= 90 % in the last
+// round (tail quantisation) -- it also lets small batches use every CU.
+constexpr int kMaxSeg = 8;
+
+inline int pick_nseg(int B, int ntiles) {
+    const int slots = 256 * 2;                      // CUs x resident 256-thread workgroups per CU
+    const int nblk = (B + 63) / 64;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int n = 1; n <= kMaxSeg; ++n) {
+        if (n > 1 && ntiles / n < 8) break;         // keep segments >= 128 px
+        const double x = (double)nblk * n / slots;
+        const double eff = x / (double)(long long)(x + 0.999999);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = n; }
+        if (eff >= 0.9) { best = n; break; }
+    }
+    return best;
+}
+
+struct Layout {
+    int KP, NpixPad, ntiles, Bpad, nseg, seg_tiles;
+    size_t oPF, oPFT, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
+};
+
+template <int KP>
+Layout make_layout_t(int B, int Npix) {
+    using C = Cfg<KP>;
+    Layout L;
+    L.KP = KP;
+    L.NpixPad = round_up(Npix, 16);
+    L.ntiles = L.NpixPad / 16;
+    L.Bpad = round_up(B, 16);
+    L.nseg = pick_nseg(B, L.ntiles);
+    L.seg_tiles = (L.ntiles + L.nseg - 1) / L.nseg;
+    L.nseg = (L.ntiles + L.seg_tiles - 1) / L.seg_tiles;          // no empty segment
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
+    L.oPF = take((size_t)L.ntiles * C::TILE_PF);
+    L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
+    L.oMOM = take((size_t)kMaxSeg * L.Bpad * C::NMOM);
+    L.oSOL = take((size_t)L.Bpad * C::NSOL);
+    L.oNLL = take((size_t)L.Bpad);
+    L.oNBL = take((size_t)L.Bpad);
+    L.total = o;
+    return L;
+}
+
+Layout make_layout(int B, int Npix, int Nh) {
+    switch (kp_for(Nh)) {
+        case 8: return make_layout_t<8>(B, Npix);
+        default: return make_layout_t<16>(B, Npix);
+    }
+}
+
+inline int check_shape(int B, int Npix, int Nb, int Nh) {
+    if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || Nh < 1 || Nh > 16) return QFA_E_SIZE;
+    if ((long long)16 * Npix >= (1LL << 31)) return QFA_E_SIZE;
+    return 0;
+}
+
+inline int hip_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+template <int KP>
+void launch_prep(const qfa_params_t &p, int Npix, int Nb, int Nh, const Layout &L, float *PF, float *PFT,
+                 hipStream_t st) {
+    dim3 blk(64, 4);
+    k_prep_pf<KP><<<(L.NpixPad + 3) / 4, blk, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, L.NpixPad, PF, PFT);
+}
+
+template <int KP>
+void sum_segments(float *MOM, const Layout &L, hipStream_t st) {
+    if (L.nseg <= 1) return;
+    const size_t n4 = (size_t)L.Bpad * Cfg<KP>::NMOM / 4;      // Bpad*NMOM is a multiple of 4
+    k_sum_segments<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(reinterpret_cast<float4 *>(MOM), L.nseg, n4);
+}
+
+template <int KP>
+int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                 float *nll, float *accum, float *ws, hipStream_t st, void *const *events) {
+    const Layout L = make_layout_t<KP>(B, Npix);
+    float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL, *NBL = ws + L.oNBL;
+    float *nllbuf = nll ? nll : ws + L.oNLL;
+    const size_t accS = (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
+    auto mark = [&](int i) {
+        if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
+    };
+    mark(0);
+    launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
+    mark(1);
+    const dim3 grid((B + 63) / 64, L.nseg);
+    k_moments<KP, false><<<grid, 256, 0, st>>>(p, b, tau, nullptr, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, PF, MOM);
+    mark(2);
+    sum_segments<KP>(MOM, L, st);
+    constexpr int G = 64 / KP;
+    k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, 1, L.Bpad, SOL, nllbuf, NBL, B, Nh, nullptr,
+                                                                 nullptr);
+    k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
+    mark(3);
+    k_grads<KP><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, PFT, SOL, accum);
+    mark(4);
+    return hip_status();
+}
+
+template <int KP>
+int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
+                int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
+                hipStream_t st) {
+    const Layout L = make_layout_t<KP>(B, Npix);
+    float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL;
+    launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
+    const dim3 grid((B + 63) / 64, L.nseg);
+    k_moments<KP, true><<<grid, 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, PF, MOM);
+    sum_segments<KP>(MOM, L, st);
+    constexpr int G = 64 / KP;
+    k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, 1, L.Bpad, SOL, ll, nullptr, B, Nh, hmean, hcov);
+    k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);
+    return hip_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int qfa_abi_version(void) { return QFA_ABI_VERSION; }
+
+int qfa_tau_model(int which, int series, qfa_tau_t *out) {
+    if (!out) return QFA_E_NULL;
+    if (series < 1 || series > 30) return QFA_E_TAU;
+    const double coeff = kLymanLam[series - 1] * kLymanF[series - 1] / (kLymanLam[0] * kLymanF[0]);
+    double amp, scale, expo, off;
+    switch (which) {
+        case QFA_TAU_BECKER: amp = 0.751; scale = 1.0 / 4.5; expo = 2.90; off = -0.132; break;
+        case QFA_TAU_FG: amp = 0.0018; scale = 1.0; expo = 3.92; off = 0.0; break;
+        case QFA_TAU_KAMBLE: amp = 5.54e-3; scale = 1.0; expo = 3.182; off = 0.0; break;
+        case QFA_TAU_MOCK: amp = 0.2231435513142097; scale = 1.0 / 3.25; expo = 3.2; off = 0.0; break;
+        default: return QFA_E_TAU;
+    }
+    out->amp = (float)(amp * coeff);
+    out->scale = (float)scale;
+    out->expo = (float)expo;
+    out->offset = (float)(off * coeff);
+    return 0;
+}
+
+size_t qfa_workspace_bytes(int B, int Npix, int Nh) {
+    if (B < 1 || Npix < 1 || Nh < 1 || Nh > 16) return 0;
+    return make_layout(B, Npix, Nh).total * sizeof(float);
+}
+
+size_t qfa_accum_floats(int Npix, int Nb, int Nh) {
+    return (size_t)Npix * Nh + 3 * (size_t)Npix + (size_t)Nb + 8;
+}
+
+int qfa_nll_grad_events_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix,
+                            int Nb, int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes,
+                            void *stream, void *const *events);
+
+int qfa_nll_grad_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix, int Nb,
+                     int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes, void *stream) {
+    return qfa_nll_grad_events_f32(p, b, tau, B, Npix, Nb, Nh, nll, accum, workspace, workspace_bytes, stream, nullptr);
+}
+
+int qfa_nll_grad_events_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix,
+                            int Nb, int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes,
+                            void *stream, void *const *events) {
+    if (!p || !b || !tau || !accum || !workspace) return QFA_E_NULL;
+    if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
+    if (!b->delta || !b->error || !b->mask || (Nb > 0 && !b->zabs)) return QFA_E_NULL;
+    if (int e = check_shape(B, Npix, Nb, Nh)) return e;
+    if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events);
+    return run_nll_grad<16>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events);
+}
+
+int qfa_finalize_grads_f32(const float *accum, const float *F, int Npix, int Nb, int Nh, int normalize, float *gF,
+                           float *gPsi, float *gOmega, float *gTau0, float *gC0, float *gBeta, float *loss,
+                           void *stream) {
+    if (!accum || !F || !gF || !gPsi || !gTau0 || !gC0 || !gBeta || !loss || (Nb > 0 && !gOmega)) return QFA_E_NULL;
+    if (int e = check_shape(1, Npix, Nb, Nh)) return e;
+    const size_t n = (size_t)Npix * Nh;
+    k_finalize<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(accum, F, Npix, Nb, Nh, normalize, gF, gPsi,
+                                                                            gOmega, gTau0, gC0, gBeta, loss);
+    return hip_status();
+}
+
+int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b, const qfa_tau_t *tau, int B,
+                    int Npix, int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc,
+                    void *workspace, size_t workspace_bytes, void *stream) {
+    if (!p || !b || !tau || !mu || !ll || !hmean || !hcov || !cont || !unc || !workspace) return QFA_E_NULL;
+    if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
+    if (!b->delta || !b->error || !b->mask || (Nb > 0 && !b->zabs)) return QFA_E_NULL;
+    if (int e = check_shape(B, Npix, Nb, Nh)) return e;
+    if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    if (kp_for(Nh) == 8) return run_predict<8>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st);
+    return run_predict<16>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st);
+}
+
+int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float *p_out, size_t n, double lr, double b1,
+                      double b2, double eps, double wd, int i, float lo, float hi, void *stream) {
+    if (!p || !g || !m || !v || !p_out) return QFA_E_NULL;
+    if (n == 0) return 0;
+    if (i < 0) return QFA_E_SIZE;
+    // The reference mixes Python floats (double) with float32 tensors: every scalar below is
+    // formed in double and rounded to float32 once, exactly where torch would round it.
+    const float bc1 = (float)(1.0 - pow(b1, (double)(i + 1))), bc2 = (float)(1.0 - pow(b2, (double)(i + 1)));
+    k_adam_clip<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        p, g, m, v, p_out, n, (float)lr, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps,
+        (float)wd, bc1, bc2, lo, hi);
+    return hip_status();
+}
+
+int qfa_clip_f32(const float *x, float *y, size_t n, float lo, float hi, void *stream) {
+    if (!x || !y) return QFA_E_NULL;
+    if (n == 0) return 0;
+    k_clip<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, lo, hi);
+    return hip_status();
+}
+
+int qfa_smooth_f32(const float *x, float *y, int n, int cols, int half, void *stream) {
+    if (!x || !y) return QFA_E_NULL;
+    if (n < 1 || cols < 1 || half < 0) return QFA_E_SIZE;
+    const size_t tot = (size_t)n * cols;
+    k_smooth<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, cols, half);
+    return hip_status();
+}
+
+int qfa_tau_f32(const float *z, float *out, size_t n, const qfa_tau_t *tau, void *stream) {
+    if (!z || !out || !tau) return QFA_E_NULL;
+    if (n == 0) return 0;
+    k_tau<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(z, out, n, *tau);
+    return hip_status();
+}
+
+int qfa_tauhi_f32(const float *z, const float *tau0, const float *beta, float *out, size_t n, void *stream) {
+    if (!z || !out || !tau0 || !beta) return QFA_E_NULL;
+    if (n == 0) return 0;
+    k_tauhi<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(z, tau0, beta, out, n);
+    return hip_status();
+}
+
+int qfa_omega_func_f32(const float *z, const float *tau0, const float *beta, const float *c0, float *out, size_t n,
+                       void *stream) {
+    if (!z || !out || !tau0 || !beta || !c0) return QFA_E_NULL;
+    if (n == 0) return 0;
+    k_omega_func<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(z, tau0, beta, c0, out, n);
+    return hip_status();
+}
+
+int qfa_woodbury_f32(const float *M, const float *D, int n, int k, float *inv, float *logdet, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+    if (!M || !D || !workspace || (!inv && !logdet)) return QFA_E_NULL;
+    if (n < 1 || k < 1 || k > 32) return QFA_E_SIZE;
+    if (workspace_bytes < (size_t)(k * k + 1) * sizeof(double)) return QFA_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double *core = (double *)workspace;
+    k_wood_core<<<1, 1024, (size_t)k * k * sizeof(double), st>>>(M, D, n, k, core);
+    const size_t tot = inv ? (size_t)n * n : 1;
+    k_wood_inv<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(M, D, n, k, core, inv, logdet);
+    return hip_status();
+}
+
+}  // extern "C"

@@ -29,8 +29,17 @@ struct Cfg {
     static constexpr int NT = (KK2 + 15) / 16;          // 16-column tiles of the pair part
     static constexpr int PW = NT * 16;                  // padded pair width
     static constexpr int NFT = FW / 16;                 // 16-column tiles of the F part
-    static constexpr int NCP = FW + PW;                 // PF row stride (floats)
-    static constexpr int NCT = KP + KK2;                // rows of the transposed image PFT
+    // PF image (pass 1): row i = [f_i (FW) | f_ia f_ib (PW) | Psi_i, omega_i, 0, 0].  The stride is
+    // 4 mod 8 floats so that the B-operand read of lane (j, col) at row 4j+e hits 32 distinct
+    // LDS banks per half-wave (4*NCPL = 16 mod 32).
+    static constexpr int PF_PSI = FW + PW;
+    static constexpr int NCPL = FW + PW + 4;
+    static constexpr int TILE_PF = 16 * NCPL;           // floats per 16-pixel tile (contiguous)
+    // PFT image (pass 2), tile-major: tile t = [row c][16 px]; rows [0,KP) = F^T, [KP,KP+KK2) =
+    // pair products, then Psi, omega, zero padding to a multiple of 4 rows.
+    static constexpr int PFT_PSI = KP + KK2;
+    static constexpr int NR = (KP + KK2 + 2 + 3) / 4 * 4;
+    static constexpr int TILE_PFT = NR * 16;
     // per-spectrum moment record: [C PW][T PW][b FW][b2 FW][qd, ld, n, nblue]
     static constexpr int NMOM = 2 * PW + 2 * FW + 4;
     static constexpr int MOM_T = PW, MOM_B = 2 * PW, MOM_B2 = 2 * PW + FW, MOM_S = 2 * PW + 2 * FW;
@@ -80,9 +89,20 @@ __device__ __forceinline__ BlueTerms blue_terms(float z, const DevConsts &k) {
     return t;
 }
 
+#ifndef QFA_ABL
+#define QFA_ABL 0          // timing-only ablation builds (tools/ablate.sh); 0 = product
+#endif
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+#if QFA_ABL == 1           // no MFMA: keep operands alive, one VALU op instead
+    asm volatile("" ::"v"(a), "v"(b));
+    c[0] += a;
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
+
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 __device__ __forceinline__ DevConsts load_consts(const qfa_params_t &p, const qfa_tau_t &tau) {
     DevConsts k;

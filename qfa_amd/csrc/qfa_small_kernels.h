@@ -1,0 +1,158 @@
+// qfa_small_kernels.h -- normalisation, optimiser, parameter maintenance and public helper kernels.
+#pragma once
+#include "qfa_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// k_finalize : grad = sum / count, elementwise, 0/0 = NaN (QFA/model.py:104); loss = sum NLL / B.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_finalize(const float *__restrict__ accum, const float *__restrict__ F, int Npix, int Nb, int Nh,
+                           int normalize, float *__restrict__ gF, float *__restrict__ gPsi, float *__restrict__ gOm,
+                           float *__restrict__ gTau0, float *__restrict__ gC0, float *__restrict__ gBeta,
+                           float *__restrict__ loss) {
+    const float *accF = accum;
+    const float *accA = accF + (size_t)Npix * Nh;
+    const float *accPsi = accA + Npix;
+    const float *accOm = accPsi + Npix;
+    const float *accCnt = accOm + Nb;
+    const float *accS = accCnt + Npix;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)Npix * Nh) {
+        const int i = (int)(idx / Nh);
+        const float v = F[idx] * accA[i] - accF[idx];
+        gF[idx] = normalize ? v / accCnt[i] : v;
+    }
+    if (idx < (size_t)Npix) gPsi[idx] = normalize ? accPsi[idx] / accCnt[idx] : accPsi[idx];
+    if (idx < (size_t)Nb) gOm[idx] = normalize ? accOm[idx] / accCnt[idx] : accOm[idx];
+    if (idx == 0) {
+        const float cs = normalize ? accS[3] : 1.f;
+        *gTau0 = accS[0] / cs;
+        *gC0 = accS[1] / cs;
+        *gBeta = accS[2] / cs;
+        *loss = normalize ? accS[4] / accS[5] : accS[4];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_adam_clip : Adam.update + clip for one tensor (QFA/optimizer.py:47-52, QFA/model.py:237-241)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_adam_clip(const float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, float *__restrict__ pout, size_t n, float lr, float b1, float b2,
+                            float omb1, float omb2, float eps, float wd, float bc1, float bc2, float lo, float hi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float pi = p[i];
+    const float gi = g[i] + wd * pi;
+    const float mi = omb1 * gi + b1 * m[i];
+    const float vi = omb2 * gi * gi + b2 * v[i];
+    m[i] = mi;
+    v[i] = vi;
+    float q = pi - lr * (mi / bc1) / (__fsqrt_rn(vi / bc2) + eps);
+    if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);   // NaN stays NaN, like torch.clip
+    pout[i] = q;
+}
+
+__global__ void k_clip(const float *__restrict__ x, float *__restrict__ y, size_t n, float lo, float hi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float q = x[i];
+        y[i] = q < lo ? lo : (q > hi ? hi : q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_smooth : edge-aware moving average along axis 0 (QFA/model.py:243-252)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_smooth(const float *__restrict__ x, float *__restrict__ y, int n, int cols, int half) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * cols) return;
+    const int i = (int)(idx / cols), c = (int)(idx % cols);
+    const int lo = i - half < 0 ? 0 : i - half;
+    const int hi = i + half + 1 > n ? n : i + half + 1;
+    float acc = 0.f;
+    for (int r = lo; r < hi; ++r) acc += x[(size_t)r * cols + c];
+    y[idx] = acc / (float)(hi - lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise optical-depth helpers (QFA/utils.py:57-92, 149-171)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_tau(const float *__restrict__ z, float *__restrict__ out, size_t n, qfa_tau_t t) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = t.amp * powf((1.0f + z[i]) * t.scale, t.expo) + t.offset;
+}
+__global__ void k_tauhi(const float *__restrict__ z, const float *tau0, const float *beta, float *__restrict__ out,
+                        size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = *tau0 * powf(1.0f + z[i], *beta);
+}
+__global__ void k_omega_func(const float *__restrict__ z, const float *tau0, const float *beta, const float *c0,
+                             float *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float r = 1.0f - *c0 - expf(-(*tau0 * powf(1.0f + z[i], *beta)));
+        out[i] = r * r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Woodbury utilities for one (n,k) M and (n,) D (QFA/utils.py:12-54): small, generic, fp64 core.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_wood_core(const float *__restrict__ M, const float *__restrict__ D, int n,
+                                                    int k, double *__restrict__ core /* k*k + 1 */) {
+    extern __shared__ double sh[];   // k*k
+    const int t = threadIdx.x;
+    if (t < k * k) {
+        const int a = t / k, b = t % k;
+        double acc = a == b ? 1.0 : 0.0;
+        for (int i = 0; i < n; ++i) acc += (double)M[(size_t)i * k + a] * (double)M[(size_t)i * k + b] / (double)D[i];
+        sh[t] = acc;
+    }
+    __syncthreads();
+    // sum log D on all threads
+    double ld = 0.0;
+    for (int i = t; i < n; i += blockDim.x) ld += log((double)D[i]);
+    for (int o = 32; o >= 1; o >>= 1) ld += __shfl_xor(ld, o);
+    __shared__ double shl[16];
+    if ((t & 63) == 0) shl[t >> 6] = ld;
+    __syncthreads();
+    double logdet = 0.0;
+    for (int jj = 0; jj < k; ++jj) {           // in-place Gauss-Jordan, threads over (i, c)
+        const double piv = sh[jj * k + jj];
+        __syncthreads();
+        double nv = 0.0;
+        const int i = t / k, c = t % k;
+        if (t < k * k) {
+            const double ip = 1.0 / piv;
+            const double aij = sh[i * k + jj], ajc = sh[jj * k + c];
+            if (i == jj) nv = (c == jj) ? ip : ajc * ip;
+            else nv = (c == jj) ? -aij * ip : sh[t] - aij * ajc * ip;
+        }
+        logdet += log(piv);
+        __syncthreads();
+        if (t < k * k) sh[t] = nv;
+        __syncthreads();
+    }
+    if (t < k * k) core[t] = sh[t];
+    if (t == 0) {
+        double s = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += shl[i];
+        core[k * k] = s + logdet;
+    }
+}
+
+__global__ void k_wood_inv(const float *__restrict__ M, const float *__restrict__ D, int n, int k,
+                           const double *__restrict__ core, float *__restrict__ inv, float *__restrict__ logdet) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && logdet) *logdet = (float)core[k * k];
+    if (!inv || idx >= (size_t)n * n) return;
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    double acc = 0.0;
+    for (int a = 0; a < k; ++a) {
+        double t = 0.0;
+        for (int b = 0; b < k; ++b) t += core[a * k + b] * (double)M[(size_t)j * k + b];
+        acc += (double)M[(size_t)i * k + a] * t;
+    }
+    const double di = 1.0 / (double)D[i], dj = 1.0 / (double)D[j];
+    inv[idx] = (float)((i == j ? di : 0.0) - di * acc * dj);
+}
+

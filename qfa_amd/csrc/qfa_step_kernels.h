@@ -1,0 +1,794 @@
+// qfa_step_kernels.h -- the hot kernels of one QFA training / prediction step on CDNA4 (gfx950).
+//
+//   k_prep_pf      F, Psi, omega -> PF image (pass 1 B operand) and tile-major PFT image (pass 2)
+//   k_moments      pass 1: C, T, b, b2 + scalar sums of 16 spectra per wave on v_mfma_f32_16x16x4_f32
+//   k_solve        k x k Gauss-Jordan in fp64 on KP lanes per spectrum (wavefront shuffles)
+//   k_reduce_nll   sum NLL / spectrum counts (fp64, fixed order)
+//   k_grads        pass 2: u, diag(Sigma^-1), Psi/omega/scalar sums, F-gradient contraction on MFMA
+//   k_predict_out  cont = F hmean + mu, unc = sqrt(f^T hcov f)
+//
+// Both passes share one structure: a 256-thread workgroup = 4 waves = 4 x 16 spectra walks a
+// segment of the pixel axis in 16-pixel tiles; the tile of the parameter image every wave needs
+// (10 KB) is staged once per workgroup in LDS (double buffered, register-staged one tile ahead,
+// ONE barrier per tile) and the spectra of the next tile are prefetched into registers before the
+// MFMA block of the current one.  grid.y splits the pixel axis into segments so that
+// (#spectra tiles x #segments) fills 256 CUs evenly (tail quantisation, small batches).
+#pragma once
+#include <type_traits>
+
+#include "qfa_common.h"
+
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ void k_prep_pf(const float *__restrict__ F, const float *__restrict__ Psi,
+                          const float *__restrict__ omega, int Npix, int Nb, int Nh, int NpixPad,
+                          float *__restrict__ PF, float *__restrict__ PFT) {
+    using C = Cfg<KP>;
+    const int i = blockIdx.x * blockDim.y + threadIdx.y;   // pixel row
+    if (i >= NpixPad) return;
+    const bool live = i < Npix;
+    float *pft = PFT + (size_t)(i >> 4) * C::TILE_PFT + (i & 15);
+    for (int c = threadIdx.x; c < C::NCPL; c += blockDim.x) {
+        float v = 0.f;
+        int rt = -1;                       // row in the PFT tile
+        if (c < C::FW) {
+            if (live && c < Nh) v = F[(size_t)i * Nh + c];
+            if (c < KP) rt = c;
+        } else if (c < C::PF_PSI) {
+            const int pidx = c - C::FW;
+            if (pidx < C::KK2) {
+                int a = 0;
+                while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= pidx) ++a;
+                const int b = a + (pidx - pair_index(a, a, KP));
+                if (live && b < Nh) v = F[(size_t)i * Nh + a] * F[(size_t)i * Nh + b];
+                rt = KP + pidx;
+            }
+        } else if (c == C::PF_PSI) {
+            if (live) v = Psi[i];
+            rt = C::PFT_PSI;
+        } else if (c == C::PF_PSI + 1) {
+            if (i < Nb) v = omega[i];
+            rt = C::PFT_PSI + 1;
+        }
+        PF[(size_t)i * C::NCPL + c] = v;
+        if (rt >= 0) pft[rt * 16] = v;
+    }
+    // zero padding rows of the PFT tile
+    for (int r = C::PFT_PSI + 2 + threadIdx.x; r < C::NR; r += blockDim.x) pft[r * 16] = 0.f;
+}
+
+// copy one contiguous tile (NF4 float4) global -> registers -> LDS with all 256 threads; the staging
+// registers are plain locals of the kernel (a struct captured by the nested lambdas ended up in scratch).
+template <int NF4>
+struct TileCopy {
+    static constexpr int N = (NF4 + 255) / 256;
+    static_assert(N <= 3, "tile larger than 3 x 256 float4");
+    static __device__ __forceinline__ bool in(int i, int idx) { return 256 * i + 255 < NF4 || idx < NF4; }
+    static __device__ __forceinline__ void load(const float4 *__restrict__ src, int tid, float4 &v0, float4 &v1,
+                                                float4 &v2) {
+        v0 = src[in(0, tid) ? tid : NF4 - 1];
+        if (N > 1) v1 = src[in(1, tid + 256) ? tid + 256 : NF4 - 1];
+        if (N > 2) v2 = src[in(2, tid + 512) ? tid + 512 : NF4 - 1];
+    }
+    static __device__ __forceinline__ void store(float4 *dst, int tid, const float4 &v0, const float4 &v1,
+                                                 const float4 &v2) {
+        if (in(0, tid)) dst[tid] = v0;
+        if (N > 1 && in(1, tid + 256)) dst[tid + 256] = v1;
+        if (N > 2 && in(2, tid + 512)) dst[tid + 512] = v2;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_moments (pass 1).  Lane (sl = lane&15, j = lane>>4) owns spectrum s0+sl at pixels
+// 16*tile + 4j + e (e = 0..3): exactly the A-operand layout A[i = lane&15][k = lane>>4] of
+// v_mfma_f32_16x16x4_f32 for K-step e; the B operand B[k = j][col = sl] = PF[16*tile + 4j + e][col]
+// comes from the LDS tile (bank-conflict free by the row stride, see Cfg).  A lane's four pixels are
+// contiguous, so each input array costs ONE 16-byte load per lane and tile (64 B per spectrum row).
+// The blue tiles (mean-transmission / absorption-noise terms, 5 transcendentals per pixel) and the
+// red tiles (A = 1, no z-dependence) run in two specialised loops.
+// MOM: [segment][Bpad][NMOM] partial records (k_sum_segments adds them up).
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };       // 4-byte aligned 16-byte load
+struct __attribute__((packed, aligned(1))) u4u { unsigned char v[4]; };
+
+struct SpecRegs1 {
+    float d[4], sg[4], z[4];
+    unsigned m;       // 4 mask bytes
+};
+
+template <int KP, bool PREDICT>
+__global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
+                                                 const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
+                                                 int ntiles, int seg_tiles, const float *__restrict__ PF,
+                                                 float *__restrict__ MOM) {
+    using C = Cfg<KP>;
+    constexpr int NF4 = C::TILE_PF / 4;
+    __shared__ float4 lds4[2][NF4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = wave_uniform(tid >> 6);
+    const int s0 = (blockIdx.x * 4 + wv) * 16;
+    const bool active = s0 < B;                                   // wave-uniform
+    const int t0 = blockIdx.y * seg_tiles;
+    const int t1 = min(t0 + seg_tiles, ntiles);
+    const int nbt = (Nb + 15) >> 4;                               // tiles that contain blue pixels
+    const DevConsts k = load_consts(p, tau);
+    const int sl = lane & 15, j = lane >> 4;
+    const bool svalid = (s0 + sl) < B;
+    const int srow = active ? min(sl, B - 1 - s0) : 0;
+    const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
+    const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
+    const uint8_t *mbase = bt.mask + (size_t)(active ? s0 : 0) * Npix;
+    const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
+    const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
+    const int offN = srow * Npix, offB = srow * Nb;
+    const float4 *PF4 = reinterpret_cast<const float4 *>(PF);
+
+    f32x4 accC[C::NT], accT[C::NT], accb[C::NFT], accb2[C::NFT];
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) accC[t] = accT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C::NFT; ++t) accb[t] = accb2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    double qd = 0.0, ld = 0.0;        // float32 inside a 4-pixel group, float64 across groups
+    float cn = 0.f, cblue = 0.f;
+    float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f};
+    using TC = TileCopy<NF4>;
+
+    auto run = [&](auto blue_tag, int ta, int tb) {
+        constexpr bool BLUE = decltype(blue_tag)::value;
+        const int n = tb - ta;
+        if (n <= 0) return;                                       // block-uniform
+
+        auto load_spec = [&](int tg, SpecRegs1 &r) {
+            const int pb = 16 * tg + 4 * j;
+            if (pb + 3 < Npix) {
+                const f4u vd = *reinterpret_cast<const f4u *>(dbase + offN + pb);
+                const f4u ve = *reinterpret_cast<const f4u *>(ebase + offN + pb);
+                const u4u vm = *reinterpret_cast<const u4u *>(mbase + offN + pb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r.d[e] = vd.v[e]; r.sg[e] = ve.v[e]; }
+                r.m = (unsigned)vm.v[0] | ((unsigned)vm.v[1] << 8) | ((unsigned)vm.v[2] << 16) |
+                      ((unsigned)vm.v[3] << 24);
+            } else {                                              // ragged end of the pixel axis
+                r.m = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int px = min(pb + e, Npix - 1);
+                    r.d[e] = dbase[offN + px];
+                    r.sg[e] = ebase[offN + px];
+                    r.m |= (pb + e < Npix && mbase[offN + px] != 0) ? (1u << (8 * e)) : 0u;
+                }
+            }
+            if (BLUE) {
+                if (pb + 3 < Nb) {
+                    const f4u vz = *reinterpret_cast<const f4u *>(zbase + offB + pb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r.z[e] = vz.v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r.z[e] = zbase[offB + min(pb + e, Nb - 1)];
+                }
+            }
+        };
+
+        auto compute = [&](int tg, const SpecRegs1 &cur, const float *tile) {
+            const float *trow0 = tile + (4 * j) * C::NCPL;
+            // ---- phase 0: issue the LDS reads of K-step 0 and of the per-pixel Psi/omega pairs
+            float fbv[2][C::NFT], pbv[2][C::NT];
+            float2 po[4];
+            auto fetch = [&](int e, int slot) {
+                const float *brow = trow0 + e * C::NCPL + sl;
+#pragma unroll
+                for (int t = 0; t < C::NFT; ++t) fbv[slot][t] = brow[16 * t];
+#pragma unroll
+                for (int t = 0; t < C::NT; ++t) pbv[slot][t] = brow[C::FW + 16 * t];
+            };
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                po[e] = *reinterpret_cast<const float2 *>(trow0 + e * C::NCPL + C::PF_PSI);
+            fetch(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase 1: per-element weights on the VALU (the LDS reads above land meanwhile)
+            float c2[4], c3[4], cb[4], cb2[4];
+            float qd4 = 0.f, ld4 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int px = 16 * tg + 4 * j + e;
+                const bool w = svalid && ((cur.m >> (8 * e)) & 0xffu) != 0;
+                float d = cur.d[e];
+                const float sg = cur.sg[e];
+                float D, wD;
+                if (BLUE) {
+                    const bool blue = px < Nb;
+                    const BlueTerms t = blue_terms(cur.z[e], k);
+                    float Ab = t.A;
+                    if (abase) Ab = abase[offB + min(px, Nb - 1)];        // custom tau callable (rare path)
+                    const float A = blue ? Ab : 1.f;
+                    const float zdom = blue ? t.zd * po[e].y : 0.f;
+                    D = A * A * po[e].x + zdom + sg * sg;
+                    if (PREDICT) d = d - mu[min(px, Npix - 1)] * A;      // QFA/model.py:166
+                    wD = w ? fast_rcp(D) : 0.f;
+                    d = w ? d : 0.f;
+                    const float wDA = wD * A;
+                    c2[e] = wDA * A;
+                    c3[e] = c2[e] * A;
+                    cb[e] = wDA * d;
+                    cb2[e] = c2[e] * d;
+                    cblue += (w && blue) ? 1.f : 0.f;
+                } else {                                                 // red side: A = 1, no omega term
+                    D = po[e].x + sg * sg;
+                    if (PREDICT) d = d - mu[min(px, Npix - 1)];
+                    wD = w ? fast_rcp(D) : 0.f;
+                    d = w ? d : 0.f;
+                    c2[e] = wD;
+                    c3[e] = wD;
+                    cb[e] = wD * d;
+                    cb2[e] = cb[e];
+                }
+                qd4 += wD * d * d;
+                ld4 += w ? fast_log(D) : 0.f;
+                cn += w ? 1.f : 0.f;
+            }
+            qd += (double)qd4;
+            ld += (double)ld4;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase 2: MFMAs of K-step e while the B operands of K-step e+1 are in flight
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e < 3) fetch(e + 1, (e + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < C::NFT; ++t) {
+                    accb[t] = mfma4(cb[e], fbv[e & 1][t], accb[t]);
+                    accb2[t] = mfma4(cb2[e], fbv[e & 1][t], accb2[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < C::NT; ++t) {
+                    accC[t] = mfma4(c2[e], pbv[e & 1][t], accC[t]);
+                    accT[t] = mfma4(c3[e], pbv[e & 1][t], accT[t]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        // one tile: prefetch tile c+1 (parameter image -> registers, spectra -> nxt), compute tile c
+        // from LDS buffer `buf`, publish the prefetched image to the other buffer, ONE barrier.
+        auto step = [&](int c, const SpecRegs1 &cur, SpecRegs1 &nxt, int buf) {
+            const bool more = c + 1 < n;
+            if (more) {
+                TC::load(PF4 + (size_t)(ta + c + 1) * NF4, tid, tv0, tv1, tv2);
+#if QFA_ABL != 2
+                if (active) load_spec(ta + c + 1, nxt);
+#else
+                nxt = cur;
+#endif
+            }
+            if (active) compute(ta + c, cur, reinterpret_cast<const float *>(lds4[buf]));
+            if (more) TC::store(lds4[buf ^ 1], tid, tv0, tv1, tv2);
+            __syncthreads();
+        };
+
+        SpecRegs1 ra, rb;
+        TC::load(PF4 + (size_t)ta * NF4, tid, tv0, tv1, tv2);
+        TC::store(lds4[0], tid, tv0, tv1, tv2);
+        if (active) load_spec(ta, ra);
+        __syncthreads();
+        for (int c = 0; c < n; c += 2) {
+            step(c, ra, rb, 0);
+            if (c + 1 < n) step(c + 1, rb, ra, 1);
+        }
+    };
+    run(std::true_type{}, t0, min(t1, nbt));
+    run(std::false_type{}, max(t0, nbt), t1);
+
+    if (!active) return;
+    // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4j + r, column 16t + sl
+    float *momseg = MOM + (size_t)blockIdx.y * Bpad * C::NMOM;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ss = s0 + 4 * j + r;
+        if (ss < B) {
+            float *m = momseg + (size_t)ss * C::NMOM + sl;
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) {
+                m[16 * t] = accC[t][r];
+                m[C::MOM_T + 16 * t] = accT[t][r];
+            }
+#pragma unroll
+            for (int t = 0; t < C::NFT; ++t) {
+                m[C::MOM_B + 16 * t] = accb[t][r];
+                m[C::MOM_B2 + 16 * t] = accb2[t][r];
+            }
+        }
+    }
+    qd += __shfl_xor(qd, 16); qd += __shfl_xor(qd, 32);
+    ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
+    cn += __shfl_xor(cn, 16); cn += __shfl_xor(cn, 32);
+    cblue += __shfl_xor(cblue, 16); cblue += __shfl_xor(cblue, 32);
+    if (j == 0 && svalid) {
+        float *m = momseg + (size_t)(s0 + sl) * C::NMOM + C::MOM_S;
+        m[0] = (float)qd; m[1] = (float)ld; m[2] = cn; m[3] = cblue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sum_segments : MOM[0] += MOM[1] + ... + MOM[nseg-1] (fixed order), float4-vectorised.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = mom[i];
+    for (int g = 1; g < nseg; ++g) {
+        const float4 b = mom[g * n4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    mom[i] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_solve.  KP lanes per spectrum, lane c holds column c (= row c) of the symmetric k x k
+// matrices in registers; in-place Gauss-Jordan inversion in fp64, every step broadcasting the
+// pivot column with wavefront shuffles.  The pivots are the squared Cholesky diagonal, so
+// log det C = sum log(pivot) (finite where the reference's float32 det overflows, QFA/utils.py:54).
+// The nseg partial moment records of the pixel segments are summed on load.
+// ------------------------------------------------------------------------------------------------
+template <int KP, bool PREDICT>
+__global__ __launch_bounds__(256) void k_solve(const float *__restrict__ MOM, int nseg, int Bpad,
+                                               float *__restrict__ SOL, float *__restrict__ nll_out,
+                                               float *__restrict__ nblue_out, int B, int Nh,
+                                               float *__restrict__ hmean, float *__restrict__ hcov) {
+    using C = Cfg<KP>;
+    constexpr int G = 64 / KP;
+    const int lane = threadIdx.x & 63;
+    const int c = lane % KP;
+    const int s = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + lane / KP;
+    const bool valid = s < B;
+    const float *mom = MOM + (size_t)(valid ? s : B - 1) * C::NMOM;
+    const size_t segstride = (size_t)Bpad * C::NMOM;
+    auto msum = [&](int idx) {
+        double a = 0.0;
+        for (int g = 0; g < nseg; ++g) a += (double)mom[g * segstride + idx];
+        return a;
+    };
+
+    double Cc[KP];
+#pragma unroll
+    for (int r = 0; r < KP; ++r) {
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        Cc[r] = msum(pair_index(a, b, KP)) + (r == c ? 1.0 : 0.0);
+    }
+    double logdet = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < KP; ++jj) {
+        double colj[KP];
+#pragma unroll
+        for (int i = 0; i < KP; ++i) colj[i] = __shfl(Cc[i], jj, KP);
+        const double piv = colj[jj];
+        logdet += log(piv);
+        const double ip = 1.0 / piv;
+        const double rjc = (c == jj) ? ip : Cc[jj] * ip;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            if (i != jj) Cc[i] = (c == jj) ? -colj[i] * ip : Cc[i] - colj[i] * rjc;
+        }
+        Cc[jj] = rjc;
+    }
+    // y = C^-1 b  (Cc[r] = Cinv[r][c] = Cinv[c][r])
+    const double bc = msum(C::MOM_B + c);
+    double y = 0.0;
+#pragma unroll
+    for (int r = 0; r < KP; ++r) y += Cc[r] * __shfl(bc, r, KP);
+    double quad = bc * y;
+#pragma unroll
+    for (int o = KP / 2; o >= 1; o >>= 1) quad += __shfl_xor(quad, o, KP);
+    const double nll = 0.5 * (msum(C::MOM_S + 0) - quad + msum(C::MOM_S + 2) * (double)QFA_LOG2PI +
+                              msum(C::MOM_S + 1) + logdet);
+    if (valid && c == 0) {
+        nll_out[s] = (float)nll;
+        if (nblue_out) nblue_out[s] = (float)msum(C::MOM_S + 3);
+    }
+
+    float *sol = SOL + (size_t)(valid ? s : 0) * C::NSOL;
+    if (valid) {
+        sol[c] = (float)y;
+#pragma unroll
+        for (int r = 0; r < KP; ++r)
+            if (r <= c) sol[C::SOL_CI + pair_index(r, c, KP)] = (float)(r == c ? Cc[r] : 2.0 * Cc[r]);
+    }
+    if (PREDICT) {
+        if (valid && c < Nh) {
+            hmean[(size_t)s * Nh + c] = (float)y;
+#pragma unroll
+            for (int r = 0; r < KP; ++r)
+                if (r < Nh) hcov[((size_t)s * Nh + c) * Nh + r] = (float)Cc[r];
+        }
+        return;
+    }
+    // T column c (= row c), Z row c: Z[c][b] = sum_m Cinv[c][m] T[m][b]
+    float Tc[KP];
+#pragma unroll
+    for (int r = 0; r < KP; ++r) {
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        Tc[r] = (float)msum(C::MOM_T + pair_index(a, b, KP));
+    }
+    double Zr[KP];
+#pragma unroll
+    for (int b = 0; b < KP; ++b) Zr[b] = 0.0;
+#pragma unroll
+    for (int m = 0; m < KP; ++m) {
+#pragma unroll
+        for (int b = 0; b < KP; ++b) Zr[b] += Cc[m] * (double)__shfl(Tc[m], b, KP);
+    }
+    // p_c = b2_c - sum_m T[c][m] y_m
+    double pc = msum(C::MOM_B2 + c);
+#pragma unroll
+    for (int m = 0; m < KP; ++m) pc -= (double)Tc[m] * __shfl(y, m, KP);
+    if (valid) {
+#pragma unroll
+        for (int b = 0; b < KP; ++b) sol[C::SOL_Z + c * KP + b] = (float)Zr[b];
+        sol[C::SOL_P + c] = (float)pc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_reduce_nll : accum scalars += {#spectra with an unmasked blue pixel, sum NLL, B}.  One block,
+// fp64 partial sums, fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_reduce_nll(const float *__restrict__ nll, const float *__restrict__ nblue,
+                                                     int B, float *__restrict__ scal) {
+    __shared__ double sh[2][16];
+    double a = 0.0, nb = 0.0;
+    for (int s = threadIdx.x; s < B; s += blockDim.x) {
+        a += (double)nll[s];
+        nb += nblue[s] > 0.f ? 1.0 : 0.0;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        nb += __shfl_xor(nb, o);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = nb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { ta += sh[0][i]; tb += sh[1][i]; }
+        scal[3] += (float)tb;
+        scal[4] += (float)ta;
+        scal[5] += (float)B;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_grads (pass 2).  Lane (lo = lane&15, g = lane>>4) owns pixel 16*tile + lo of spectra
+// s0 + 4g + r (r = 0..3):
+//   stage 1  [f^T y | f^T C^-1 f] (16 spectra x 16 px) = [y | Cinv'] (registers, A operand) x PFT tile
+//            (LDS, B operand) -> C/D layout col = px, row = 4g + r: the lane's own four elements
+//   stage 2  u, diag(Sigma^-1), dG and the Psi / omega / tau0 / c0 / beta sums     (QFA/model.py:136-144)
+//   stage 3  accF[px][b] += sum_{s,a} (wD A^2)_{s,px} f_{px,a} Z_s[a][b] + sum_s (A u)_{s,px} p_s[b]
+//            K = (spectrum, a); the A operand is lane-local, the B operand Z_{s0+4g+r}[a][b = lo] stays in
+//            registers for the whole pixel loop.
+// Every wave parks its tile result in its own LDS slot; after the tile barrier one wave sums the
+// slots in fixed order and adds the workgroup's tile to the packed accumulation buffer with 5
+// full-width float atomics (4 x 256 B contiguous rows of accF + one row of per-pixel sums).
+// gF = f * sumA - accF is formed in k_finalize (QFA/model.py:137 in low-rank form, App. A step 7).
+// Blue and red tiles run in two specialised loops (the red one has no transcendental work).
+// ------------------------------------------------------------------------------------------------
+struct SpecRegs2 {
+    float d[4], sg[4], z[4];
+    unsigned m[4];
+};
+
+template <int KP>
+__global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix,
+                                               int Nb, int Nh, int ntiles, int seg_tiles,
+                                               const float *__restrict__ PFT, const float *__restrict__ SOL,
+                                               float *__restrict__ accum) {
+    using C = Cfg<KP>;
+    constexpr int KF = KP / 4, KQ = C::KK2 / 4;
+    constexpr int NF4 = C::TILE_PFT / 4;
+    constexpr int NPART = 512;      // per wave and tile: aG [px][16] (256) + 4 per-pixel sums x 64 lanes
+    __shared__ float4 lds4[2][NF4];
+    __shared__ float ldspart[2][4][NPART];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = wave_uniform(tid >> 6);
+    const int s0 = (blockIdx.x * 4 + wv) * 16;
+    const bool active = s0 < B;
+    const int t0 = blockIdx.y * seg_tiles;
+    const int t1 = min(t0 + seg_tiles, ntiles);
+    const int nbt = (Nb + 15) >> 4;
+    const int nwav = min(4, (B - (int)blockIdx.x * 64 + 15) / 16);    // active waves of this workgroup
+    const DevConsts k = load_consts(p, tau);
+    const int lo = lane & 15, g = lane >> 4;
+
+    float *accF = accum;
+    float *accA = accF + (size_t)Npix * Nh;
+    float *accPsi = accA + Npix;
+    float *accOm = accPsi + Npix;
+    float *accCnt = accOm + Nb;
+    float *accS = accCnt + Npix;
+
+    // A operands of stage 1: spectrum s0+lo, k = 4t + g
+    float yA[KF], qA[KQ];
+    {
+        const bool v = active && (s0 + lo) < B;
+        const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+#pragma unroll
+        for (int t = 0; t < KF; ++t) yA[t] = v ? sol[4 * t + g] : 0.f;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) qA[t] = v ? sol[C::SOL_CI + 4 * t + g] : 0.f;
+    }
+    // B operands of stage 3: spectra s0+4g+r, column b = lo
+    float Zr[4][KP], pr[4];
+    bool sv[4];
+    int offN[4], offB[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int srel = 4 * g + r;
+        sv[r] = active && (s0 + srel) < B;
+        const bool v = sv[r] && lo < KP;
+        const float *sol = SOL + (size_t)(v ? s0 + srel : 0) * C::NSOL;
+#pragma unroll
+        for (int a = 0; a < KP; ++a) Zr[r][a] = v ? sol[C::SOL_Z + a * KP + lo] : 0.f;
+        pr[r] = v ? sol[C::SOL_P + lo] : 0.f;
+        const int sc = active ? min(srel, B - 1 - s0) : 0;
+        offN[r] = sc * Npix;
+        offB[r] = sc * Nb;
+    }
+    const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
+    const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
+    const uint8_t *mbase = bt.mask + (size_t)(active ? s0 : 0) * Npix;
+    const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
+    const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
+    const float4 *PFT4 = reinterpret_cast<const float4 *>(PFT);
+    float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f};
+    using TC = TileCopy<NF4>;
+    double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;   // float32 per tile, float64 across tiles
+    int ntile_done = 0;                               // picks the flushing wave, round robin
+
+    auto run = [&](auto blue_tag, int ta, int tb) {
+        constexpr bool BLUE = decltype(blue_tag)::value;
+        const int n = tb - ta;
+        if (n <= 0) return;                                       // block-uniform
+        // de-phase the tile order between workgroups so that concurrent flushes hit different rows
+        const int rot = (int)(((unsigned)blockIdx.x * 2654435761u) % (unsigned)n);
+        auto tile_of = [&](int c) {
+            int x = c + rot;
+            if (x >= n) x -= n;
+            return ta + x;
+        };
+
+        auto load_spec = [&](int tg, SpecRegs2 &rg) {
+            const int px = min(16 * tg + lo, Npix - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rg.d[r] = dbase[offN[r] + px];
+                rg.sg[r] = ebase[offN[r] + px];
+                rg.m[r] = mbase[offN[r] + px];
+            }
+            if (BLUE) {
+                const int pz = min(16 * tg + lo, Nb - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rg.z[r] = zbase[offB[r] + pz];
+            }
+        };
+
+        auto compute = [&](int tg, const SpecRegs2 &cur, const float *tile, float *part) {
+            const int px = 16 * tg + lo;
+            const bool inb = px < Npix;
+            // ---- stage 1: B operands from LDS in groups of 8, one group in flight ahead of the MFMAs
+            f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+            const float *tb_ = tile + g * 16 + lo;
+            constexpr int NK1 = KF + KQ, GRP = 8, NGRP = (NK1 + GRP - 1) / GRP;
+            float bop[2][GRP];
+            auto rowof = [](int t) { return t < KF ? 4 * t : KP + 4 * (t - KF); };
+            auto fetch1 = [&](int gi, int slot) {
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int t = gi * GRP + i;
+                    if (t < NK1) bop[slot][i] = tb_[rowof(t) * 16];
+                }
+            };
+            fetch1(0, 0);
+            const float Psi = tile[C::PFT_PSI * 16 + lo];
+            const float om = tile[(C::PFT_PSI + 1) * 16 + lo];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gi = 0; gi < NGRP; ++gi) {
+                if (gi + 1 < NGRP) fetch1(gi + 1, (gi + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int t = gi * GRP + i;
+                    if (t < KF) afy = mfma4(yA[t], bop[gi & 1][i], afy);
+                    else if (t < NK1) aq = mfma4(qA[t - KF], bop[gi & 1][i], aq);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- stage 2 (the f_{px,a} reads for stage 3 are issued first and land meanwhile)
+            float f[KP];
+#pragma unroll
+            for (int a = 0; a < KP; ++a) f[a] = tile[a * 16 + lo];
+            float betaR[4], gamR[4];
+            float gPsi = 0.f, gOm = 0.f, sA = 0.f, cnt = 0.f;
+            float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float d = cur.d[r];
+                const float sg = cur.sg[r];
+                const bool w = inb && sv[r] && cur.m[r] != 0;
+                if (BLUE) {
+                    const bool blue = px < Nb;
+                    const BlueTerms t = blue_terms(cur.z[r], k);
+                    float Ab = t.A;
+                    if (abase) Ab = abase[offB[r] + min(px, Nb - 1)];      // custom tau callable (rare path)
+                    const float A = blue ? Ab : 1.f;
+                    const float zd = blue ? t.zd : 0.f;
+                    const float D = A * A * Psi + om * zd + sg * sg;
+                    const float wD = w ? fast_rcp(D) : 0.f;
+                    d = w ? d : 0.f;
+                    const float wDA = wD * A;
+                    const float u = wD * (d - A * afy[r]);                 // (Sigma^-1 delta)_i
+                    const float dS = wD - wDA * wDA * aq[r];               // diag(Sigma^-1)_i
+                    const float dG = 0.5f * (dS - u * u);                  // QFA/model.py:136,138
+                    gPsi += A * A * dG;                                    // :139
+                    gOm += dG * zd;                                        // :140
+                    const float root = 1.0f - k.tau0 * t.pw - k.c0;        // :141
+                    const float e = dG * (om * zd) * zd * 2.0f * root;
+                    t_tau0 -= e * t.pw;                                    // :142
+                    t_beta -= e * (k.tau0 * t.pw * (t.l2 * QFA_LN2));      // :143
+                    t_c0 -= e;                                             // :144
+                    betaR[r] = wDA * A;
+                    sA += betaR[r] * A;
+                    gamR[r] = A * u;
+                } else {                                                   // red side: A = 1, zd = 0
+                    const float D = Psi + sg * sg;
+                    const float wD = w ? fast_rcp(D) : 0.f;
+                    d = w ? d : 0.f;
+                    const float u = wD * (d - afy[r]);
+                    const float dS = wD - wD * wD * aq[r];
+                    gPsi += 0.5f * (dS - u * u);
+                    betaR[r] = wD;
+                    sA += wD;
+                    gamR[r] = u;
+                }
+                cnt += w ? 1.f : 0.f;
+            }
+            if (BLUE) {
+                s_tau0 += (double)t_tau0;
+                s_c0 += (double)t_c0;
+                s_beta += (double)t_beta;
+            }
+            // ---- stage 3
+            f32x4 aG = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int a = 0; a < KP; ++a) aG = mfma4(betaR[r] * f[a], Zr[r][a], aG);
+                aG = mfma4(gamR[r], pr[r], aG);
+            }
+            // ---- per-wave partial tile to LDS.  aG: col = b = lo, row = 4g + rr -> pixel 4g + rr
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = aG[rr];
+            part[256 + lane] = gPsi;
+            part[320 + lane] = gOm;
+            part[384 + lane] = sA;
+            part[448 + lane] = cnt;
+        };
+
+        // tile tg leaves the workgroup: sum the waves' slots (fixed order), 5 float atomics.
+        auto flush = [&](int tg, const float (*pp)[NPART]) {
+            const int base = 16 * tg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q;
+                float v = 0.f;
+                for (int w = 0; w < nwav; ++w) v += pp[w][idx];
+                const int px = base + (idx >> 4), b = idx & 15;
+                if (b < Nh && px < Npix) atomicAdd(accF + (size_t)px * Nh + b, v);
+            }
+            const int which = lane >> 4, px = base + (lane & 15);
+            float v = 0.f;
+            for (int w = 0; w < nwav; ++w) {
+                const float *q = pp[w] + 256 + which * 64 + (lane & 15);
+                v += (q[0] + q[16]) + (q[32] + q[48]);
+            }
+            if (px < Npix) {
+                if (which == 0) atomicAdd(accPsi + px, v);
+                else if (which == 1) { if (px < Nb) atomicAdd(accOm + px, v); }
+                else if (which == 2) atomicAdd(accA + px, v);
+                else atomicAdd(accCnt + px, v);
+            }
+        };
+
+        auto step = [&](int c, const SpecRegs2 &cur, SpecRegs2 &nxt, int buf) {
+            const bool more = c + 1 < n;
+            const int tg = tile_of(c);
+            if (more) {
+                const int tn = tile_of(c + 1);
+                TC::load(PFT4 + (size_t)tn * NF4, tid, tv0, tv1, tv2);
+#if QFA_ABL != 2
+                if (active) load_spec(tn, nxt);
+#else
+                nxt = cur;
+#endif
+            }
+            if (active) compute(tg, cur, reinterpret_cast<const float *>(lds4[buf]), ldspart[buf][wv]);
+            if (more) TC::store(lds4[buf ^ 1], tid, tv0, tv1, tv2);
+            __syncthreads();
+            // ldspart[buf] is rewritten two tiles later, i.e. after the next barrier
+            if (wv == (ntile_done & 3)) flush(tg, ldspart[buf]);
+            ++ntile_done;
+        };
+
+        SpecRegs2 ra, rb;
+        TC::load(PFT4 + (size_t)tile_of(0) * NF4, tid, tv0, tv1, tv2);
+        TC::store(lds4[0], tid, tv0, tv1, tv2);
+        if (active) load_spec(tile_of(0), ra);
+        __syncthreads();
+        for (int c = 0; c < n; c += 2) {
+            step(c, ra, rb, 0);
+            if (c + 1 < n) step(c + 1, rb, ra, 1);
+        }
+        __syncthreads();      // the last flush reads ldspart; the next range's first tile rewrites it
+    };
+    run(std::true_type{}, t0, min(t1, nbt));
+    run(std::false_type{}, max(t0, nbt), t1);
+
+    if (!active) return;
+    for (int o = 32; o >= 1; o >>= 1) {
+        s_tau0 += __shfl_xor(s_tau0, o);
+        s_c0 += __shfl_xor(s_c0, o);
+        s_beta += __shfl_xor(s_beta, o);
+    }
+    if (lane == 0) {
+        atomicAdd(accS + 0, (float)s_tau0);
+        atomicAdd(accS + 1, (float)s_c0);
+        atomicAdd(accS + 2, (float)s_beta);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_predict_out : cont = F hmean + mu on ALL pixels, unc = sqrt(diag(F hcov F^T))  (QFA/model.py:180)
+// -- stage 1 of k_grads with [hmean | hcov'] as the A operand; bound by the (B, Npix) output writes.
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void k_predict_out(const float *__restrict__ mu, int B, int Npix, int ntiles,
+                                                     const float *__restrict__ PFT, const float *__restrict__ SOL,
+                                                     float *__restrict__ cont, float *__restrict__ unc) {
+    using C = Cfg<KP>;
+    constexpr int KF = KP / 4, KQ = C::KK2 / 4;
+    const int lane = threadIdx.x & 63;
+    const int s0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+    if (s0 >= B) return;
+    const int lo = lane & 15, g = lane >> 4;
+    float yA[KF], qA[KQ];
+    {
+        const bool v = (s0 + lo) < B;
+        const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+#pragma unroll
+        for (int t = 0; t < KF; ++t) yA[t] = v ? sol[4 * t + g] : 0.f;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) qA[t] = v ? sol[C::SOL_CI + 4 * t + g] : 0.f;
+    }
+    for (int tg = 0; tg < ntiles; ++tg) {
+        const int px = 16 * tg + lo;
+        f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+        const float *tb = PFT + (size_t)tg * C::TILE_PFT + g * 16 + lo;
+#pragma unroll
+        for (int t = 0; t < KF; ++t) afy = mfma4(yA[t], tb[(4 * t) * 16], afy);
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) aq = mfma4(qA[t], tb[(KP + 4 * t) * 16], aq);
+        if (px < Npix) {
+            const float m = mu[px];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = s0 + 4 * g + r;
+                if (s < B) {
+                    cont[(size_t)s * Npix + px] = afy[r] + m;
+                    unc[(size_t)s * Npix + px] = __builtin_amdgcn_sqrtf(aq[r]);
+                }
+            }
+        }
+    }
+}

@@ -351,7 +351,8 @@ def test_full_size_properties_config2(dev):
     nll_a = torch.empty(h, dtype=torch.float32, device=dev)
     acc_a = m.accumulate(d[:h], e[:h], z[:h], mk[:h], nll=nll_a).clone()
     acc_b = m.accumulate(d[h:], e[h:], z[h:], mk[h:]).clone()
-    assert torch.equal(nll[:h], nll_a)                                   # bitwise: no cross-spectrum coupling
+    # no cross-spectrum coupling; only the pixel-segment split (chosen from B) re-associates sums
+    assert rel_l2(nll[:h].cpu().numpy(), nll_a.cpu().numpy()) < 1e-6
     tot = acc_a + acc_b
     assert rel_l2(tot.cpu().numpy(), acc.cpu().numpy()) < 2e-5          # atomics re-associate sums
     assert acc[-3].item() == B
