@@ -577,7 +577,9 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
             const int px = 16 * tg + lo;
             const bool inb = px < Npix;
             // ---- stage 1: B operands from LDS in groups of 8, one group in flight ahead of the MFMAs
-            f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+            // (independent accumulator chains: a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles,
+            // an independent one every 32)
+            f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f}, aq2 = {0.f, 0.f, 0.f, 0.f};
             const float *tb_ = tile + g * 16 + lo;
             constexpr int NK1 = KF + KQ, GRP = 8, NGRP = (NK1 + GRP - 1) / GRP;
             float bop[2][GRP];
@@ -601,10 +603,12 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
                 for (int i = 0; i < GRP; ++i) {
                     const int t = gi * GRP + i;
                     if (t < KF) afy = mfma4(yA[t], bop[gi & 1][i], afy);
-                    else if (t < NK1) aq = mfma4(qA[t - KF], bop[gi & 1][i], aq);
+                    else if (t < NK1 && (t & 1)) aq = mfma4(qA[t - KF], bop[gi & 1][i], aq);
+                    else if (t < NK1) aq2 = mfma4(qA[t - KF], bop[gi & 1][i], aq2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            aq += aq2;
             // ---- stage 2 (the f_{px,a} reads for stage 3 are issued first and land meanwhile)
             float f[KP];
 #pragma unroll
@@ -660,13 +664,18 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
                 s_beta += (double)t_beta;
             }
             // ---- stage 3
-            f32x4 aG = {0.f, 0.f, 0.f, 0.f};
+            f32x4 aG = {0.f, 0.f, 0.f, 0.f}, aG2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int a = 0; a < KP; ++a) aG = mfma4(betaR[r] * f[a], Zr[r][a], aG);
-                aG = mfma4(gamR[r], pr[r], aG);
+                for (int a = 0; a < KP; a += 2) {
+                    aG = mfma4(betaR[r] * f[a], Zr[r][a], aG);
+                    aG2 = mfma4(betaR[r] * f[a + 1], Zr[r][a + 1], aG2);
+                }
+                if (r & 1) aG = mfma4(gamR[r], pr[r], aG);
+                else aG2 = mfma4(gamR[r], pr[r], aG2);
             }
+            aG += aG2;
             // ---- per-wave partial tile to LDS.  aG: col = b = lo, row = 4g + rr -> pixel 4g + rr
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = aG[rr];
