@@ -122,7 +122,8 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
                                                                  nullptr);
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
     mark(3);
-    k_grads<KP><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, PFT, SOL, accum);
+    if (b.A_blue) k_grads<KP, true><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, PFT, SOL, accum);
+    else k_grads<KP, false><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, PFT, SOL, accum);
     mark(4);
     return hip_status();
 }
@@ -146,6 +147,12 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
 }  // namespace
 
 extern "C" {
+
+#if QFA_ABL == 7
+int qfa_debug_stamps(unsigned long long *out) {      // diagnostic build only
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qfa_dbg_stamps), 64 * sizeof(unsigned long long));
+}
+#endif
 
 int qfa_abi_version(void) { return QFA_ABI_VERSION; }
 

@@ -102,6 +102,15 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 #endif
 }
 
+// keep a value's computation in front of this point (IR passes otherwise sink pure arithmetic past
+// the sched_barrier fences of the hand-woven MFMA/VALU regions)
+__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
+template <typename... T>
+__device__ __forceinline__ void pin(float &x, T &...rest) {
+    pin(x);
+    pin(rest...);
+}
+
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 __device__ __forceinline__ DevConsts load_consts(const qfa_params_t &p, const qfa_tau_t &tau) {

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int px = 16 * tg + 4 * j + e;
-                const bool w = svalid && ((cur.m >> (8 * e)) & 0xffu) != 0;
+                const bool w = svalid & (((cur.m >> (8 * e)) & 0xffu) != 0);
                 float d = cur.d[e];
                 const float sg = cur.sg[e];
                 float D, wD;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t 
                     c3[e] = c2[e] * A;
                     cb[e] = wDA * d;
                     cb2[e] = c2[e] * d;
-                    cblue += (w && blue) ? 1.f : 0.f;
+                    cblue += (w & blue) ? 1.f : 0.f;
                 } else {                                                 // red side: A = 1, no omega term
                     D = po[e].x + sg * sg;
                     if (PREDICT) d = d - mu[min(px, Npix - 1)];
@@ -458,6 +458,9 @@ __global__ __launch_bounds__(1024) void k_reduce_nll(const float *__restrict__ n
     }
 }
 
+#if QFA_ABL == 7
+__device__ unsigned long long qfa_dbg_stamps[64];
+#endif
 // ------------------------------------------------------------------------------------------------
 // k_grads (pass 2).  Lane (lo = lane&15, g = lane>>4) owns pixel 16*tile + lo of spectra
 // s0 + 4g + r (r = 0..3):
@@ -478,7 +481,7 @@ struct SpecRegs2 {
     unsigned m[4];
 };
 
-template <int KP>
+template <int KP, bool HASA>
 __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix,
                                                int Nb, int Nh, int ntiles, int seg_tiles,
                                                const float *__restrict__ PFT, const float *__restrict__ SOL,
@@ -487,8 +490,13 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
     constexpr int KF = KP / 4, KQ = C::KK2 / 4;
     constexpr int NF4 = C::TILE_PFT / 4;
     constexpr int NPART = 512;      // per wave and tile: aG [px][16] (256) + 4 per-pixel sums x 64 lanes
-    __shared__ float4 lds4[2][NF4];
+    __shared__ float4 lds4[3][NF4];                               // ring of 3 parameter tiles
     __shared__ float ldspart[2][4][NPART];
+#if QFA_ABL == 6                                                  // occupancy experiment: one workgroup per CU
+    __shared__ float ldspad[22000];
+    if (B < 0) ldspad[threadIdx.x] = 1.f;
+    if (B < -1) accum[0] = ldspad[threadIdx.x + 1];
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
     const int t0 = blockIdx.y * seg_tiles;
     const int t1 = min(t0 + seg_tiles, ntiles);
     const int nbt = (Nb + 15) >> 4;
-    const int nwav = min(4, (B - (int)blockIdx.x * 64 + 15) / 16);    // active waves of this workgroup
+    for (int i = tid; i < 2 * 4 * NPART; i += 256) (&ldspart[0][0][0])[i] = 0.f;   // inactive waves' slots stay 0
     const DevConsts k = load_consts(p, tau);
     const int lo = lane & 15, g = lane >> 4;
 
@@ -545,6 +553,16 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
     using TC = TileCopy<NF4>;
     double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;   // float32 per tile, float64 across tiles
     int ntile_done = 0;                               // picks the flushing wave, round robin
+#if QFA_ABL == 7      // diagnostic build: where does a tile step spend its cycles (never shipped)
+    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0};
+#define QFA_STAMP(var)                                                                      \
+    unsigned long long var;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define QFA_STAMP(var)
+#endif
 
     auto run = [&](auto blue_tag, int ta, int tb) {
         constexpr bool BLUE = decltype(blue_tag)::value;
@@ -559,111 +577,210 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
         };
 
         auto load_spec = [&](int tg, SpecRegs2 &rg) {
-            const int px = min(16 * tg + lo, Npix - 1);
+            // unsigned 32-bit element offsets from wave-uniform bases: scalar-base + VGPR-offset loads
+            const unsigned px = (unsigned)min(16 * tg + lo, Npix - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                rg.d[r] = dbase[offN[r] + px];
-                rg.sg[r] = ebase[offN[r] + px];
-                rg.m[r] = mbase[offN[r] + px];
+                const unsigned o = (unsigned)offN[r] + px;
+                rg.d[r] = dbase[o];
+                rg.sg[r] = ebase[o];
+                rg.m[r] = mbase[o];
             }
             if (BLUE) {
-                const int pz = min(16 * tg + lo, Nb - 1);
+                const unsigned pz = (unsigned)min(16 * tg + lo, Nb - 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rg.z[r] = zbase[offB[r] + pz];
+                for (int r = 0; r < 4; ++r) rg.z[r] = zbase[(unsigned)offB[r] + pz];
             }
         };
 
-        auto compute = [&](int tg, const SpecRegs2 &cur, const float *tile, float *part) {
+        // ---- stage 1 of one tile: [f^T y | f^T C^-1 f] for the lane's four elements, plus Psi/omega
+        // (plain form, used once to prime the pipeline)
+        auto stage1 = [&](const float *tile, f32x4 &afy, f32x4 &aq, float &Psi, float &om) {
+            constexpr int NK1 = KF + KQ;
+            const float *tb_ = tile + g * 16 + lo;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NK1; ++t) {
+                const int row = t < KF ? 4 * t : KP + 4 * (t - KF);
+                const float bv = tb_[row * 16];
+                if (t < KF) a0 = mfma4(yA[t], bv, a0);
+                else if (t & 1) a1 = mfma4(qA[t - KF], bv, a1);
+                else a2 = mfma4(qA[t - KF], bv, a2);
+            }
+            afy = a0;
+            aq = a1 + a2;
+            Psi = tile[C::PFT_PSI * 16 + lo];
+            om = tile[(C::PFT_PSI + 1) * 16 + lo];
+        };
+
+        // ---- region 1 of the software pipeline: stage 2 of tile `tg` (VALU: u, diag(Sigma^-1), dG, the
+        // per-pixel and scalar sums) hand-woven with stage 1 of the NEXT tile (MFMA).  The per-element
+        // arithmetic is cut into chunks of ~6-10 VALU instructions; after each chunk one or two MFMAs of
+        // the next tile are issued (their B operands were read from LDS six slots earlier), and
+        // sched_barrier(0) pins that order, so a single wave keeps the matrix pipe and the VALU busy
+        // at the same time (an MFMA occupies the pipe for 32 cycles = 6-8 VALU issues).
+        auto region1 = [&](int tg, const SpecRegs2 &cur, const f32x4 &afy, const f32x4 &aq, float Psi, float om,
+                           const float *tileN, f32x4 &afyN, f32x4 &aqN, float &PsiN, float &omN,
+                           float (&betaR)[4], float (&gamR)[4], float *part) {
+            constexpr int NK1 = KF + KQ, AHEAD = 6;
+            const float *tbN = tileN + g * 16 + lo;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+            float bop[8];
+            auto rd = [&](int t) {
+                if (t < NK1) bop[t & 7] = tbN[(t < KF ? 4 * t : KP + 4 * (t - KF)) * 16];
+            };
+            auto mf = [&](int t) {
+                if (t < KF) a0 = mfma4(yA[t < KF ? t : 0], bop[t & 7], a0);
+                else if (t < NK1 && (t & 1)) a1 = mfma4(qA[t < NK1 ? t - KF : 0], bop[t & 7], a1);
+                else if (t < NK1) a2 = mfma4(qA[t < NK1 ? t - KF : 0], bop[t & 7], a2);
+            };
+            int slot_no = 0;
+            auto slots = [&](int nmf) {              // nmf MFMA slots, then fence
+#pragma unroll
+                for (int i = 0; i < nmf; ++i) {
+                    rd(slot_no + AHEAD);
+                    mf(slot_no);
+                    ++slot_no;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int t = 0; t < AHEAD; ++t) rd(t);
+            PsiN = tileN[C::PFT_PSI * 16 + lo];
+            omN = tileN[(C::PFT_PSI + 1) * 16 + lo];
+            __builtin_amdgcn_sched_barrier(0);
+
             const int px = 16 * tg + lo;
             const bool inb = px < Npix;
-            // ---- stage 1: B operands from LDS in groups of 8, one group in flight ahead of the MFMAs
-            // (independent accumulator chains: a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles,
-            // an independent one every 32)
-            f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f}, aq2 = {0.f, 0.f, 0.f, 0.f};
-            const float *tb_ = tile + g * 16 + lo;
-            constexpr int NK1 = KF + KQ, GRP = 8, NGRP = (NK1 + GRP - 1) / GRP;
-            float bop[2][GRP];
-            auto rowof = [](int t) { return t < KF ? 4 * t : KP + 4 * (t - KF); };
-            auto fetch1 = [&](int gi, int slot) {
-#pragma unroll
-                for (int i = 0; i < GRP; ++i) {
-                    const int t = gi * GRP + i;
-                    if (t < NK1) bop[slot][i] = tb_[rowof(t) * 16];
-                }
-            };
-            fetch1(0, 0);
-            const float Psi = tile[C::PFT_PSI * 16 + lo];
-            const float om = tile[(C::PFT_PSI + 1) * 16 + lo];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int gi = 0; gi < NGRP; ++gi) {
-                if (gi + 1 < NGRP) fetch1(gi + 1, (gi + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < GRP; ++i) {
-                    const int t = gi * GRP + i;
-                    if (t < KF) afy = mfma4(yA[t], bop[gi & 1][i], afy);
-                    else if (t < NK1 && (t & 1)) aq = mfma4(qA[t - KF], bop[gi & 1][i], aq);
-                    else if (t < NK1) aq2 = mfma4(qA[t - KF], bop[gi & 1][i], aq2);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            aq += aq2;
-            // ---- stage 2 (the f_{px,a} reads for stage 3 are issued first and land meanwhile)
-            float f[KP];
-#pragma unroll
-            for (int a = 0; a < KP; ++a) f[a] = tile[a * 16 + lo];
-            float betaR[4], gamR[4];
+            const bool blue = px < Nb;
             float gPsi = 0.f, gOm = 0.f, sA = 0.f, cnt = 0.f;
             float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
+            // two elements per chunk (independent dependency chains back to back), two MFMA slots after it
+            float dd[4], l2[4], x1[4], x2[4], pw[4], y1[4], y2[4], Av[4], zd[4], A2[4], wD[4], wDA[4], uu[4], dG[4];
+            bool wv_[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float d = cur.d[r];
-                const float sg = cur.sg[r];
-                const bool w = inb && sv[r] && cur.m[r] != 0;
-                if (BLUE) {
-                    const bool blue = px < Nb;
-                    const BlueTerms t = blue_terms(cur.z[r], k);
-                    float Ab = t.A;
-                    if (abase) Ab = abase[offB[r] + min(px, Nb - 1)];      // custom tau callable (rare path)
-                    const float A = blue ? Ab : 1.f;
-                    const float zd = blue ? t.zd : 0.f;
-                    const float D = A * A * Psi + om * zd + sg * sg;
-                    const float wD = w ? fast_rcp(D) : 0.f;
-                    d = w ? d : 0.f;
-                    const float wDA = wD * A;
-                    const float u = wD * (d - A * afy[r]);                 // (Sigma^-1 delta)_i
-                    const float dS = wD - wDA * wDA * aq[r];               // diag(Sigma^-1)_i
-                    const float dG = 0.5f * (dS - u * u);                  // QFA/model.py:136,138
-                    gPsi += A * A * dG;                                    // :139
-                    gOm += dG * zd;                                        // :140
-                    const float root = 1.0f - k.tau0 * t.pw - k.c0;        // :141
-                    const float e = dG * (om * zd) * zd * 2.0f * root;
-                    t_tau0 -= e * t.pw;                                    // :142
-                    t_beta -= e * (k.tau0 * t.pw * (t.l2 * QFA_LN2));      // :143
-                    t_c0 -= e;                                             // :144
-                    betaR[r] = wDA * A;
-                    sA += betaR[r] * A;
-                    gamR[r] = A * u;
-                } else {                                                   // red side: A = 1, zd = 0
-                    const float D = Psi + sg * sg;
-                    const float wD = w ? fast_rcp(D) : 0.f;
-                    d = w ? d : 0.f;
-                    const float u = wD * (d - afy[r]);
-                    const float dS = wD - wD * wD * aq[r];
-                    gPsi += 0.5f * (dS - u * u);
-                    betaR[r] = wD;
-                    sA += wD;
-                    gamR[r] = u;
-                }
-                cnt += w ? 1.f : 0.f;
+                dd[r] = cur.d[r];
+                wv_[r] = inb & sv[r] & (cur.m[r] != 0);
             }
+#pragma unroll
+            for (int rp = 0; rp < 4; rp += 2) {
+                if (BLUE) {
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {           // chunk 0
+                        l2[r] = fast_log2(1.0f + cur.z[r]);
+                        x1[r] = k.t_expo * (l2[r] + k.t_lscale);
+                        x2[r] = k.beta * l2[r];
+                        pin(x1[r], x2[r]);
+                    }
+                    slots(2);
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {           // chunk 1
+                        pw[r] = fast_exp2(x2[r]);
+                        const float tauv = k.t_amp * fast_exp2(x1[r]) + k.t_off;       // QFA/utils.py:105-141
+                        y1[r] = -tauv * QFA_LOG2E;
+                        y2[r] = -k.tau0 * pw[r] * QFA_LOG2E;
+                        pin(y1[r], y2[r]);
+                    }
+                    slots(2);
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {           // chunk 2
+                        float Ab = fast_exp2(y1[r]);                                   // QFA/model.py:125
+                        if (HASA) Ab = abase[offB[r] + min(px, Nb - 1)];               // custom tau callable
+                        const float re = 1.0f - k.c0 - fast_exp2(y2[r]);               // QFA/utils.py:91
+                        Av[r] = blue ? Ab : 1.f;
+                        zd[r] = blue ? re * re : 0.f;
+                        pin(Av[r], zd[r]);
+                    }
+                    slots(2);
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {           // chunk 3
+                        A2[r] = Av[r] * Av[r];
+                        const float D = A2[r] * Psi + om * zd[r] + cur.sg[r] * cur.sg[r];
+                        wD[r] = wv_[r] ? fast_rcp(D) : 0.f;
+                        dd[r] = wv_[r] ? dd[r] : 0.f;
+                        wDA[r] = wD[r] * Av[r];
+                        pin(wDA[r], dd[r]);
+                    }
+                    slots(4);
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {           // chunk 4
+                        uu[r] = wD[r] * (dd[r] - Av[r] * afy[r]);                      // (Sigma^-1 delta)_i
+                        const float dS = wD[r] - wDA[r] * wDA[r] * aq[r];              // diag(Sigma^-1)_i
+                        dG[r] = 0.5f * (dS - uu[r] * uu[r]);                           // QFA/model.py:136,138
+                        gPsi += A2[r] * dG[r];                                         // :139
+                        gOm += dG[r] * zd[r];                                          // :140
+                    }
+                    pin(gPsi, gOm);
+                    slots(4);
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {           // chunk 5
+                        const float root = 1.0f - k.tau0 * pw[r] - k.c0;               // :141
+                        const float e = dG[r] * (om * zd[r]) * zd[r] * 2.0f * root;
+                        t_tau0 -= e * pw[r];                                           // :142
+                        t_beta -= e * (k.tau0 * pw[r] * (l2[r] * QFA_LN2));            // :143
+                        t_c0 -= e;                                                     // :144
+                    }
+                    pin(t_tau0, t_beta, t_c0);
+                    slots(4);
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {           // chunk 6
+                        cnt += wv_[r] ? 1.f : 0.f;
+                        betaR[r] = wDA[r] * Av[r];
+                        sA += betaR[r] * Av[r];
+                        gamR[r] = Av[r] * uu[r];
+                        pin(gamR[r]);
+                    }
+                    pin(cnt, sA);
+                    slots(2);
+                } else {                                                               // red side: A = 1, zd = 0
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {
+                        const float D = Psi + cur.sg[r] * cur.sg[r];
+                        wD[r] = wv_[r] ? fast_rcp(D) : 0.f;
+                        dd[r] = wv_[r] ? dd[r] : 0.f;
+                        pin(wD[r], dd[r]);
+                    }
+                    slots(6);
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {
+                        uu[r] = wD[r] * (dd[r] - afy[r]);
+                        const float dS = wD[r] - wD[r] * wD[r] * aq[r];
+                        gPsi += 0.5f * (dS - uu[r] * uu[r]);
+                    }
+                    pin(gPsi);
+                    slots(6);
+#pragma unroll
+                    for (int r = rp; r < rp + 2; ++r) {
+                        cnt += wv_[r] ? 1.f : 0.f;
+                        betaR[r] = wD[r];
+                        sA += wD[r];
+                        gamR[r] = uu[r];
+                        pin(gamR[r]);
+                    }
+                    pin(cnt, sA);
+                    slots(8);
+                }
+            }
+            static_assert(NK1 <= 40, "stage 1 has more K-steps than MFMA slots");
             if (BLUE) {
                 s_tau0 += (double)t_tau0;
                 s_c0 += (double)t_c0;
                 s_beta += (double)t_beta;
             }
-            // ---- stage 3
+            afyN = a0;
+            aqN = a1 + a2;
+            part[256 + lane] = sA;
+            part[320 + lane] = gPsi;
+            part[384 + lane] = gOm;
+            part[448 + lane] = cnt;
+        };
+
+        // ---- stage 3 of one tile: the F-gradient contraction, f_{px,a} re-read from the tile image
+        auto stage3 = [&](const float *tile, const float (&betaR)[4], const float (&gamR)[4], float *part) {
+            float f[KP];
+#pragma unroll
+            for (int a = 0; a < KP; ++a) f[a] = tile[a * 16 + lo];
             f32x4 aG = {0.f, 0.f, 0.f, 0.f}, aG2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -676,74 +793,122 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
                 else aG2 = mfma4(gamR[r], pr[r], aG2);
             }
             aG += aG2;
-            // ---- per-wave partial tile to LDS.  aG: col = b = lo, row = 4g + rr -> pixel 4g + rr
+            // aG: col = b = lo, row = 4g + rr -> pixel 4g + rr
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = aG[rr];
-            part[256 + lane] = gPsi;
-            part[320 + lane] = gOm;
-            part[384 + lane] = sA;
-            part[448 + lane] = cnt;
         };
 
-        // tile tg leaves the workgroup: sum the waves' slots (fixed order), 5 float atomics.
-        auto flush = [&](int tg, const float (*pp)[NPART]) {
+        // tile tg leaves the workgroup: every wave sums one quarter of the accF tile over the four
+        // waves' slots (fixed order; slots of inactive waves hold zeros) and adds it to the packed
+        // buffer with ONE full-width float atomic (256 contiguous bytes at N_h = 16); the wave whose
+        // turn it is also adds the row of per-pixel sums [sumA | gPsi | gOmega | cnt] (branch-free).
+        auto flush = [&](int tg, const float (*pp)[NPART], bool extra) {
             const int base = 16 * tg;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = lane + 64 * q;
-                float v = 0.f;
-                for (int w = 0; w < nwav; ++w) v += pp[w][idx];
+            {
+                const int idx = lane + 64 * wv;
+                const float v = (pp[0][idx] + pp[1][idx]) + (pp[2][idx] + pp[3][idx]);
                 const int px = base + (idx >> 4), b = idx & 15;
-                if (b < Nh && px < Npix) atomicAdd(accF + (size_t)px * Nh + b, v);
+                if ((b < Nh) & (px < Npix)) atomicAdd(accF + (size_t)px * Nh + b, v);
             }
-            const int which = lane >> 4, px = base + (lane & 15);
-            float v = 0.f;
-            for (int w = 0; w < nwav; ++w) {
-                const float *q = pp[w] + 256 + which * 64 + (lane & 15);
-                v += (q[0] + q[16]) + (q[32] + q[48]);
-            }
-            if (px < Npix) {
-                if (which == 0) atomicAdd(accPsi + px, v);
-                else if (which == 1) { if (px < Nb) atomicAdd(accOm + px, v); }
-                else if (which == 2) atomicAdd(accA + px, v);
-                else atomicAdd(accCnt + px, v);
+            if (extra) {
+                const int which = lane >> 4, px = base + (lane & 15);
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float *q = pp[w] + 256 + which * 64 + (lane & 15);
+                    v += (q[0] + q[16]) + (q[32] + q[48]);
+                }
+                // accA = sumA (Npix) | gPsi (Npix) | gOmega (Nb) | cnt (Npix), contiguous
+                const int off = which * Npix - (which == 3 ? Npix - Nb : 0) + px;
+                const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
+                if (ok) atomicAdd(accA + off, v);
             }
         };
+        auto tilebuf = [&](int c) { return reinterpret_cast<const float *>(lds4[c % 3]); };
 
-        auto step = [&](int c, const SpecRegs2 &cur, SpecRegs2 &nxt, int buf) {
+        // Software pipeline over tiles (one barrier per tile, ring of 3 parameter tiles):
+        //   step c:  region 1 = stage 1 of tile c+1 (38 MFMAs, independent) beside stage 2 of tile c (VALU),
+        //            region 2 = stage 3 of tile c (68 MFMAs);
+        // so the matrix pipe has work from a neighbouring tile while the VALU does the per-pixel math.
+        f32x4 afy, aq;
+        float Psi = 0.f, om = 0.f;
+        auto step = [&](int c, const SpecRegs2 &cur, SpecRegs2 &nxt) {
             const bool more = c + 1 < n;
             const int tg = tile_of(c);
-            if (more) {
-                const int tn = tile_of(c + 1);
-                TC::load(PFT4 + (size_t)tn * NF4, tid, tv0, tv1, tv2);
+            const int pbuf = c & 1;
+            QFA_STAMP(q0)
+            f32x4 afyN = {0.f, 0.f, 0.f, 0.f}, aqN = {0.f, 0.f, 0.f, 0.f};
+            float PsiN = 0.f, omN = 0.f;
+            float betaR[4] = {0.f, 0.f, 0.f, 0.f}, gamR[4] = {0.f, 0.f, 0.f, 0.f};
+            if (active) {
+                const int cn1 = more ? c + 1 : c;                 // last tile: harmless recomputation
 #if QFA_ABL != 2
-                if (active) load_spec(tn, nxt);
+                load_spec(tile_of(cn1), nxt);
 #else
                 nxt = cur;
 #endif
+                QFA_STAMP(q1)
+                region1(tg, cur, afy, aq, Psi, om, tilebuf(cn1), afyN, aqN, PsiN, omN, betaR, gamR,
+                        ldspart[pbuf][wv]);
+                __builtin_amdgcn_sched_barrier(0);
+                QFA_STAMP(q2)
             }
-            if (active) compute(tg, cur, reinterpret_cast<const float *>(lds4[buf]), ldspart[buf][wv]);
-            if (more) TC::store(lds4[buf ^ 1], tid, tv0, tv1, tv2);
+            // parameter tile c+2: issued here so that its latency runs under stage 3
+            if (c + 2 < n) TC::load(PFT4 + (size_t)tile_of(c + 2) * NF4, tid, tv0, tv1, tv2);
+            if (active) {
+#if QFA_ABL != 5
+                stage3(tilebuf(c), betaR, gamR, ldspart[pbuf][wv]);
+#else
+                asm volatile("" ::"v"(betaR[0]), "v"(betaR[1]), "v"(betaR[2]), "v"(betaR[3]), "v"(gamR[0]), "v"(gamR[1]),
+                             "v"(gamR[2]), "v"(gamR[3]));
+#endif
+                afy = afyN; aq = aqN; Psi = PsiN; om = omN;
+                QFA_STAMP(q3)
+#if QFA_ABL == 7
+                st_t[0] += q1 - q0; st_t[1] += q2 - q1; st_t[2] += q3 - q2;
+#endif
+            }
+            QFA_STAMP(q4)
+            if (c + 2 < n) TC::store(lds4[(c + 2) % 3], tid, tv0, tv1, tv2);
+            QFA_STAMP(q5)
             __syncthreads();
-            // ldspart[buf] is rewritten two tiles later, i.e. after the next barrier
-            if (wv == (ntile_done & 3)) flush(tg, ldspart[buf]);
+            QFA_STAMP(q6)
+            // ldspart[pbuf] is rewritten two tiles later, i.e. after the next barrier
+#if QFA_ABL != 4 && !defined(QFA_NOFLUSH)
+            flush(tg, ldspart[pbuf], wv == (ntile_done & 3));
+#endif
+            QFA_STAMP(q7)
+#if QFA_ABL == 7
+            st_t[3] += q5 - q4; st_t[4] += q6 - q5; st_t[5] += q7 - q6;
+#endif
             ++ntile_done;
         };
 
         SpecRegs2 ra, rb;
         TC::load(PFT4 + (size_t)tile_of(0) * NF4, tid, tv0, tv1, tv2);
         TC::store(lds4[0], tid, tv0, tv1, tv2);
+        if (n > 1) {
+            TC::load(PFT4 + (size_t)tile_of(1) * NF4, tid, tv0, tv1, tv2);
+            TC::store(lds4[1], tid, tv0, tv1, tv2);
+        }
         if (active) load_spec(tile_of(0), ra);
         __syncthreads();
+        if (active) stage1(tilebuf(0), afy, aq, Psi, om);
         for (int c = 0; c < n; c += 2) {
-            step(c, ra, rb, 0);
-            if (c + 1 < n) step(c + 1, rb, ra, 1);
+            step(c, ra, rb);
+            if (c + 1 < n) step(c + 1, rb, ra);
         }
         __syncthreads();      // the last flush reads ldspart; the next range's first tile rewrites it
     };
     run(std::true_type{}, t0, min(t1, nbt));
     run(std::false_type{}, max(t0, nbt), t1);
 
+#if QFA_ABL == 7
+    if (blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {
+        for (int i = 0; i < 6; ++i) qfa_dbg_stamps[wv * 8 + i] = st_t[i];
+        qfa_dbg_stamps[wv * 8 + 6] = (unsigned long long)ntile_done;
+    }
+#endif
     if (!active) return;
     for (int o = 32; o >= 1; o >>= 1) {
         s_tau0 += __shfl_xor(s_tau0, o);
