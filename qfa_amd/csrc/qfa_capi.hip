@@ -118,8 +118,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     mark(2);
     sum_segments<KP>(MOM, L, st);
     constexpr int G = 64 / KP;
-    k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, 1, L.Bpad, SOL, nllbuf, NBL, B, Nh, nullptr,
-                                                                 nullptr);
+    k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr);
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
     mark(3);
     if (b.A_blue) k_grads<KP, true><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, PFT, SOL, accum);
@@ -139,7 +138,7 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     k_moments<KP, true><<<grid, 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, PF, MOM);
     sum_segments<KP>(MOM, L, st);
     constexpr int G = 64 / KP;
-    k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, 1, L.Bpad, SOL, ll, nullptr, B, Nh, hmean, hcov);
+    k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, ll, nullptr, B, Nh, hmean, hcov);
     k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);
     return hip_status();
 }

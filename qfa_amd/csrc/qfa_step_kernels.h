@@ -330,13 +330,11 @@ __global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t n4) {
 // matrices in registers; in-place Gauss-Jordan inversion in fp64, every step broadcasting the
 // pivot column with wavefront shuffles.  The pivots are the squared Cholesky diagonal, so
 // log det C = sum log(pivot) (finite where the reference's float32 det overflows, QFA/utils.py:54).
-// The nseg partial moment records of the pixel segments are summed on load.
 // ------------------------------------------------------------------------------------------------
 template <int KP, bool PREDICT>
-__global__ __launch_bounds__(256) void k_solve(const float *__restrict__ MOM, int nseg, int Bpad,
-                                               float *__restrict__ SOL, float *__restrict__ nll_out,
-                                               float *__restrict__ nblue_out, int B, int Nh,
-                                               float *__restrict__ hmean, float *__restrict__ hcov) {
+__global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
+                                               float *__restrict__ nll_out, float *__restrict__ nblue_out, int B,
+                                               int Nh, float *__restrict__ hmean, float *__restrict__ hcov) {
     using C = Cfg<KP>;
     constexpr int G = 64 / KP;
     const int lane = threadIdx.x & 63;
@@ -344,48 +342,44 @@ __global__ __launch_bounds__(256) void k_solve(const float *__restrict__ MOM, in
     const int s = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + lane / KP;
     const bool valid = s < B;
     const float *mom = MOM + (size_t)(valid ? s : B - 1) * C::NMOM;
-    const size_t segstride = (size_t)Bpad * C::NMOM;
-    auto msum = [&](int idx) {
-        double a = 0.0;
-        for (int g = 0; g < nseg; ++g) a += (double)mom[g * segstride + idx];
-        return a;
-    };
 
     double Cc[KP];
 #pragma unroll
     for (int r = 0; r < KP; ++r) {
         const int a = r < c ? r : c, b = r < c ? c : r;
-        Cc[r] = msum(pair_index(a, b, KP)) + (r == c ? 1.0 : 0.0);
+        Cc[r] = (double)mom[pair_index(a, b, KP)] + (r == c ? 1.0 : 0.0);
     }
     double logdet = 0.0;
 #pragma unroll
     for (int jj = 0; jj < KP; ++jj) {
-        double colj[KP];
-#pragma unroll
-        for (int i = 0; i < KP; ++i) colj[i] = __shfl(Cc[i], jj, KP);
-        const double piv = colj[jj];
+        // pivot column jj lives in lane jj; every element is broadcast right where it is consumed
+        const double piv = __shfl(Cc[jj], jj, KP);
         logdet += log(piv);
         const double ip = 1.0 / piv;
         const double rjc = (c == jj) ? ip : Cc[jj] * ip;
 #pragma unroll
         for (int i = 0; i < KP; ++i) {
-            if (i != jj) Cc[i] = (c == jj) ? -colj[i] * ip : Cc[i] - colj[i] * rjc;
+            if (i != jj) {
+                const double cij = __shfl(Cc[i], jj, KP);         // A[i][jj] before this step's update
+                Cc[i] = (c == jj) ? -cij * ip : Cc[i] - cij * rjc;
+            }
         }
         Cc[jj] = rjc;
+        __builtin_amdgcn_sched_barrier(0);      // keep the broadcasts of step jj+1 out of step jj (VGPR pressure)
     }
     // y = C^-1 b  (Cc[r] = Cinv[r][c] = Cinv[c][r])
-    const double bc = msum(C::MOM_B + c);
+    const double bc = (double)mom[C::MOM_B + c];
     double y = 0.0;
 #pragma unroll
     for (int r = 0; r < KP; ++r) y += Cc[r] * __shfl(bc, r, KP);
     double quad = bc * y;
 #pragma unroll
     for (int o = KP / 2; o >= 1; o >>= 1) quad += __shfl_xor(quad, o, KP);
-    const double nll = 0.5 * (msum(C::MOM_S + 0) - quad + msum(C::MOM_S + 2) * (double)QFA_LOG2PI +
-                              msum(C::MOM_S + 1) + logdet);
+    const float *sc = mom + C::MOM_S;
+    const double nll = 0.5 * ((double)sc[0] - quad + (double)sc[2] * (double)QFA_LOG2PI + (double)sc[1] + logdet);
     if (valid && c == 0) {
         nll_out[s] = (float)nll;
-        if (nblue_out) nblue_out[s] = (float)msum(C::MOM_S + 3);
+        if (nblue_out) nblue_out[s] = sc[3];
     }
 
     float *sol = SOL + (size_t)(valid ? s : 0) * C::NSOL;
@@ -404,28 +398,30 @@ __global__ __launch_bounds__(256) void k_solve(const float *__restrict__ MOM, in
         }
         return;
     }
-    // T column c (= row c), Z row c: Z[c][b] = sum_m Cinv[c][m] T[m][b]
+    // T column c (= row c); Z row c: Z[c][b] = sum_m Cinv[c][m] T[m][b] (float32 products of the
+    // float64-inverted C^-1: Z is stored in float32 anyway); p_c = b2_c - sum_m T[c][m] y_m
     float Tc[KP];
 #pragma unroll
     for (int r = 0; r < KP; ++r) {
         const int a = r < c ? r : c, b = r < c ? c : r;
-        Tc[r] = (float)msum(C::MOM_T + pair_index(a, b, KP));
+        Tc[r] = mom[C::MOM_T + pair_index(a, b, KP)];
     }
-    double Zr[KP];
+    float Zr[KP];
 #pragma unroll
-    for (int b = 0; b < KP; ++b) Zr[b] = 0.0;
+    for (int b = 0; b < KP; ++b) Zr[b] = 0.f;
 #pragma unroll
     for (int m = 0; m < KP; ++m) {
+        const float cm = (float)Cc[m];
 #pragma unroll
-        for (int b = 0; b < KP; ++b) Zr[b] += Cc[m] * (double)__shfl(Tc[m], b, KP);
+        for (int b = 0; b < KP; ++b) Zr[b] = fmaf(cm, __shfl(Tc[m], b, KP), Zr[b]);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // p_c = b2_c - sum_m T[c][m] y_m
-    double pc = msum(C::MOM_B2 + c);
+    double pc = (double)mom[C::MOM_B2 + c];
 #pragma unroll
     for (int m = 0; m < KP; ++m) pc -= (double)Tc[m] * __shfl(y, m, KP);
     if (valid) {
 #pragma unroll
-        for (int b = 0; b < KP; ++b) sol[C::SOL_Z + c * KP + b] = (float)Zr[b];
+        for (int b = 0; b < KP; ++b) sol[C::SOL_Z + c * KP + b] = Zr[b];
         sol[C::SOL_P + c] = (float)pc;
     }
 }

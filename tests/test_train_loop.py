@@ -1,0 +1,134 @@
+"""QFA.train control flow on the GPU against an oracle-driven replica of the reference loop
+(reference QFA/model.py:183-231): Niter = N // B with a trailing partial batch, Adam.step() once
+per epoch, smooth / save cadence, early stop on negative epoch loss, .npz round trip with the
+c0 <- beta load quirk."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+KEYS = ("F", "Psi", "omega", "tau0", "c0", "beta")
+
+
+class FakeLoader:
+    """Dataloader contract consumed by QFA.train (reference QFA/dataloader.py:114-138,154-167,189-191),
+    deterministic (rewind does not shuffle)."""
+
+    def __init__(self, b, mu, batch_size, device):
+        import torch
+        self.t = {k: torch.tensor(b[k], device=device) for k in ("delta", "error", "zabs", "mask")}
+        self.mu = mu
+        self.data_size = b["delta"].shape[0]
+        self.batch_size = batch_size
+        self.cur = 0
+
+    def rewind(self):
+        self.cur = 0
+
+    def have_next_batch(self):
+        return self.cur < self.data_size
+
+    def next_batch(self):
+        s, e = self.cur, min(self.cur + self.batch_size, self.data_size)
+        self.cur = e
+        return tuple(self.t[k][s:e] for k in ("delta", "error", "zabs", "mask"))
+
+
+def _oracle_train(p, b, batch_size, n_epochs, lr, alpha, step, wd, smooth_interval):
+    from oracle import qfa_oracle as O
+    params = {k: np.asarray(v, dtype=np.float64) for k, v in p.items()}
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v = {k: np.zeros_like(vv) for k, vv in params.items()}
+    N = b["delta"].shape[0]
+    niter = N // batch_size
+    losses = []
+    i = 0
+    for epoch in range(n_epochs):
+        tot = 0.0
+        for s in range(0, N, batch_size):
+            e = min(s + batch_size, N)
+            loss, g = O.forward(params, b["delta"][s:e], b["error"][s:e], b["zabs"][s:e], b["mask"][s:e])
+            tot += loss / niter
+            params, m, v = O.adam_update(m, v, i, params, g, O.step_lr(i, lr, alpha, step), weight_decay=wd)
+            params = O.clip_params(params)
+        i += 1
+        losses.append(tot)
+        if tot < 0:
+            params = O.smooth_params(params)
+            break
+        if (epoch + 1) % smooth_interval == 0:
+            params = O.smooth_params(params)
+    return params, losses
+
+
+def test_train_two_epochs_matches_oracle_loop(tmp_path, capsys):
+    import torch
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+    dev = torch.device("cuda:0")
+    wav, nb, nr = synthetic.wavelength_grid(320)
+    p, mu = synthetic.mock_parameters(320, nb, 4, seed=21)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 22, seed=211)           # 22 = 2 x 8 + 6: partial last batch
+    model = QFA(nb, nr, 4, dev, model_params=p)
+    opt = Adam(model.parameters, dev, scheduler=step_scheduler(0.9, 1), learning_rate=1e-3, weight_decay=1e-1)
+    model.train(opt, FakeLoader(b, mu, 8, dev), 2, str(tmp_path), save_interval=1, smooth_interval=2, quiet=False)
+    out = capsys.readouterr().out
+    ref, losses = _oracle_train(p, b, 8, 2, 1e-3, 0.9, 1, 1e-1, 2)
+    printed = [float(line.split("loss:")[1].split(";")[0]) for line in out.splitlines() if "loss:" in line]
+    assert len(printed) == 2
+    for a, r in zip(printed, losses):
+        assert abs(a - r) <= 0.006 + 1e-5 * abs(r)                          # printed with 2 decimals
+    assert opt.i == 2
+    for k in KEYS:
+        assert rel_l2(model.parameters[k].cpu().numpy(), ref[k]) < 2e-5, k
+    ck = os.path.join(str(tmp_path), "checkpoints")
+    assert sorted(os.listdir(ck)) == ["model_parameters_epoch_01.npz", "model_parameters_epoch_02.npz"]
+    f = np.load(os.path.join(ck, "model_parameters_epoch_02.npz"))
+    assert sorted(f.files) == sorted(["mu", "F", "Psi", "omega", "tau0", "c0", "beta"])
+    # load round trip: quirk on (reference behaviour) and off
+    m2 = QFA(nb, nr, 4, dev)
+    m2.load_from_npz(os.path.join(ck, "model_parameters_epoch_02.npz"))
+    assert torch.equal(m2.F, model.F) and torch.equal(m2.c0, model.beta)      # c0 <- beta (model.py:295)
+    m2.load_from_npz(os.path.join(ck, "model_parameters_epoch_02.npz"), reference_c0_quirk=False)
+    assert torch.equal(m2.c0, model.c0)
+    assert torch.equal(m2.mu, torch.tensor(mu, device=dev))
+
+
+def test_train_early_stop_and_zero_niter(tmp_path):
+    import torch
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+    dev = torch.device("cuda:0")
+    wav, nb, nr = synthetic.wavelength_grid(200)
+    p, mu = synthetic.mock_parameters(200, nb, 4, seed=3)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 6, seed=33, masks=False)  # (a pixel masked in a whole batch
+    b["error"] = (b["error"] * 0 + 0.01).astype(np.float32)                 #  would poison the parameters with NaN,
+    b["delta"] = (b["delta"] * 1e-3).astype(np.float32)                     #  as in the reference)
+    p2 = dict(p)
+    p2["Psi"] = np.full_like(p["Psi"], 1e-3)
+    p2["omega"] = np.full_like(p["omega"], 1e-3)
+    p2["F"] = (p["F"] * 1e-3).astype(np.float32)
+    model = QFA(nb, nr, 4, dev, model_params=p2)
+    opt = Adam(model.parameters, dev, scheduler=None, learning_rate=1e-6, weight_decay=0.0)
+    model.train(opt, FakeLoader(b, mu, 3, dev), 5, str(tmp_path), save_interval=5, smooth_interval=5, quiet=True)
+    # epoch-mean NLL is negative at once: exactly one epoch ran, smoothed and saved (model.py:224-227)
+    assert opt.i == 1
+    assert os.listdir(os.path.join(str(tmp_path), "checkpoints")) == ["model_parameters_epoch_01.npz"]
+    with pytest.raises(ZeroDivisionError):                                   # Niter = 6 // 8 = 0 (model.py:205,213)
+        model.train(opt, FakeLoader(b, mu, 8, dev), 1, str(tmp_path), quiet=True)
+
+
+def test_adam_state_dict_roundtrip():
+    import torch
+    from qfa_amd import Adam
+    dev = torch.device("cuda:0")
+    params = {"F": torch.randn(5, 2, device=dev), "Psi": torch.rand(5, device=dev)}
+    g = {k: torch.randn_like(v) for k, v in params.items()}
+    a = Adam(params, dev, scheduler=None)
+    a.update(params, g); a.step()
+    b = Adam(params, dev, scheduler=None)
+    b.load_state_dict(a.state_dict())
+    out_a, out_b = a.update(params, g), b.update(params, g)
+    for k in params:
+        assert torch.equal(out_a[k], out_b[k])
