@@ -1,0 +1,23 @@
+"""profiles/traffic_<cfg>.json from a tools/pmc.sh summary: HBM bytes per launch per kernel =
+2 * FETCH_SIZE * 1024 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md section HBM; cross-checked
+here with TCC_EA0_RDREQ_128B * 128) + WRITE_SIZE * 1024."""
+import json, re, sys
+summary, cfg, B, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+cur, vals = None, {}
+for line in open(summary):
+    if not line.startswith(" "):
+        cur = line.strip().split("<")[0]
+        vals.setdefault(cur, {})
+    else:
+        m = re.match(r"\s+(\S+)\s+mean/dispatch\s+(\S+)", line)
+        if m: vals[cur][m.group(1)] = float(m.group(2))
+res = {"config": cfg, "B": B, "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ*); "
+       "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; check: TCC_EA0_RDREQ_128B*128"}
+for k in ("k_grads", "k_moments", "k_solve"):
+    v = vals.get(k, {})
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        res[k + "_hbm_bytes_per_launch"] = 2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
+        res[k + "_read_bytes_rdreq128"] = v.get("TCC_EA0_RDREQ_128B", 0) * 128 + v.get("TCC_EA0_RDREQ_64B", 0) * 64
+        res[k + "_write_bytes"] = v["WRITE_SIZE"] * 1024
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
