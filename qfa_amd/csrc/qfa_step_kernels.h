@@ -240,12 +240,12 @@ __global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t 
 #pragma unroll
                 for (int t = 0; t < C::NFT; ++t) {
                     accb[t] = mfma4(cb[e], fbv[e & 1][t], accb[t]);
-                    accb2[t] = mfma4(cb2[e], fbv[e & 1][t], accb2[t]);
+                    if (BLUE) accb2[t] = mfma4(cb2[e], fbv[e & 1][t], accb2[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < C::NT; ++t) {
                     accC[t] = mfma4(c2[e], pbv[e & 1][t], accC[t]);
-                    accT[t] = mfma4(c3[e], pbv[e & 1][t], accT[t]);
+                    if (BLUE) accT[t] = mfma4(c3[e], pbv[e & 1][t], accT[t]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -278,8 +278,15 @@ __global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t 
             if (c + 1 < n) step(c + 1, rb, ra, 1);
         }
     };
-    run(std::true_type{}, t0, min(t1, nbt));
+    // Red tiles first: there A = 1, so T and b2 receive exactly what C and b receive -- the red loop
+    // issues only the C and b MFMAs (half the matrix work on ~60 % of the pixels) and T, b2 start
+    // the blue loop as copies.
     run(std::false_type{}, max(t0, nbt), t1);
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) accT[t] = accC[t];
+#pragma unroll
+    for (int t = 0; t < C::NFT; ++t) accb2[t] = accb[t];
+    run(std::true_type{}, t0, min(t1, nbt));
 
     if (!active) return;
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4j + r, column 16t + sl
