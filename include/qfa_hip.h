@@ -140,6 +140,23 @@ int qfa_tauhi_f32(const float *z, const float *tau0, const float *beta, float *o
 int qfa_omega_func_f32(const float *z, const float *tau0, const float *beta, const float *c0,
                        float *out, size_t n, void *stream);
 
+/* Device-side batch builder.  Replaces what Dataloader.next_batch / __init__ do
+ * on the host with numpy (reference QFA/dataloader.py:29,102,124-138 and tau_total, QFA/utils.py:174-203):
+ * for row r of the batch, spectrum s = idx ? idx[r] : r of the resident (N, Npix) flux/error arrays,
+ *   zabs  = (1+zqso) wav_blue / 1215.67 - 1,  delta = flux - mu * exp(-tau_total) (blue) | flux - mu (red),
+ *   mask  = (flux != -999) & (error != -999),  error_out = error[s].
+ * float64 arithmetic like numpy, outputs rounded to float32 once.  wav0 = wav[0] (host copy). */
+int qfa_build_batch_f32(const float *flux, const float *error, const double *zqso, const int *idx,
+                        const double *wav, double wav0, const double *mu, int which, int nrow, int Npix,
+                        int Nb, float *delta, float *error_out, float *zabs, uint8_t *mask, void *stream);
+
+/* Replaces the continuum-mean estimate of Dataloader.__init__ (reference QFA/dataloader.py:110-112):
+ * mu_raw = sum_s flux exp(+tau_total) mask / #(flux != -999); mu_smooth = reflect-padded boxcar of
+ * window_len (QFA/utils.py:206-219; may be NULL).  scratch: 2*Npix doubles. */
+int qfa_mu_estimate_f64(const float *flux, const float *error, const double *zqso, const double *wav,
+                        double wav0, int which, int B, int Npix, int Nb, int window_len, double *scratch,
+                        double *mu_raw, double *mu_smooth, void *stream);
+
 /* Replace MatrixInverse / MatrixLogDet (reference QFA/utils.py:12-54) for one (n,k) M and (n,) D:
  * inv (n,n) dense, logdet scalar (Cholesky-free Gauss-Jordan on the k x k core, finite where the
  * reference's float32 det overflows). workspace: qfa_workspace_bytes(1, n, k). */

@@ -299,3 +299,57 @@ def load_params_npz(path, quirk_c0_from_beta=True, dtype=np.float32):
     p["c0"] = np.asarray(f["beta"] if quirk_c0_from_beta else f["c0"], dtype=dtype)
     mu = np.asarray(f["mu"], dtype=dtype)
     return p, mu
+
+
+# --------------------------------------------------------------------------------------
+# host preprocessing of the reference's dataloader
+# --------------------------------------------------------------------------------------
+
+def tau_total(wav_grid, zqso, which="becker"):
+    """Total Lyman-series optical depth on the blue pixels (QFA/utils.py:174-203): every series
+    line i whose wavelength exceeds wav_grid[0] contributes tau(z_i) on the pixels blueward of it,
+    z_i = (1+zqso) wav / lambda_i - 1.  Returns (N, Nb), Nb = #(wav < 1215.6701)."""
+    wav = np.asarray(wav_grid, dtype=np.float64)
+    zq = np.asarray(zqso, dtype=np.float64).reshape(-1)
+    level = int(np.sum(wav[0] < _LYMAN_LAM))          # lambdas decrease: the first `level` lines apply
+    if level == 0:
+        raise ValueError("Wavelength grid does not cover Lyman series lines")
+    nb = int(np.sum(wav < _LYMAN_LAM[0]))
+    out = np.zeros((len(zq), nb))
+    for i in range(level):
+        n_i = int(np.sum(wav < _LYMAN_LAM[i]))
+        z_i = (zq + 1.0)[:, None] * wav[None, :n_i] / _LYMAN_LAM[i] - 1.0
+        out[:, :n_i] += tau_eff(z_i, which, i + 1)
+    return out
+
+
+def boxcar_reflect(s, window_len=32):
+    """numpy `smooth` of the reference (QFA/utils.py:206-219): reflect-pad, boxcar, trim."""
+    s = np.asarray(s, dtype=np.float64)
+    ext = np.r_[s[window_len - 1:0:-1], s, s[-2:-window_len - 1:-1]]
+    y = np.convolve(np.ones(window_len) / window_len, ext, mode="valid")
+    return y[int(window_len / 2 - 1):-int(window_len / 2)]
+
+
+def zabs_from_zqso(wav_grid, zqso, nb):
+    """(1+zqso) wav_blue / 1215.67 - 1 (QFA/dataloader.py:102)."""
+    wav = np.asarray(wav_grid, dtype=np.float64)
+    return (np.asarray(zqso, dtype=np.float64) + 1).reshape(-1, 1) * wav[:nb] / LYA - 1
+
+
+def mu_estimate(wav_grid, flux, mask, zqso, nb, which="becker", window_len=16):
+    """Mean continuum: sum_s flux * exp(+tau_total) * mask / #(flux != -999), then the boxcar
+    (QFA/dataloader.py:110-112)."""
+    flux = np.asarray(flux, dtype=np.float64)
+    up = np.ones_like(flux)
+    up[:, :nb] = np.exp(tau_total(wav_grid, zqso, which))
+    raw = np.sum(flux * up * np.asarray(mask), axis=0) / np.sum(flux != -999.0, axis=0)
+    return raw, boxcar_reflect(raw, window_len)
+
+
+def delta_from_flux(wav_grid, flux, zqso, mu, nb, which="becker"):
+    """delta = flux - mu * exp(-tau_total) (blue) / flux - mu (red) (QFA/dataloader.py:135-138)."""
+    flux = np.asarray(flux, dtype=np.float64)
+    dn = np.ones_like(flux)
+    dn[:, :nb] = np.exp(-tau_total(wav_grid, zqso, which))
+    return flux - np.asarray(mu, dtype=np.float64) * dn

@@ -2,6 +2,7 @@
 // launch geometry.  Kernels live in qfa_step_kernels.h (hot path) and qfa_small_kernels.h.
 #include "qfa_step_kernels.h"
 #include "qfa_small_kernels.h"
+#include "qfa_prep_kernels.h"
 
 // ================================================================================================
 // C ABI
@@ -279,6 +280,54 @@ int qfa_omega_func_f32(const float *z, const float *tau0, const float *beta, con
     if (!z || !out || !tau0 || !beta || !c0) return QFA_E_NULL;
     if (n == 0) return 0;
     k_omega_func<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(z, tau0, beta, c0, out, n);
+    return hip_status();
+}
+
+static int fill_lyman(int which, double wav0, LymanTable *t) {
+    double amp, scale, expo, off;
+    switch (which) {
+        case QFA_TAU_BECKER: amp = 0.751; scale = 1.0 / 4.5; expo = 2.90; off = -0.132; break;
+        case QFA_TAU_FG: amp = 0.0018; scale = 1.0; expo = 3.92; off = 0.0; break;
+        case QFA_TAU_KAMBLE: amp = 5.54e-3; scale = 1.0; expo = 3.182; off = 0.0; break;
+        case QFA_TAU_MOCK: amp = 0.2231435513142097; scale = 1.0 / 3.25; expo = 3.2; off = 0.0; break;
+        default: return QFA_E_TAU;
+    }
+    t->amp = amp; t->scale = scale; t->expo = expo; t->offset = off;
+    t->level = 0;
+    for (int i = 0; i < 30; ++i) {
+        t->lam[i] = kLymanLam[i];
+        t->coeff[i] = kLymanLam[i] * kLymanF[i] / (kLymanLam[0] * kLymanF[0]);
+        if (wav0 < kLymanLam[i]) t->level = i + 1;        // lambdas decrease (QFA/utils.py:186-192)
+    }
+    return t->level == 0 ? QFA_E_SIZE : 0;
+}
+
+int qfa_build_batch_f32(const float *flux, const float *error, const double *zqso, const int *idx, const double *wav,
+                        double wav0, const double *mu, int which, int nrow, int Npix, int Nb, float *delta,
+                        float *error_out, float *zabs, uint8_t *mask, void *stream) {
+    if (!flux || !error || !zqso || !wav || !mu || !delta || !error_out || !mask || (Nb > 0 && !zabs)) return QFA_E_NULL;
+    if (nrow < 1 || Npix < 1 || Nb < 0 || Nb > Npix) return QFA_E_SIZE;
+    LymanTable tab;
+    if (int e = fill_lyman(which, wav0, &tab)) return e;
+    const size_t tot = (size_t)nrow * Npix;
+    k_build_batch<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(flux, error, zqso, idx, wav, mu, tab, nrow,
+                                                                             Npix, Nb, delta, error_out, zabs, mask);
+    return hip_status();
+}
+
+int qfa_mu_estimate_f64(const float *flux, const float *error, const double *zqso, const double *wav, double wav0,
+                        int which, int B, int Npix, int Nb, int window_len, double *scratch, double *mu_raw,
+                        double *mu_smooth, void *stream) {
+    if (!flux || !error || !zqso || !wav || !scratch || !mu_raw) return QFA_E_NULL;
+    if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || window_len < 2 || window_len > Npix) return QFA_E_SIZE;
+    LymanTable tab;
+    if (int e = fill_lyman(which, wav0, &tab)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(scratch, 0, 2 * (size_t)Npix * sizeof(double), st);
+    const int chunk = 64;
+    const dim3 grid((Npix + 255) / 256, (B + chunk - 1) / chunk);
+    k_mu_accumulate<<<grid, 256, 0, st>>>(flux, error, zqso, wav, tab, B, Npix, Nb, chunk, scratch, scratch + Npix);
+    k_mu_finish<<<(Npix + 255) / 256, 256, 0, st>>>(scratch, scratch + Npix, Npix, window_len, mu_raw, mu_smooth);
     return hip_status();
 }
 

@@ -270,6 +270,53 @@ class QFA(object):
             _lib.current_stream(dev)), "qfa_predict_f32")
         return ll, hmean, hcov, cont, unc
 
+    def predict_to_npz(self, dataloader, output_dir, batch_size=4096):
+        """The predict mode of the reference's main.py:87-98 for a whole dataloader: one
+        ``<basename>`` .npz per spectrum with keys ll, hmean, hcov, cont, uncertainty and the
+        reference's shapes ((1,1), (Nh,1), (Nh,Nh), (Npix,), (Npix,)); the posterior runs batched."""
+        os.makedirs(output_dir, exist_ok=True)
+        n = len(dataloader)
+        written = []
+        for s in range(0, n, batch_size):
+            items = [dataloader[i] for i in range(s, min(s + batch_size, n))]
+            f, e, z, m = (torch.stack([it[j] for it in items]) for j in range(4))
+            ll, hmean, hcov, cont, unc = (x.cpu().numpy() for x in self.predict(f, e, z, m))
+            for r, it in enumerate(items):
+                name = os.path.basename(str(it[4]))
+                if not name.endswith(".npz"):
+                    name += ".npz"
+                np.savez(os.path.join(output_dir, name), ll=ll[r].reshape(1, 1), hmean=hmean[r].reshape(self.Nh, 1),
+                         hcov=hcov[r], cont=cont[r], uncertainty=unc[r])
+                written.append(name)
+        return written
+
+    def save_checkpoint(self, path, optimizer=None):
+        """Parameters + mu in the reference's .npz layout (model.py:254-280) plus, optionally, the Adam
+        state (i, m_*, v_*) the reference never saves -- so that a resumed run continues exactly."""
+        arrs = {k: getattr(self, k).detach().cpu().numpy() for k in PARAM_KEYS}
+        if self.mu is not None:
+            arrs["mu"] = self.mu.detach().cpu().numpy()
+        if optimizer is not None:
+            arrs["adam_i"] = np.asarray(optimizer.i)
+            for k in PARAM_KEYS:
+                arrs["adam_m_" + k] = optimizer.m[k].detach().cpu().numpy()
+                arrs["adam_v_" + k] = optimizer.v[k].detach().cpu().numpy()
+        np.savez(path, **arrs)
+
+    def load_checkpoint(self, path, optimizer=None):
+        """Inverse of save_checkpoint (c0 is read from c0: this is not the reference loader)."""
+        f = np.load(path)
+        def T(x):
+            return torch.tensor(np.asarray(x), dtype=f32, device=self.device).contiguous()
+        for k in PARAM_KEYS:
+            setattr(self, k, T(f[k]))
+        if "mu" in f.files:
+            self.mu = T(f["mu"])
+        if optimizer is not None and "adam_i" in f.files:
+            optimizer.i = int(f["adam_i"])
+            optimizer.m = {k: T(f["adam_m_" + k]) for k in PARAM_KEYS}
+            optimizer.v = {k: T(f["adam_v_" + k]) for k in PARAM_KEYS}
+
     def prediction_for_single_spectra(self, flux, error, zabs, mask):
         """reference QFA/model.py:160-180: ll (1,1), hmean (Nh,1), hcov (Nh,Nh), cont (Npix,), unc (Npix,)."""
         ll, hmean, hcov, cont, unc = self.predict(flux[None, :], error[None, :], zabs[None, :], mask[None, :])

@@ -19,6 +19,7 @@ Fixtures written (SURVEY.md 8(c) list):
   g8_woodbury.npz     MatrixInverse / MatrixLogDet at n=64, k=4
   g9_tau.npz          tau(which, series), tauHI, omega_func on a z grid
   g10_k16.npz         k=16 case: reference float32 loss (inf) next to per-spectrum values
+  g11_dataprep.npz    tau_total (1 and 2 Lyman series), zabs, mu estimate + smooth, delta (dataloader call sites)
   sdss_spectrum.npz   inputs flux/error/z of data/spec-4321-55504-0114.npz (MIT, see ATTRIBUTION)
   model_parameters.npz  copy of data/model_parameters.npz (MIT, see ATTRIBUTION)
 """
@@ -208,6 +209,32 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g10_k16.npz"), seed=20220710, n_pix=4000, loss=loss.numpy(),
                         **{f"g_{k}": v for k, v in npd(g).items()})
     print("reference k=16 float32 loss:", loss)
+
+    # ---- G11: host preprocessing of the dataloader (next row N1) -------------------------------
+    # tau_total / smooth come from the imported reference (QFA/utils.py:174-219); the three
+    # expressions around them are the call sites QFA/dataloader.py:102, 110-112, 135-138.
+    r11 = np.random.default_rng(11)
+    zq = r11.uniform(2.0, 3.5, size=6)
+    wav_lo = 10 ** np.arange(np.log10(1000.0), np.log10(1600.0), 1e-4)     # reaches below Ly-beta: 2 series
+    out11 = {"zqso": zq}
+    for tag, wv in (("c1", wav), ("lyb", wav_lo)):
+        nbb = int(np.sum(wv < 1215.67))
+        fl = 1.0 + 0.3 * r11.standard_normal((6, len(wv)))
+        mk = r11.random((6, len(wv))) > 0.05
+        fl = np.where(mk, fl, -999.0)
+        for which in ("becker", "kamble"):
+            tt = utils.tau_total(wv, zq, which=which)
+            out11[f"tau_total_{tag}_{which}"] = tt
+        tt = utils.tau_total(wv, zq, which="becker")
+        zabs11 = (zq + 1).reshape(-1, 1) * wv[:nbb] / 1215.67 - 1
+        s_up = np.hstack((np.exp(1 * tt), np.ones((6, len(wv) - nbb), dtype=float)))
+        mu_raw = np.sum(fl * s_up * mk, axis=0) / np.sum(fl != -999., axis=0)
+        mu_s = utils.smooth(mu_raw, window_len=16)
+        s_dn = np.hstack((np.exp(-1 * tt), np.ones((6, len(wv) - nbb), dtype=float)))
+        delta11 = fl - mu_s * s_dn
+        out11.update({f"wav_{tag}": wv, f"flux_{tag}": fl, f"zabs_{tag}": zabs11, f"mu_raw_{tag}": mu_raw,
+                      f"mu_{tag}": mu_s, f"delta_{tag}": delta11})
+    np.savez_compressed(os.path.join(HERE, "g11_dataprep.npz"), **out11)
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -199,3 +199,23 @@ def test_oracle_float32_mode_close_to_float64(shipped, grid):
     n32, g32 = O.nll_and_grads_single(p, b["delta"][0], b["error"][0], b["zabs"][0], b["mask"][0], dtype=np.float32)
     assert abs(n32 - n64) / abs(n64) < 1e-4
     assert rel_l2(g32["Psi"], g64["Psi"]) < 1e-3
+
+
+def test_g11_dataloader_preprocessing():
+    g = golden("g11_dataprep.npz")
+    zq = g["zqso"]
+    for tag in ("c1", "lyb"):
+        wav = g[f"wav_{tag}"]
+        nb = int(np.sum(wav < 1215.67))
+        for which in ("becker", "kamble"):
+            tt = O.tau_total(wav, zq, which)
+            assert tt.shape == g[f"tau_total_{tag}_{which}"].shape
+            assert rel_l2(tt, g[f"tau_total_{tag}_{which}"]) < 1e-12
+        assert rel_l2(O.zabs_from_zqso(wav, zq, nb), g[f"zabs_{tag}"]) < 1e-14
+        flux = g[f"flux_{tag}"]
+        raw, mu = O.mu_estimate(wav, flux, flux != -999.0, zq, nb)
+        assert rel_l2(raw, g[f"mu_raw_{tag}"]) < 1e-12
+        assert rel_l2(mu, g[f"mu_{tag}"]) < 1e-12
+        assert rel_l2(O.delta_from_flux(wav, flux, zq, mu, nb), g[f"delta_{tag}"]) < 1e-12
+    # the second grid reaches below Ly-beta: two series contribute there
+    assert int(np.sum(g["wav_lyb"][0] < O._LYMAN_LAM)) == 2

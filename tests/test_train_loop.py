@@ -132,3 +132,47 @@ def test_adam_state_dict_roundtrip():
     out_a, out_b = a.update(params, g), b.update(params, g)
     for k in params:
         assert torch.equal(out_a[k], out_b[k])
+
+
+def test_predict_writer_and_checkpoint_resume(tmp_path):
+    """Row N2: per-spectrum .npz of main.py:94-98 (batched) and a checkpoint that carries the Adam state."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+    from qfa_amd.dataloader import DeviceDataloader
+    dev = torch.device("cuda:0")
+    wav, nb, nr = synthetic.wavelength_grid(256)
+    p, mu0 = synthetic.mock_parameters(256, nb, 4, seed=8)
+    b = synthetic.make_batch_numpy(p, mu0, wav, nb, 9, seed=81)
+    paths = [f"/data/spec-{i:04d}.npz" for i in range(9)]
+    dl = DeviceDataloader(b["flux"], b["error"], b["zqso"], wav, batch_size=4, device=dev, shuffle=False, paths=paths)
+    model = QFA(nb, nr, 4, dev, model_params=p)
+    model.mu = torch.tensor(dl.mu, dtype=torch.float32, device=dev)
+    out = tmp_path / "predict"
+    names = model.predict_to_npz(dl, str(out), batch_size=4)
+    assert names == [f"spec-{i:04d}.npz" for i in range(9)]
+    mu32 = model.mu.cpu().numpy()
+    for i in (0, 5, 8):
+        f = np.load(out / names[i])
+        assert sorted(f.files) == ["cont", "hcov", "hmean", "ll", "uncertainty"]
+        assert f["ll"].shape == (1, 1) and f["hmean"].shape == (4, 1) and f["hcov"].shape == (4, 4)
+        zabs = O.zabs_from_zqso(wav, b["zqso"][i:i + 1], nb)[0].astype(np.float32)
+        o = O.predict_single(p, mu32, b["flux"][i], b["error"][i], zabs, b["mask"][i])
+        assert abs(f["ll"].item() - o[0]) / abs(o[0]) < 1e-5
+        assert rel_l2(f["cont"], o[3]) < 1e-4 and rel_l2(f["uncertainty"], o[4]) < 1e-4
+    # checkpoint with optimiser state: a resumed run reproduces the uninterrupted one (up to the
+    # re-association of the float atomics between two launches)
+    T = lambda k: torch.tensor(b[k], device=dev)
+    args = (T("delta"), T("error"), T("zabs"), T("mask"))
+    m1 = QFA(nb, nr, 4, dev, model_params=p)
+    o1 = Adam(m1.parameters, dev, scheduler=step_scheduler(0.9, 1), learning_rate=1e-3, weight_decay=1e-1)
+    m1.step(o1, *args); o1.step()
+    m1.save_checkpoint(str(tmp_path / "ck.npz"), o1)
+    m1.step(o1, *args)
+    m2 = QFA(nb, nr, 4, dev)
+    o2 = Adam(m2.parameters, dev, scheduler=step_scheduler(0.9, 1), learning_rate=1e-3, weight_decay=1e-1)
+    m2.load_checkpoint(str(tmp_path / "ck.npz"), o2)
+    assert o2.i == 1
+    m2.step(o2, *args)
+    for k in KEYS:
+        assert rel_l2(m2.parameters[k].cpu().numpy(), m1.parameters[k].cpu().numpy()) < 1e-6, k
