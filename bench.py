@@ -102,8 +102,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("QFA_BENCH_FORCE_DIST") == "1"     # (the flag rehearses RCCL at N = 1)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, npix, nh, masks, n_cpu = CONFIGS[args.config]
@@ -126,7 +128,7 @@ def main():
 
     model = QFA(nb, nr, nh, dev, model_params=params)
     model.mu = torch.tensor(mu, device=dev)
-    if world > 1:
+    if use_dist:
         model.enable_data_parallel()
     opt = Adam(model.parameters, dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3, weight_decay=1e-1)
 
@@ -137,7 +139,7 @@ def main():
         for e in es:
             e.record()          # creates the underlying hipEvent_t; re-recorded by the library
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -145,11 +147,11 @@ def main():
     for i in range(args.steps):
         losses.append(model.step(opt, *batch, events=evs[i]))
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -196,7 +198,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(params, batch, n_cpu, npix)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
