@@ -36,6 +36,7 @@ CONFIGS = {
     "c2": (10000, 2000, 8, False, 32),
     "c3": (100000, 4000, 16, True, 12),
     "c1": (128, 1913, 8, True, 32),
+    "c5": (20000, 8000, 32, True, 2),
 }
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -114,7 +115,7 @@ def main():
     wav, nb, nr = synthetic.wavelength_grid(None if args.config == "c1" else npix)
     npix = len(wav)
     params, mu = synthetic.mock_parameters(npix, nb, nh, seed=20220700)
-    cfg_index = {"c1": 1, "c2": 2, "c3": 3}[args.config]
+    cfg_index = {"c1": 1, "c2": 2, "c3": 3, "c5": 5}[args.config]
     # generate in slabs to bound temporary memory
     parts = []
     slab = 25000

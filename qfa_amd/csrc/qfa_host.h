@@ -1,0 +1,149 @@
+// qfa_host.h -- host side of the step: workspace layout, launch geometry, kernel sequences.
+// Shared by qfa_capi.hip (N_h <= 16; built with -amdgpu-mfma-vgpr-form so that the MFMA accumulators
+// stay in VGPRs) and qfa_k32.hip (N_h in 17..32: 280 accumulator registers per lane need the AGPR
+// half of the register file, so that translation unit is built without the flag).
+#pragma once
+#include "qfa_step_kernels.h"
+
+namespace {
+
+inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
+
+// Pixel-axis segmentation (grid.y): both passes run (#spectra tiles / 4) x nseg workgroups.  nseg is
+// the smallest split that fills the resident-workgroup slots of the chip to >= 90 % in the last
+// round (tail quantisation) -- it also lets small batches use every CU.
+constexpr int kMaxSeg = 8;
+
+inline int pick_nseg(int B, int ntiles) {
+    const int slots = 256 * 2;                      // CUs x resident 256-thread workgroups per CU
+    const int nblk = (B + 63) / 64;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int n = 1; n <= kMaxSeg; ++n) {
+        if (n > 1 && ntiles / n < 8) break;         // keep segments >= 128 px
+        const double x = (double)nblk * n / slots;
+        const double eff = x / (double)(long long)(x + 0.999999);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = n; }
+        if (eff >= 0.9) { best = n; break; }
+    }
+    return best;
+}
+
+struct Layout {
+    int KP, NpixPad, ntiles, Bpad, nseg, seg_tiles;
+    size_t oPF, oPFT, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
+};
+
+template <int KP>
+Layout make_layout_t(int B, int Npix) {
+    using C = Cfg<KP>;
+    Layout L;
+    L.KP = KP;
+    L.NpixPad = round_up(Npix, 16);
+    L.ntiles = L.NpixPad / 16;
+    L.Bpad = round_up(B, 16);
+    L.nseg = pick_nseg(B, L.ntiles);
+    L.seg_tiles = (L.ntiles + L.nseg - 1) / L.nseg;
+    L.nseg = (L.ntiles + L.seg_tiles - 1) / L.seg_tiles;          // no empty segment
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
+    L.oPF = take((size_t)L.ntiles * C::TILE_PF);
+    L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
+    L.oMOM = take((size_t)kMaxSeg * L.Bpad * C::NMOM);
+    L.oSOL = take((size_t)L.Bpad * C::NSOL);
+    L.oNLL = take((size_t)L.Bpad);
+    L.oNBL = take((size_t)L.Bpad);
+    L.total = o;
+    return L;
+}
+
+Layout make_layout(int B, int Npix, int Nh) {
+    switch (kp_for(Nh)) {
+        case 8: return make_layout_t<8>(B, Npix);
+        case 16: return make_layout_t<16>(B, Npix);
+        default: return make_layout_t<32>(B, Npix);
+    }
+}
+
+inline int check_shape(int B, int Npix, int Nb, int Nh) {
+    if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || Nh < 1 || Nh > 32) return QFA_E_SIZE;
+    if ((long long)16 * Npix >= (1LL << 31)) return QFA_E_SIZE;
+    return 0;
+}
+
+inline int hip_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+template <int KP>
+void launch_prep(const qfa_params_t &p, int Npix, int Nb, int Nh, const Layout &L, float *PF, float *PFT,
+                 hipStream_t st) {
+    dim3 blk(64, 4);
+    k_prep_pf<KP><<<(L.NpixPad + 3) / 4, blk, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, L.NpixPad, PF, PFT);
+}
+
+template <int KP>
+void sum_segments(float *MOM, const Layout &L, hipStream_t st) {
+    if (L.nseg <= 1) return;
+    const size_t n4 = (size_t)L.Bpad * Cfg<KP>::NMOM / 4;      // Bpad*NMOM is a multiple of 4
+    k_sum_segments<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(reinterpret_cast<float4 *>(MOM), L.nseg, n4);
+}
+
+template <int KP>
+int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                 float *nll, float *accum, float *ws, hipStream_t st, void *const *events) {
+    const Layout L = make_layout_t<KP>(B, Npix);
+    float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL, *NBL = ws + L.oNBL;
+    float *nllbuf = nll ? nll : ws + L.oNLL;
+    const size_t accS = (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
+    auto mark = [&](int i) {
+        if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
+    };
+    mark(0);
+    launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
+    mark(1);
+    const dim3 grid((B + 63) / 64, L.nseg);
+    k_moments<KP, false><<<grid, 256, 0, st>>>(p, b, tau, nullptr, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, PF, MOM);
+    mark(2);
+    sum_segments<KP>(MOM, L, st);
+    constexpr int G = 64 / KP;
+    k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr);
+    k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
+    mark(3);
+    for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
+        if (16 * bh >= Nh) break;
+        if (b.A_blue)
+            k_grads<KP, true><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, bh, PFT, SOL, accum);
+        else
+            k_grads<KP, false><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, bh, PFT, SOL, accum);
+    }
+    mark(4);
+    return hip_status();
+}
+
+template <int KP>
+int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
+                int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
+                hipStream_t st) {
+    const Layout L = make_layout_t<KP>(B, Npix);
+    float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL;
+    launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
+    const dim3 grid((B + 63) / 64, L.nseg);
+    k_moments<KP, true><<<grid, 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, PF, MOM);
+    sum_segments<KP>(MOM, L, st);
+    constexpr int G = 64 / KP;
+    k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, ll, nullptr, B, Nh, hmean, hcov);
+    k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);
+    return hip_status();
+}
+
+
+}  // namespace
+
+// N_h in 17..32 (defined in qfa_k32.hip)
+int qfa_k32_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                     float *nll, float *accum, float *ws, hipStream_t st, void *const *events);
+int qfa_k32_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
+                    int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
+                    hipStream_t st);

@@ -57,24 +57,33 @@ __global__ void k_prep_pf(const float *__restrict__ F, const float *__restrict__
     for (int r = C::PFT_PSI + 2 + threadIdx.x; r < C::NR; r += blockDim.x) pft[r * 16] = 0.f;
 }
 
-// copy one contiguous tile (NF4 float4) global -> registers -> LDS with all 256 threads; the staging
-// registers are plain locals of the kernel (a struct captured by the nested lambdas ended up in scratch).
+// copy one contiguous tile (NF4 float4) global -> registers -> LDS with all 256 threads.  The first
+// three staging registers are named locals of the kernel (an array or a struct captured by the nested
+// lambdas ended up in scratch for N = 3); tiles of N_h > 16 continue in a local array.
 template <int NF4>
 struct TileCopy {
     static constexpr int N = (NF4 + 255) / 256;
-    static_assert(N <= 3, "tile larger than 3 x 256 float4");
+    static constexpr int NX = N > 3 ? N - 3 : 1;
     static __device__ __forceinline__ bool in(int i, int idx) { return 256 * i + 255 < NF4 || idx < NF4; }
+    static __device__ __forceinline__ float4 ld(const float4 *__restrict__ src, int i, int tid) {
+        return src[in(i, tid + 256 * i) ? tid + 256 * i : NF4 - 1];
+    }
     static __device__ __forceinline__ void load(const float4 *__restrict__ src, int tid, float4 &v0, float4 &v1,
-                                                float4 &v2) {
-        v0 = src[in(0, tid) ? tid : NF4 - 1];
-        if (N > 1) v1 = src[in(1, tid + 256) ? tid + 256 : NF4 - 1];
-        if (N > 2) v2 = src[in(2, tid + 512) ? tid + 512 : NF4 - 1];
+                                                float4 &v2, float4 (&vx)[NX]) {
+        v0 = ld(src, 0, tid);
+        if (N > 1) v1 = ld(src, 1, tid);
+        if (N > 2) v2 = ld(src, 2, tid);
+#pragma unroll
+        for (int i = 3; i < N; ++i) vx[i - 3] = ld(src, i, tid);
     }
     static __device__ __forceinline__ void store(float4 *dst, int tid, const float4 &v0, const float4 &v1,
-                                                 const float4 &v2) {
+                                                 const float4 &v2, const float4 (&vx)[NX]) {
         if (in(0, tid)) dst[tid] = v0;
         if (N > 1 && in(1, tid + 256)) dst[tid + 256] = v1;
         if (N > 2 && in(2, tid + 512)) dst[tid + 512] = v2;
+#pragma unroll
+        for (int i = 3; i < N; ++i)
+            if (in(i, tid + 256 * i)) dst[tid + 256 * i] = vx[i - 3];
     }
 };
 
@@ -97,7 +106,7 @@ struct SpecRegs1 {
 };
 
 template <int KP, bool PREDICT>
-__global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
+__global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                  const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
                                                  int ntiles, int seg_tiles, const float *__restrict__ PF,
                                                  float *__restrict__ MOM) {
@@ -131,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t 
     for (int t = 0; t < C::NFT; ++t) accb[t] = accb2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     double qd = 0.0, ld = 0.0;        // float32 inside a 4-pixel group, float64 across groups
     float cn = 0.f, cblue = 0.f;
-    float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f};
     using TC = TileCopy<NF4>;
+    float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f}, tvx[TC::NX];
 
     auto run = [&](auto blue_tag, int ta, int tb) {
         constexpr bool BLUE = decltype(blue_tag)::value;
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t 
         auto step = [&](int c, const SpecRegs1 &cur, SpecRegs1 &nxt, int buf) {
             const bool more = c + 1 < n;
             if (more) {
-                TC::load(PF4 + (size_t)(ta + c + 1) * NF4, tid, tv0, tv1, tv2);
+                TC::load(PF4 + (size_t)(ta + c + 1) * NF4, tid, tv0, tv1, tv2, tvx);
 #if QFA_ABL != 2
                 if (active) load_spec(ta + c + 1, nxt);
 #else
@@ -264,13 +273,13 @@ __global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t 
 #endif
             }
             if (active) compute(ta + c, cur, reinterpret_cast<const float *>(lds4[buf]));
-            if (more) TC::store(lds4[buf ^ 1], tid, tv0, tv1, tv2);
+            if (more) TC::store(lds4[buf ^ 1], tid, tv0, tv1, tv2, tvx);
             __syncthreads();
         };
 
         SpecRegs1 ra, rb;
-        TC::load(PF4 + (size_t)ta * NF4, tid, tv0, tv1, tv2);
-        TC::store(lds4[0], tid, tv0, tv1, tv2);
+        TC::load(PF4 + (size_t)ta * NF4, tid, tv0, tv1, tv2, tvx);
+        TC::store(lds4[0], tid, tv0, tv1, tv2, tvx);
         if (active) load_spec(ta, ra);
         __syncthreads();
         for (int c = 0; c < n; c += 2) {
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void k_moments(qfa_params_t p, qfa_batch_t 
 // ------------------------------------------------------------------------------------------------
 // k_sum_segments : MOM[0] += MOM[1] + ... + MOM[nseg-1] (fixed order), float4-vectorised.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t n4) {
+static __global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t n4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     float4 a = mom[i];
@@ -339,7 +348,7 @@ __global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t n4) {
 // log det C = sum log(pivot) (finite where the reference's float32 det overflows, QFA/utils.py:54).
 // ------------------------------------------------------------------------------------------------
 template <int KP, bool PREDICT>
-__global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
+__global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
                                                float *__restrict__ nll_out, float *__restrict__ nblue_out, int B,
                                                int Nh, float *__restrict__ hmean, float *__restrict__ hcov) {
     using C = Cfg<KP>;
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM,
 // k_reduce_nll : accum scalars += {#spectra with an unmasked blue pixel, sum NLL, B}.  One block,
 // fp64 partial sums, fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_reduce_nll(const float *__restrict__ nll, const float *__restrict__ nblue,
+static __global__ __launch_bounds__(1024) void k_reduce_nll(const float *__restrict__ nll, const float *__restrict__ nblue,
                                                      int B, float *__restrict__ scal) {
     __shared__ double sh[2][16];
     double a = 0.0, nb = 0.0;
@@ -485,10 +494,13 @@ struct SpecRegs2 {
 };
 
 template <int KP, bool HASA>
-__global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix,
-                                               int Nb, int Nh, int ntiles, int seg_tiles,
-                                               const float *__restrict__ PFT, const float *__restrict__ SOL,
-                                               float *__restrict__ accum) {
+__global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B,
+                                                              int Npix, int Nb, int Nh, int ntiles, int seg_tiles,
+                                                              int bhalf, const float *__restrict__ PFT,
+                                                              const float *__restrict__ SOL,
+                                                              float *__restrict__ accum) {
+    // bhalf: which 16 columns of the F gradient this launch produces (N_h > 16 runs the kernel once per
+    // half; the per-pixel and scalar sums are added by the bhalf == 0 launch only)
     using C = Cfg<KP>;
     constexpr int KF = KP / 4, KQ = C::KK2 / 4;
     constexpr int NF4 = C::TILE_PFT / 4;
@@ -537,11 +549,12 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
     for (int r = 0; r < 4; ++r) {
         const int srel = 4 * g + r;
         sv[r] = active && (s0 + srel) < B;
-        const bool v = sv[r] && lo < KP;
+        const int col = 16 * bhalf + lo;
+        const bool v = sv[r] && col < KP;
         const float *sol = SOL + (size_t)(v ? s0 + srel : 0) * C::NSOL;
 #pragma unroll
-        for (int a = 0; a < KP; ++a) Zr[r][a] = v ? sol[C::SOL_Z + a * KP + lo] : 0.f;
-        pr[r] = v ? sol[C::SOL_P + lo] : 0.f;
+        for (int a = 0; a < KP; ++a) Zr[r][a] = v ? sol[C::SOL_Z + a * KP + col] : 0.f;
+        pr[r] = v ? sol[C::SOL_P + col] : 0.f;
         const int sc = active ? min(srel, B - 1 - s0) : 0;
         offN[r] = sc * Npix;
         offB[r] = sc * Nb;
@@ -552,8 +565,8 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
     const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
     const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
     const float4 *PFT4 = reinterpret_cast<const float4 *>(PFT);
-    float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f};
     using TC = TileCopy<NF4>;
+    float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f}, tvx[TC::NX];
     double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;   // float32 per tile, float64 across tiles
     int ntile_done = 0;                               // picks the flushing wave, round robin
 #if QFA_ABL == 7      // diagnostic build: where does a tile step spend its cycles (never shipped)
@@ -637,10 +650,11 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
                 else if (t < NK1 && (t & 1)) a1 = mfma4(qA[t < NK1 ? t - KF : 0], bop[t & 7], a1);
                 else if (t < NK1) a2 = mfma4(qA[t < NK1 ? t - KF : 0], bop[t & 7], a2);
             };
+            constexpr int SF = (NK1 + 39) / 40;      // MFMAs per slot (1 up to N_h = 16, 4 at N_h = 32)
             int slot_no = 0;
-            auto slots = [&](int nmf) {              // nmf MFMA slots, then fence
+            auto slots = [&](int nslot) {            // nslot MFMA slots, then fence
 #pragma unroll
-                for (int i = 0; i < nmf; ++i) {
+                for (int i = 0; i < nslot * SF; ++i) {
                     rd(slot_no + AHEAD);
                     mf(slot_no);
                     ++slot_no;
@@ -765,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
                     slots(8);
                 }
             }
-            static_assert(NK1 <= 40, "stage 1 has more K-steps than MFMA slots");
+            static_assert(NK1 <= 40 * SF && AHEAD < 8, "stage 1 has more K-steps than MFMA slots");
             if (BLUE) {
                 s_tau0 += (double)t_tau0;
                 s_c0 += (double)t_c0;
@@ -810,10 +824,10 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
             {
                 const int idx = lane + 64 * wv;
                 const float v = (pp[0][idx] + pp[1][idx]) + (pp[2][idx] + pp[3][idx]);
-                const int px = base + (idx >> 4), b = idx & 15;
+                const int px = base + (idx >> 4), b = 16 * bhalf + (idx & 15);
                 if ((b < Nh) & (px < Npix)) atomicAdd(accF + (size_t)px * Nh + b, v);
             }
-            if (extra) {
+            if (extra & (bhalf == 0)) {
                 const int which = lane >> 4, px = base + (lane & 15);
                 float v = 0.f;
 #pragma unroll
@@ -857,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
                 QFA_STAMP(q2)
             }
             // parameter tile c+2: issued here so that its latency runs under stage 3
-            if (c + 2 < n) TC::load(PFT4 + (size_t)tile_of(c + 2) * NF4, tid, tv0, tv1, tv2);
+            if (c + 2 < n) TC::load(PFT4 + (size_t)tile_of(c + 2) * NF4, tid, tv0, tv1, tv2, tvx);
             if (active) {
 #if QFA_ABL != 5
                 stage3(tilebuf(c), betaR, gamR, ldspart[pbuf][wv]);
@@ -872,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
 #endif
             }
             QFA_STAMP(q4)
-            if (c + 2 < n) TC::store(lds4[(c + 2) % 3], tid, tv0, tv1, tv2);
+            if (c + 2 < n) TC::store(lds4[(c + 2) % 3], tid, tv0, tv1, tv2, tvx);
             QFA_STAMP(q5)
             __syncthreads();
             QFA_STAMP(q6)
@@ -888,11 +902,11 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
         };
 
         SpecRegs2 ra, rb;
-        TC::load(PFT4 + (size_t)tile_of(0) * NF4, tid, tv0, tv1, tv2);
-        TC::store(lds4[0], tid, tv0, tv1, tv2);
+        TC::load(PFT4 + (size_t)tile_of(0) * NF4, tid, tv0, tv1, tv2, tvx);
+        TC::store(lds4[0], tid, tv0, tv1, tv2, tvx);
         if (n > 1) {
-            TC::load(PFT4 + (size_t)tile_of(1) * NF4, tid, tv0, tv1, tv2);
-            TC::store(lds4[1], tid, tv0, tv1, tv2);
+            TC::load(PFT4 + (size_t)tile_of(1) * NF4, tid, tv0, tv1, tv2, tvx);
+            TC::store(lds4[1], tid, tv0, tv1, tv2, tvx);
         }
         if (active) load_spec(tile_of(0), ra);
         __syncthreads();
@@ -918,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void k_grads(qfa_params_t p, qfa_batch_t bt
         s_c0 += __shfl_xor(s_c0, o);
         s_beta += __shfl_xor(s_beta, o);
     }
-    if (lane == 0) {
+    if (lane == 0 && bhalf == 0) {
         atomicAdd(accS + 0, (float)s_tau0);
         atomicAdd(accS + 1, (float)s_c0);
         atomicAdd(accS + 2, (float)s_beta);

@@ -49,7 +49,7 @@ def test_host_only_entry_points():
     assert h.qfa_accum_floats(1913, 720, 8) == 1913 * 8 + 3 * 1913 + 720 + 8
     assert h.qfa_workspace_bytes(128, 1913, 8) > 0
     assert h.qfa_workspace_bytes(0, 1913, 8) == 0
-    assert h.qfa_workspace_bytes(4, 100, 33) == 0
+    assert h.qfa_workspace_bytes(4, 100, 33) == 0 and h.qfa_workspace_bytes(4, 100, 32) > 0
     # argument validation happens before any device work
     assert h.qfa_nll_grad_f32(None, None, None, 1, 1, 1, 1, None, None, None, 0, None) == -1
     assert h.qfa_adam_clip_f32(None, None, None, None, None, 4, 0, 0, 0, 0, 0, 0, 0, 0, None) == -1
