@@ -570,9 +570,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;   // float32 per tile, float64 across tiles
     int ntile_done = 0;                               // picks the flushing wave, round robin
 #if QFA_ABL == 7      // diagnostic build: where does a tile step spend its cycles (never shipped)
-    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [blue 0..6 | red 8..14]
 #define QFA_STAMP(var)                                                                      \
-    unsigned long long var;                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                      \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");            \
     __builtin_amdgcn_sched_barrier(0);
@@ -853,6 +852,9 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
             const bool more = c + 1 < n;
             const int tg = tile_of(c);
             const int pbuf = c & 1;
+#if QFA_ABL == 7
+            unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0;
+#endif
             QFA_STAMP(q0)
             f32x4 afyN = {0.f, 0.f, 0.f, 0.f}, aqN = {0.f, 0.f, 0.f, 0.f};
             float PsiN = 0.f, omN = 0.f;
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
                 afy = afyN; aq = aqN; Psi = PsiN; om = omN;
                 QFA_STAMP(q3)
 #if QFA_ABL == 7
-                st_t[0] += q1 - q0; st_t[1] += q2 - q1; st_t[2] += q3 - q2;
+                st_t[(BLUE ? 0 : 8) + 0] += q1 - q0; st_t[(BLUE ? 0 : 8) + 1] += q2 - q1; st_t[(BLUE ? 0 : 8) + 2] += q3 - q2;
 #endif
             }
             QFA_STAMP(q4)
@@ -896,7 +898,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
 #endif
             QFA_STAMP(q7)
 #if QFA_ABL == 7
-            st_t[3] += q5 - q4; st_t[4] += q6 - q5; st_t[5] += q7 - q6;
+            st_t[(BLUE ? 0 : 8) + 3] += q5 - q4; st_t[(BLUE ? 0 : 8) + 4] += q6 - q5; st_t[(BLUE ? 0 : 8) + 5] += q7 - q6;
+            st_t[(BLUE ? 0 : 8) + 6] += 1;
 #endif
             ++ntile_done;
         };
@@ -921,9 +924,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     run(std::false_type{}, max(t0, nbt), t1);
 
 #if QFA_ABL == 7
-    if (blockIdx.x == 300 && blockIdx.y == 0 && lane == 0) {
-        for (int i = 0; i < 6; ++i) qfa_dbg_stamps[wv * 8 + i] = st_t[i];
-        qfa_dbg_stamps[wv * 8 + 6] = (unsigned long long)ntile_done;
+    if (blockIdx.x == 300 && lane == 0 && wv == 0 && blockIdx.y < 4) {
+        for (int i = 0; i < 16; ++i) qfa_dbg_stamps[blockIdx.y * 16 + i] = st_t[i];
     }
 #endif
     if (!active) return;

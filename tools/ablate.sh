@@ -2,7 +2,7 @@
 # GPU box: timing-only ablation builds of the hot kernels (results are wrong by construction).
 cd $GRAFT_REPO_ROOT
 for a in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fno-math-errno -mllvm -amdgpu-mfma-vgpr-form -DQFA_ABL=$a qfa_amd/csrc/qfa_capi.hip -o /tmp/libqfa_abl$a.so || exit 1
+  tools/build_variant.sh /tmp/libqfa_abl$a.so -DQFA_ABL=$a || exit 1
   QFA_HIP_LIB=/tmp/libqfa_abl$a.so timeout -k 10 300 python bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/abl_$a.json 2> gpurun_out/abl_$a.err
   python - <<PY
 import json

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 i=0
 for fl in "$@"; do
   i=$((i+1))
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fno-math-errno -mllvm -amdgpu-mfma-vgpr-form $fl qfa_amd/csrc/qfa_capi.hip -o /tmp/libqfa_try$i.so || exit 1
+  tools/build_variant.sh /tmp/libqfa_try$i.so $fl || exit 1
   QFA_HIP_LIB=/tmp/libqfa_try$i.so timeout -k 10 300 python bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/try_$i.json 2> gpurun_out/try_$i.err
   python - <<PY
 import json
