@@ -4,6 +4,7 @@
 // half of the register file, so that translation unit is built without the flag).
 #pragma once
 #include "qfa_step_kernels.h"
+#include "qfa_xdl_kernels.h"
 
 namespace {
 
@@ -31,7 +32,8 @@ inline int pick_nseg(int B, int ntiles) {
 
 struct Layout {
     int KP, NpixPad, ntiles, Bpad, nseg, seg_tiles;
-    size_t oPF, oPFT, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
+    int ntiles32, nseg1, seg_tiles1;                   // pass 1 on the XDL pipe walks 32-pixel tiles (N_h <= 16)
+    size_t oPF, oPFT, oPFX, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
 };
 
 template <int KP>
@@ -49,6 +51,12 @@ Layout make_layout_t(int B, int Npix) {
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
     L.oPF = take((size_t)L.ntiles * C::TILE_PF);
     L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
+    L.ntiles32 = (Npix + 31) / 32;
+    L.nseg1 = pick_nseg(B, L.ntiles32);
+    L.seg_tiles1 = (L.ntiles32 + L.nseg1 - 1) / L.nseg1;
+    L.nseg1 = (L.ntiles32 + L.seg_tiles1 - 1) / L.seg_tiles1;
+    L.oPFX = 0;
+    if constexpr (KP <= 16) L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4));
     L.oMOM = take((size_t)kMaxSeg * L.Bpad * C::NMOM);
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
     L.oNLL = take((size_t)L.Bpad);
@@ -84,10 +92,28 @@ void launch_prep(const qfa_params_t &p, int Npix, int Nb, int Nh, const Layout &
 }
 
 template <int KP>
-void sum_segments(float *MOM, const Layout &L, hipStream_t st) {
-    if (L.nseg <= 1) return;
+void sum_segments(float *MOM, const Layout &L, int nseg, hipStream_t st) {
+    if (nseg <= 1) return;
     const size_t n4 = (size_t)L.Bpad * Cfg<KP>::NMOM / 4;      // Bpad*NMOM is a multiple of 4
-    k_sum_segments<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(reinterpret_cast<float4 *>(MOM), L.nseg, n4);
+    k_sum_segments<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(reinterpret_cast<float4 *>(MOM), nseg, n4);
+}
+
+// pass 1: N_h <= 16 on the XDL pipe (split-bf16 operands, 32-pixel tiles), wider models on the f32 MFMA
+template <int KP, bool PREDICT>
+int launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, const float *mu, int B, int Npix,
+                   int Nb, int Nh, const Layout &L, float *ws, hipStream_t st) {
+    float *MOM = ws + L.oMOM;
+    if constexpr (KP <= 16) {
+        unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
+        k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, PFX);
+        const dim3 grid((B + 63) / 64, L.nseg1);
+        k_moments_x<KP, PREDICT><<<grid, 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.seg_tiles1, PFX, MOM);
+        return L.nseg1;
+    } else {
+        const dim3 grid((B + 63) / 64, L.nseg);
+        k_moments<KP, PREDICT><<<grid, 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, ws + L.oPF, MOM);
+        return L.nseg;
+    }
 }
 
 template <int KP>
@@ -104,9 +130,9 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
     mark(1);
     const dim3 grid((B + 63) / 64, L.nseg);
-    k_moments<KP, false><<<grid, 256, 0, st>>>(p, b, tau, nullptr, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, PF, MOM);
+    const int nseg1 = launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, ws, st);
     mark(2);
-    sum_segments<KP>(MOM, L, st);
+    sum_segments<KP>(MOM, L, nseg1, st);
     constexpr int G = 64 / KP;
     k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr);
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
@@ -129,9 +155,8 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     const Layout L = make_layout_t<KP>(B, Npix);
     float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL;
     launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
-    const dim3 grid((B + 63) / 64, L.nseg);
-    k_moments<KP, true><<<grid, 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, PF, MOM);
-    sum_segments<KP>(MOM, L, st);
+    const int nseg1 = launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, ws, st);
+    sum_segments<KP>(MOM, L, nseg1, st);
     constexpr int G = 64 / KP;
     k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, ll, nullptr, B, Nh, hmean, hcov);
     k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);

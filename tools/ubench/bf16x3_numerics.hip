@@ -1,0 +1,86 @@
+// Numerics check: 16x16 tile of sum_k A[m][k] B[k][n] accumulated over K, three ways:
+//   (a) v_mfma_f32_16x16x4_f32 (exact f32 fma chain), (b) operands split into three bf16 pieces (RNE), six
+//   v_mfma_f32_16x16x32_bf16 per K-step of 32 (hh, hm, mh, hl, lh, mm; small terms first), (c) the 3-term
+//   variant (hh, hm, mh).  Reference: float64 on the host.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ f32x4 xdl(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ void k(const float *A, const float *B, int K, float *out) {     // A [16][K], B [K][16]
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    f32x4 c32 = {0, 0, 0, 0}, c6 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < K; k0 += 4) c32 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * K + k0 + g], B[(k0 + g) * 16 + r], c32, 0, 0, 0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        u32x4 ah, am, al, bh, bm, bl;
+        for (int j = 0; j < 4; ++j) {
+            unsigned h, m, l;
+            split2(A[r * K + k0 + 8 * g + 2 * j], A[r * K + k0 + 8 * g + 2 * j + 1], h, m, l);
+            ah[j] = h; am[j] = m; al[j] = l;
+            split2(B[(k0 + 8 * g + 2 * j) * 16 + r], B[(k0 + 8 * g + 2 * j + 1) * 16 + r], h, m, l);
+            bh[j] = h; bm[j] = m; bl[j] = l;
+        }
+        c6 = xdl(al, bh, c6); c6 = xdl(ah, bl, c6); c6 = xdl(am, bm, c6);
+        c6 = xdl(am, bh, c6); c6 = xdl(ah, bm, c6); c6 = xdl(ah, bh, c6);
+        c3 = xdl(am, bh, c3); c3 = xdl(ah, bm, c3); c3 = xdl(ah, bh, c3);
+    }
+    for (int i = 0; i < 4; ++i) {
+        out[(4 * g + i) * 16 + r] = c32[i];
+        out[256 + (4 * g + i) * 16 + r] = c6[i];
+        out[512 + (4 * g + i) * 16 + r] = c3[i];
+    }
+}
+
+int main() {
+    std::mt19937 rng(7);
+    for (int K : {32, 512, 4096}) {
+        for (int mode = 0; mode < 3; ++mode) {
+            std::vector<float> A(16 * K), B(K * 16);
+            std::normal_distribution<float> nd(0.f, 1.f);
+            std::uniform_real_distribution<float> ud(0.f, 1.f);
+            for (auto &x : A) x = mode == 0 ? nd(rng) : (mode == 1 ? ud(rng) : std::exp(6.f * nd(rng)));   // signed / positive / wide range
+            for (auto &x : B) x = mode == 1 ? ud(rng) : nd(rng) * (mode == 2 ? std::exp(3.f * nd(rng)) : 1.f);
+            float *dA, *dB, *dO;
+            hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dO, 768 * 4);
+            hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+            k<<<1, 64>>>(dA, dB, K, dO);
+            std::vector<float> O(768);
+            hipMemcpy(O.data(), dO, 768 * 4, hipMemcpyDeviceToHost);
+            double e[3] = {0, 0, 0}, emax[3] = {0, 0, 0};
+            for (int m = 0; m < 16; ++m)
+                for (int n = 0; n < 16; ++n) {
+                    double ref = 0, mag = 0;
+                    for (int kk = 0; kk < K; ++kk) { ref += (double)A[m * K + kk] * B[kk * 16 + n]; mag += std::fabs((double)A[m * K + kk] * B[kk * 16 + n]); }
+                    for (int v = 0; v < 3; ++v) {
+                        const double err = std::fabs(O[256 * v + m * 16 + n] - ref) / mag;
+                        e[v] += err * err / 256; emax[v] = std::max(emax[v], err);
+                    }
+                }
+            printf("K=%5d mode=%d  err/sum|ab|  f32 mfma: rms %.2e max %.2e | bf16x6: rms %.2e max %.2e | bf16x3: rms %.2e max %.2e\n", K, mode,
+                   std::sqrt(e[0]), emax[0], std::sqrt(e[1]), emax[1], std::sqrt(e[2]), emax[2]);
+            hipFree(dA); hipFree(dB); hipFree(dO);
+        }
+    }
+    return 0;
+}
