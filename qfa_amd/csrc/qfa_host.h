@@ -75,7 +75,7 @@ Layout make_layout(int B, int Npix, int Nh) {
 
 inline int check_shape(int B, int Npix, int Nb, int Nh) {
     if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || Nh < 1 || Nh > 32) return QFA_E_SIZE;
-    if ((long long)16 * Npix >= (1LL << 31)) return QFA_E_SIZE;
+    if ((long long)64 * Npix >= (1LL << 31)) return QFA_E_SIZE;      // 32-bit byte offsets inside a wave's 16 rows
     return 0;
 }
 
@@ -106,8 +106,12 @@ int launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t 
     if constexpr (KP <= 16) {
         unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
         k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, PFX);
-        const dim3 grid((B + 63) / 64, L.nseg1);
-        k_moments_x<KP, PREDICT><<<grid, 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.seg_tiles1, PFX, MOM);
+#ifndef QFA_XNW
+#define QFA_XNW 4
+#endif
+        constexpr int NW = QFA_XNW;
+        const dim3 grid((B + 16 * NW - 1) / (16 * NW), L.nseg1);
+        k_moments_x<KP, PREDICT, NW><<<grid, 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.seg_tiles1, PFX, MOM);
         return L.nseg1;
     } else {
         const dim3 grid((B + 63) / 64, L.nseg);

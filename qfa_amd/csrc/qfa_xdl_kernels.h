@@ -11,7 +11,8 @@
 // 1e-6..1e-5).  The static operands (the parameter image) are split once per step by k_prep_pfx; the per-element
 // weights are split in the loop (11 VALU instructions per pair of values).
 //
-//   k_prep_pfx    F, Psi, omega -> PFX image: per 32-pixel tile [piece h|m|l][column][32 px] bf16 + Psi, omega
+//   k_prep_pfx    F, Psi, omega -> PFX image: per 32-pixel tile [piece h|m|l][16-column tile][8-px group][column][8 px]
+//                 bf16 + Psi, omega
 //   k_moments_x   pass 1 (C, T, b, b2 + scalar sums) with K = 32 pixels per MFMA
 #pragma once
 #include "qfa_common.h"
@@ -23,7 +24,7 @@ template <int KP>
 struct XCfg {
     using C = Cfg<KP>;
     static constexpr int NCOL = C::FW + C::PW;               // f columns first, then the pair columns
-    static constexpr int PSTR = NCOL * 64;                    // bytes of one piece: [column][32 px] bf16
+    static constexpr int PSTR = NCOL * 64;                    // bytes of one piece: 32 px x bf16 per column
     static constexpr int OFF_PSI = 3 * PSTR;                  // float32 Psi[32], omega[32]
     static constexpr int TILE_B = (3 * PSTR + 256 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
     static constexpr int NCHUNK = TILE_B / 1024;
@@ -36,6 +37,10 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {       // [15
 }
 // two float32 values -> three packed bf16 pairs with x = h + m + l exactly
 __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+#if QFA_ABL == 12          // timing only: no split arithmetic
+    h = __float_as_uint(x0); m = __float_as_uint(x1); l = h ^ m;
+    return;
+#endif
     h = cvt_pk_bf16(x0, x1);
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
     m = cvt_pk_bf16(r0, r1);
@@ -43,6 +48,10 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned
     l = cvt_pk_bf16(s0, s1);
 }
 __device__ __forceinline__ f32x4 xdl(const u32x4 &a, const u32x4 &b, f32x4 c) {
+#if QFA_ABL == 11          // timing only: no XDL MFMA
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                    0, 0);
 }
@@ -95,7 +104,8 @@ __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, c
         }
         unsigned h, m, l;
         split2(v[0], v[1], h, m, l);
-        unsigned *dst = reinterpret_cast<unsigned *>(tile + c * 64 + q * 2);
+        // lane-linear for the B-operand read: [16-column tile][8-pixel group][column][8 px]
+        unsigned *dst = reinterpret_cast<unsigned *>(tile + (c >> 4) * 1024 + (q >> 3) * 256 + (c & 15) * 16 + (q & 7) * 2);
         dst[0] = h;
         dst[X::PSTR / 4] = m;
         dst[2 * X::PSTR / 4] = l;
@@ -123,8 +133,8 @@ struct SpecRegsX {
     unsigned m0, m1;      // 8 mask bytes
 };
 
-template <int KP, bool PREDICT>
-__global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
+template <int KP, bool PREDICT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                       const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
                                                       int ntiles, int seg_tiles, const unsigned char *__restrict__ PFX,
                                                       float *__restrict__ MOM) {
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
-    const int s0 = (blockIdx.x * 4 + wv) * 16;
+    const int s0 = (blockIdx.x * NW + wv) * 16;
     const bool active = s0 < B;                                   // wave-uniform
     const int t0 = blockIdx.y * seg_tiles;
     const int t1 = min(t0 + seg_tiles, ntiles);
@@ -158,12 +168,12 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
     double qd = 0.0, ld = 0.0;        // float32 inside an 8-pixel group, float64 across groups
     float cn = 0.f, cblue = 0.f;
 
-    // LDS-DMA of one image tile: wave w moves the 1-KiB pieces w, w+4, ...
+    // LDS-DMA of one image tile: wave w moves the 1-KiB pieces w, w+NW, ...
     auto stage = [&](int tg, int buf) {
         const unsigned char *src = PFX + (size_t)tg * X::TILE_B + lane * 16;
 #pragma unroll
-        for (int i = 0; i < (X::NCHUNK + 3) / 4; ++i) {
-            const int ch = wv + 4 * i;
+        for (int i = 0; i < (X::NCHUNK + NW - 1) / NW; ++i) {
+            const int ch = wv + NW * i;
             if (ch < X::NCHUNK) glds16(src + ch * 1024, &lds[buf][ch * 1024]);
         }
     };
@@ -288,8 +298,9 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
                     w4h[q] = h; w4m[q] = m; w4l[q] = l;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             // ---- XDL: per 16-column tile of the image three ds_read_b128, then 6 (red) or 12 (blue) MFMAs
-            const unsigned char *bcol = tile + sl * 64 + g * 16;
+            const unsigned char *bcol = tile + lane * 16;            // lane-linear: conflict-free ds_read_b128
             auto rdB = [&](int piece, int ct) {
                 return *reinterpret_cast<const u32x4 *>(bcol + piece * X::PSTR + ct * 1024);
             };
