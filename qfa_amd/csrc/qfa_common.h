@@ -111,6 +111,33 @@ __device__ __forceinline__ void pin(float &x, T &...rest) {
     pin(rest...);
 }
 
+// Broadcast of lane l (constant after unrolling) of every 16-lane row: DPP row_newbcast, a VALU move with no LDS
+// round trip (a __shfl with constant source lane compiles to ds_bpermute_b32, ~100 cycles of latency each).
+__device__ __forceinline__ int dpp_row_bcast(int v, int l) {
+#define QFA_BC(n) case n: return __builtin_amdgcn_mov_dpp(v, 0x150 + n, 0xf, 0xf, true);      // no `old` operand to set up
+    switch (l & 15) {
+        QFA_BC(0) QFA_BC(1) QFA_BC(2) QFA_BC(3) QFA_BC(4) QFA_BC(5) QFA_BC(6) QFA_BC(7)
+        QFA_BC(8) QFA_BC(9) QFA_BC(10) QFA_BC(11) QFA_BC(12) QFA_BC(13) QFA_BC(14) QFA_BC(15)
+    }
+#undef QFA_BC
+    return v;
+}
+// value of lane l of the KP-lane group this lane belongs to
+template <int KP>
+__device__ __forceinline__ float group_bcast(float x, int l) {
+    if constexpr (KP == 16) return __int_as_float(dpp_row_bcast(__float_as_int(x), l));
+    else return __shfl(x, l, KP);
+}
+template <int KP>
+__device__ __forceinline__ double group_bcast(double x, int l) {
+    if constexpr (KP == 16) {
+        const int lo = dpp_row_bcast(__double2loint(x), l), hi = dpp_row_bcast(__double2hiint(x), l);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl(x, l, KP);
+    }
+}
+
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 __device__ __forceinline__ DevConsts load_consts(const qfa_params_t &p, const qfa_tau_t &tau) {

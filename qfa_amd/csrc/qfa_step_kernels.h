@@ -344,7 +344,7 @@ static __global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t
 // ------------------------------------------------------------------------------------------------
 // k_solve.  KP lanes per spectrum, lane c holds column c (= row c) of the symmetric k x k
 // matrices in registers; in-place Gauss-Jordan inversion in fp64, every step broadcasting the
-// pivot column with wavefront shuffles.  The pivots are the squared Cholesky diagonal, so
+// pivot column inside the lane group (DPP row broadcast at KP = 16, wavefront shuffles otherwise).  The pivots are the squared Cholesky diagonal, so
 // log det C = sum log(pivot) (finite where the reference's float32 det overflows, QFA/utils.py:54).
 // ------------------------------------------------------------------------------------------------
 template <int KP, bool PREDICT>
@@ -365,19 +365,26 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
         const int a = r < c ? r : c, b = r < c ? c : r;
         Cc[r] = (double)mom[pair_index(a, b, KP)] + (r == c ? 1.0 : 0.0);
     }
-    double logdet = 0.0;
+    // log det C = sum log(pivot): the pivots are multiplied up in float64 (>= 1, far from overflow in groups of
+    // eight) and ONE logarithm is taken per group -- log() in float64 was a third of this kernel's instructions
+    double logdet = 0.0, pprod = 1.0;
 #pragma unroll
     for (int jj = 0; jj < KP; ++jj) {
         // pivot column jj lives in lane jj; every element is broadcast right where it is consumed
-        const double piv = __shfl(Cc[jj], jj, KP);
-        logdet += log(piv);
+        const double piv = group_bcast<KP>(Cc[jj], jj);
+        pprod *= piv;
+        if ((jj & 7) == 7 || jj == KP - 1) {
+            logdet += log(pprod);
+            pprod = 1.0;
+        }
         const double ip = 1.0 / piv;
         const double rjc = (c == jj) ? ip : Cc[jj] * ip;
+        const double keep = (c == jj) ? 0.0 : 1.0;                 // lane jj: new = -cij * ip (its rjc is ip)
 #pragma unroll
         for (int i = 0; i < KP; ++i) {
             if (i != jj) {
-                const double cij = __shfl(Cc[i], jj, KP);         // A[i][jj] before this step's update
-                Cc[i] = (c == jj) ? -cij * ip : Cc[i] - cij * rjc;
+                const double cij = group_bcast<KP>(Cc[i], jj);         // A[i][jj] before this step's update
+                Cc[i] = fma(-cij, rjc, Cc[i] * keep);
             }
         }
         Cc[jj] = rjc;
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
     const double bc = (double)mom[C::MOM_B + c];
     double y = 0.0;
 #pragma unroll
-    for (int r = 0; r < KP; ++r) y += Cc[r] * __shfl(bc, r, KP);
+    for (int r = 0; r < KP; ++r) y += Cc[r] * group_bcast<KP>(bc, r);
     double quad = bc * y;
 #pragma unroll
     for (int o = KP / 2; o >= 1; o >>= 1) quad += __shfl_xor(quad, o, KP);
@@ -429,12 +436,14 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
     for (int m = 0; m < KP; ++m) {
         const float cm = (float)Cc[m];
 #pragma unroll
-        for (int b = 0; b < KP; ++b) Zr[b] = fmaf(cm, __shfl(Tc[m], b, KP), Zr[b]);
+        for (int b = 0; b < KP; ++b) Zr[b] = fmaf(cm, group_bcast<KP>(Tc[m], b), Zr[b]);
+#pragma unroll
+        for (int b = 0; b < KP; ++b) pin(Zr[b]);      // finish row m before the broadcasts of row m+1 (else all KP^2 are live)
         __builtin_amdgcn_sched_barrier(0);
     }
     double pc = (double)mom[C::MOM_B2 + c];
 #pragma unroll
-    for (int m = 0; m < KP; ++m) pc -= (double)Tc[m] * __shfl(y, m, KP);
+    for (int m = 0; m < KP; ++m) pc -= (double)Tc[m] * group_bcast<KP>(y, m);
     if (valid) {
 #pragma unroll
         for (int b = 0; b < KP; ++b) sol[C::SOL_Z + c * KP + b] = Zr[b];
