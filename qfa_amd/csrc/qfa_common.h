@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/qfa_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -123,9 +126,15 @@ __device__ __forceinline__ int dpp_row_bcast(int v, int l) {
     return v;
 }
 // value of lane l of the KP-lane group this lane belongs to
+// 32-lane groups: lane l of each half of the wave through v_readlane (scalar, no LDS round trip) + select
+__device__ __forceinline__ int half_bcast(int v, int l) {
+    const int a = __builtin_amdgcn_readlane(v, l & 31), b = __builtin_amdgcn_readlane(v, 32 + (l & 31));
+    return (threadIdx.x & 32) ? b : a;
+}
 template <int KP>
 __device__ __forceinline__ float group_bcast(float x, int l) {
     if constexpr (KP == 16) return __int_as_float(dpp_row_bcast(__float_as_int(x), l));
+    else if constexpr (KP == 32) return __int_as_float(half_bcast(__float_as_int(x), l));
     else return __shfl(x, l, KP);
 }
 template <int KP>
@@ -133,9 +142,23 @@ __device__ __forceinline__ double group_bcast(double x, int l) {
     if constexpr (KP == 16) {
         const int lo = dpp_row_bcast(__double2loint(x), l), hi = dpp_row_bcast(__double2hiint(x), l);
         return __hiloint2double(hi, lo);
+    } else if constexpr (KP == 32) {
+        const int lo = half_bcast(__double2loint(x), l), hi = half_bcast(__double2hiint(x), l);
+        return __hiloint2double(hi, lo);
     } else {
         return __shfl(x, l, KP);
     }
+}
+
+// compile-time loop: the body sees its index as a constant expression, so register arrays indexed by it are
+// promoted to registers even when the loop nest is too large for the unroller to finish before SROA
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

@@ -360,16 +360,16 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
     const float *mom = MOM + (size_t)(valid ? s : B - 1) * C::NMOM;
 
     double Cc[KP];
-#pragma unroll
-    for (int r = 0; r < KP; ++r) {
+    static_for<KP>([&](auto R) {
+        constexpr int r = decltype(R)::value;
         const int a = r < c ? r : c, b = r < c ? c : r;
         Cc[r] = (double)mom[pair_index(a, b, KP)] + (r == c ? 1.0 : 0.0);
-    }
+    });
     // log det C = sum log(pivot): the pivots are multiplied up in float64 (>= 1, far from overflow in groups of
     // eight) and ONE logarithm is taken per group -- log() in float64 was a third of this kernel's instructions
     double logdet = 0.0, pprod = 1.0;
-#pragma unroll
-    for (int jj = 0; jj < KP; ++jj) {
+    static_for<KP>([&](auto JJ) {
+        constexpr int jj = decltype(JJ)::value;
         // pivot column jj lives in lane jj; every element is broadcast right where it is consumed
         const double piv = group_bcast<KP>(Cc[jj], jj);
         pprod *= piv;
@@ -380,21 +380,23 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
         const double ip = 1.0 / piv;
         const double rjc = (c == jj) ? ip : Cc[jj] * ip;
         const double keep = (c == jj) ? 0.0 : 1.0;                 // lane jj: new = -cij * ip (its rjc is ip)
-#pragma unroll
-        for (int i = 0; i < KP; ++i) {
-            if (i != jj) {
+        static_for<KP>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i != jj) {
                 const double cij = group_bcast<KP>(Cc[i], jj);         // A[i][jj] before this step's update
                 Cc[i] = fma(-cij, rjc, Cc[i] * keep);
             }
-        }
+        });
         Cc[jj] = rjc;
         __builtin_amdgcn_sched_barrier(0);      // keep the broadcasts of step jj+1 out of step jj (VGPR pressure)
-    }
+    });
     // y = C^-1 b  (Cc[r] = Cinv[r][c] = Cinv[c][r])
     const double bc = (double)mom[C::MOM_B + c];
     double y = 0.0;
-#pragma unroll
-    for (int r = 0; r < KP; ++r) y += Cc[r] * group_bcast<KP>(bc, r);
+    static_for<KP>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        y += Cc[r] * group_bcast<KP>(bc, r);
+    });
     double quad = bc * y;
 #pragma unroll
     for (int o = KP / 2; o >= 1; o >>= 1) quad += __shfl_xor(quad, o, KP);
@@ -408,45 +410,51 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
     float *sol = SOL + (size_t)(valid ? s : 0) * C::NSOL;
     if (valid) {
         sol[c] = (float)y;
-#pragma unroll
-        for (int r = 0; r < KP; ++r)
+        static_for<KP>([&](auto R) {
+            constexpr int r = decltype(R)::value;
             if (r <= c) sol[C::SOL_CI + pair_index(r, c, KP)] = (float)(r == c ? Cc[r] : 2.0 * Cc[r]);
+        });
     }
     if (PREDICT) {
         if (valid && c < Nh) {
             hmean[(size_t)s * Nh + c] = (float)y;
-#pragma unroll
-            for (int r = 0; r < KP; ++r)
+            static_for<KP>([&](auto R) {
+                constexpr int r = decltype(R)::value;
                 if (r < Nh) hcov[((size_t)s * Nh + c) * Nh + r] = (float)Cc[r];
+            });
         }
         return;
     }
     // T column c (= row c); Z row c: Z[c][b] = sum_m Cinv[c][m] T[m][b] (float32 products of the
     // float64-inverted C^-1: Z is stored in float32 anyway); p_c = b2_c - sum_m T[c][m] y_m
     float Tc[KP];
-#pragma unroll
-    for (int r = 0; r < KP; ++r) {
+    static_for<KP>([&](auto R) {
+        constexpr int r = decltype(R)::value;
         const int a = r < c ? r : c, b = r < c ? c : r;
         Tc[r] = mom[C::MOM_T + pair_index(a, b, KP)];
-    }
+    });
     float Zr[KP];
-#pragma unroll
-    for (int b = 0; b < KP; ++b) Zr[b] = 0.f;
-#pragma unroll
-    for (int m = 0; m < KP; ++m) {
+    static_for<KP>([&](auto Bq) { Zr[decltype(Bq)::value] = 0.f; });
+    static_for<KP>([&](auto M) {
+        constexpr int m = decltype(M)::value;
         const float cm = (float)Cc[m];
-#pragma unroll
-        for (int b = 0; b < KP; ++b) Zr[b] = fmaf(cm, group_bcast<KP>(Tc[m], b), Zr[b]);
-#pragma unroll
-        for (int b = 0; b < KP; ++b) pin(Zr[b]);      // finish row m before the broadcasts of row m+1 (else all KP^2 are live)
+        static_for<KP>([&](auto Bq) {
+            constexpr int b = decltype(Bq)::value;
+            Zr[b] = fmaf(cm, group_bcast<KP>(Tc[m], b), Zr[b]);
+        });
+        static_for<KP>([&](auto Bq) { pin(Zr[decltype(Bq)::value]); });   // finish row m before row m+1's broadcasts
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     double pc = (double)mom[C::MOM_B2 + c];
-#pragma unroll
-    for (int m = 0; m < KP; ++m) pc -= (double)Tc[m] * group_bcast<KP>(y, m);
+    static_for<KP>([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        pc -= (double)Tc[m] * group_bcast<KP>(y, m);
+    });
     if (valid) {
-#pragma unroll
-        for (int b = 0; b < KP; ++b) sol[C::SOL_Z + c * KP + b] = Zr[b];
+        static_for<KP>([&](auto Bq) {
+            constexpr int b = decltype(Bq)::value;
+            sol[C::SOL_Z + c * KP + b] = Zr[b];
+        });
         sol[C::SOL_P + c] = (float)pc;
     }
 }
