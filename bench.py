@@ -17,7 +17,8 @@ no masks).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (pass 2, k_grads): its
 algorithmic flops over its mean duration measured with HIP events recorded by
-the library on the launch stream inside the timed region.  `cpu_baseline` times the dense
+the library on the launch stream inside the timed region (pass 2 runs on the f32 MFMA, whose peak is the VALU's:
+157.3 TFLOP/s; pass 1 runs on the bf16 XDL pipe with split operands).  `cpu_baseline` times the dense
 O(N_pix^3) CPU port of the reference's per-spectrum step (oracle/dense_port.py) on a bounded
 sample of the same batch (rank 0, N = 1 only).
 """
@@ -182,7 +183,11 @@ def main():
         "config": {"workload": f"{args.config}: {B} spectra/GPU x N_pix={npix} (N_b={nb}), N_h={nh}, "
                                f"{'random pixel masks' if masks else 'no masks'}, becker tau, "
                                f"forward + {'RCCL all-reduce + ' if world > 1 else ''}Adam + clip",
-                   "spectra_per_gpu": B, "n_pix": npix, "n_b": nb, "n_h": nh, "parallelism": f"dp{world}"},
+                   "spectra_per_gpu": B, "n_pix": npix, "n_b": nb, "n_h": nh, "parallelism": f"dp{world}",
+                   "arithmetic": "float32 throughout; pass 1 (N_h <= 16) issues its contraction as six bf16 XDL MFMAs "
+                                 "over operands split into three bf16 pieces (float32-exact split, float32 accumulate; "
+                                 "error vs float64 at or below the f32 MFMA's, tools/ubench/bf16x3_numerics.hip); "
+                                 "k x k solve in float64"},
         "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                      "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
                      "kernel_ms": dom_ms, "alg_flops_per_spectrum": dom_flops},

@@ -15,6 +15,9 @@ res = {"config": cfg, "B": B, "method": "rocprofv3 --pmc, separate passes (FETCH
        "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; check: TCC_EA0_RDREQ_128B*128"}
 for k in ("k_grads", "k_moments", "k_solve"):
     v = vals.get(k, {})
+    if k == "k_moments" and "k_moments_x" in vals:      # pass 1 on the XDL pipe (N_h <= 16)
+        v = vals["k_moments_x"]
+        res["k_moments_kernel"] = "k_moments_x"
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         res[k + "_hbm_bytes_per_launch"] = 2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
         res[k + "_read_bytes_rdreq128"] = v.get("TCC_EA0_RDREQ_128B", 0) * 128 + v.get("TCC_EA0_RDREQ_64B", 0) * 64
