@@ -7,8 +7,8 @@
 in HBM, and what the reference computes on the host with numpy for every batch -- ``zabs``,
 ``tau_total`` over the Lyman series, ``delta = flux - mu * exp(-tau_total)``, the bool mask, and
 the smoothed mean continuum ``mu`` -- runs in HIP kernels (``qfa_build_batch_f32``,
-``qfa_mu_estimate_f64``).  Reading spectra from disk and catalogue selection are out of scope
-(rows N3/N4).
+``qfa_mu_estimate_f64``).  Reading spectra from disk and the catalogue selection (row N3) are host code in ``qfa_amd.io``
+(``from_files`` / ``from_catalog`` below).
 """
 from __future__ import annotations
 
@@ -53,6 +53,23 @@ class DeviceDataloader(object):
         self.cur = 0
         self._mu_raw, self._mu = self._estimate_mu(int(window_length_for_mu))
         self._mu_dev = torch.as_tensor(self._mu, device=self.device)
+
+    # ------------------------------------------------------------------ from disk (row N3)
+    @classmethod
+    def from_files(cls, paths, wav_grid, batch_size, device, nprocs=1, **kw):
+        """spectra read from per-spectrum .npz files (reference QFA/dataloader.py:18-45,84-88)"""
+        from . import io
+        flux, error, zqso, plist = io.read_spectra(paths, nprocs)
+        return cls(flux, error, zqso, wav_grid, batch_size, device, paths=plist, **kw)
+
+    @classmethod
+    def from_catalog(cls, catalog, data_dir, num, wav_grid, batch_size, device, snr_min=-np.inf, snr_max=np.inf,
+                     z_min=-np.inf, z_max=np.inf, num_mask=np.inf, nprocs=1, output_dir=None, prefix="train", **kw):
+        """catalogue selection + read (reference QFA/dataloader.py:48-55,72-76)"""
+        from . import io
+        flux, error, zqso, plist = io.load_from_catalog(catalog, data_dir, num, snr_min, snr_max, z_min, z_max,
+                                                        num_mask, nprocs, output_dir, prefix)
+        return cls(flux, error, zqso, wav_grid, batch_size, device, paths=plist, **kw)
 
     # ------------------------------------------------------------------ mu
     def _estimate_mu(self, window):
