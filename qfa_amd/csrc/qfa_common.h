@@ -42,7 +42,13 @@ struct Cfg {
     // pair products, then Psi, omega, zero padding to a multiple of 4 rows.
     static constexpr int PFT_PSI = KP + KK2;
     static constexpr int NR = (KP + KK2 + 2 + 3) / 4 * 4;
-    static constexpr int TILE_PFT = NR * 16;
+    // N_h = 16: stage 3 of pass 2 runs on the XDL pipe; its A operand (F of the tile as three bf16 pieces in the
+    // lane order of v_mfma_f32_16x16x16_bf16: [piece][g][px][a = 4g + j], 3 x 512 bytes) is appended to the tile,
+    // and both parts are padded to whole KiB so that the tile moves as 1-KiB LDS-DMA pieces
+    static constexpr bool XS3 = KP == 16;
+    static constexpr int PFT_MAIN = XS3 ? (NR * 16 + 255) / 256 * 256 : NR * 16;   // floats of the float32 part
+    static constexpr int PFT_FP = XS3 ? 512 : 0;        // floats
+    static constexpr int TILE_PFT = PFT_MAIN + PFT_FP;
     // per-spectrum moment record: [C PW][T PW][b FW][b2 FW][qd, ld, n, nblue]
     static constexpr int NMOM = 2 * PW + 2 * FW + 4;
     static constexpr int MOM_T = PW, MOM_B = 2 * PW, MOM_B2 = 2 * PW + FW, MOM_S = 2 * PW + 2 * FW;
@@ -103,6 +109,68 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 #else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 #endif
+}
+
+
+// ---- float32 contractions on the bf16 XDL pipe (qfa_xdl_kernels.h explains why): x = h + m + l in bf16 pieces
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {       // [15:0] = bf16(a), [31:16] = bf16(b), RNE
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// two float32 values -> three packed bf16 pairs with x = h + m + l exactly
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+#if QFA_ABL == 12          // timing only: no split arithmetic
+    h = __float_as_uint(x0); m = __float_as_uint(x1); l = h ^ m;
+    return;
+#endif
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ f32x4 xdl(const u32x4 &a, const u32x4 &b, f32x4 c) {          // K = 32
+#if QFA_ABL == 11          // timing only: no XDL MFMA
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+}
+__device__ __forceinline__ f32x4 xdl16(const u32x2 &a, const u32x2 &b, f32x4 c) {        // K = 16
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0,
+                                                     0, 0);
+}
+// float32-accurate product of split operands, small terms first
+template <typename V, typename F>
+__device__ __forceinline__ f32x4 six_terms(F &&mm, const V &ah, const V &am, const V &al, const V &bh, const V &bm,
+                                           const V &bl, f32x4 c) {
+    c = mm(al, bh, c);
+    c = mm(ah, bl, c);
+    c = mm(am, bm, c);
+    c = mm(am, bh, c);
+    c = mm(ah, bm, c);
+    return mm(ah, bh, c);
+}
+__device__ __forceinline__ f32x4 xdl6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
+                                      const u32x4 &bm, const u32x4 &bl, f32x4 c) {
+    return six_terms([](const u32x4 &a, const u32x4 &b, f32x4 cc) { return xdl(a, b, cc); }, ah, am, al, bh, bm, bl, c);
+}
+__device__ __forceinline__ f32x4 xdl16_6(const u32x2 &ah, const u32x2 &am, const u32x2 &al, const u32x2 &bh,
+                                         const u32x2 &bm, const u32x2 &bl, f32x4 c) {
+    return six_terms([](const u32x2 &a, const u32x2 &b, f32x4 cc) { return xdl16(a, b, cc); }, ah, am, al, bh, bm, bl, c);
+}
+
+// LDS-DMA: the wave's 64 lanes move 64 x 16 B from per-lane global addresses to lds_base + 16 * lane
+__device__ __forceinline__ void glds16(const void *g, void *lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
 
 // keep a value's computation in front of this point (IR passes otherwise sink pure arithmetic past

@@ -55,6 +55,23 @@ __global__ void k_prep_pf(const float *__restrict__ F, const float *__restrict__
     }
     // zero padding rows of the PFT tile
     for (int r = C::PFT_PSI + 2 + threadIdx.x; r < C::NR; r += blockDim.x) pft[r * 16] = 0.f;
+    if constexpr (C::XS3) {
+        // F of this pixel as bf16 pieces, A operand of stage 3: [piece][g][px][a = 4g + j], 8 bytes per (g, px)
+        if (threadIdx.x < 4) {
+            const int g = threadIdx.x;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (live && 4 * g + j < Nh) ? F[(size_t)i * Nh + 4 * g + j] : 0.f;
+            unsigned h0, m0, l0, h1, m1, l1;
+            split2(v[0], v[1], h0, m0, l0);
+            split2(v[2], v[3], h1, m1, l1);
+            unsigned *fp = reinterpret_cast<unsigned *>(PFT + (size_t)(i >> 4) * C::TILE_PFT + C::PFT_MAIN) +
+                           g * 32 + (i & 15) * 2;
+            fp[0] = h0; fp[1] = h1;
+            fp[128] = m0; fp[129] = m1;
+            fp[256] = l0; fp[257] = l1;
+        }
+    }
 }
 
 // copy one contiguous tile (NF4 float4) global -> registers -> LDS with all 256 threads.  The first
@@ -75,6 +92,20 @@ struct TileCopy {
         if (N > 2) v2 = ld(src, 2, tid);
 #pragma unroll
         for (int i = 3; i < N; ++i) vx[i - 3] = ld(src, i, tid);
+    }
+    // same, the tile split over two LDS regions: float4 [0, NA) -> dstA, [NA, NF4) -> dstB
+    template <int NA>
+    static __device__ __forceinline__ void store2(float4 *dstA, float4 *dstB, int tid, const float4 &v0,
+                                                  const float4 &v1, const float4 &v2, const float4 (&vx)[NX]) {
+        auto put = [&](int idx, const float4 &v) {
+            if (idx < NA) dstA[idx] = v;
+            else if (idx < NF4) dstB[idx - NA] = v;
+        };
+        put(tid, v0);
+        if (N > 1) put(tid + 256, v1);
+        if (N > 2) put(tid + 512, v2);
+#pragma unroll
+        for (int i = 3; i < N; ++i) put(tid + 256 * i, vx[i - 3]);
     }
     static __device__ __forceinline__ void store(float4 *dst, int tid, const float4 &v0, const float4 &v1,
                                                  const float4 &v2, const float4 (&vx)[NX]) {
@@ -522,7 +553,14 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     constexpr int KF = KP / 4, KQ = C::KK2 / 4;
     constexpr int NF4 = C::TILE_PFT / 4;
     constexpr int NPART = 512;      // per wave and tile: aG [px][16] (256) + 4 per-pixel sums x 64 lanes
-    __shared__ float4 lds4[3][NF4];                               // ring of 3 parameter tiles
+    constexpr bool XS3 = C::XS3;
+    // ring of 3 parameter tiles; with stage 3 on the XDL pipe only the F pieces of a tile are read in its own step
+    // (the float32 part is consumed one step earlier by stage 1), so the float32 part needs two slots only
+    constexpr int NM4 = C::PFT_MAIN / 4, NP4 = XS3 ? C::PFT_FP / 4 : 1, RING_M = XS3 ? 2 : 3;
+    constexpr int NCH_MAIN = C::PFT_MAIN / 256, NCH = C::TILE_PFT / 256;   // 1-KiB LDS-DMA pieces (XDL form)
+    __shared__ float4 lds4[RING_M][XS3 ? NM4 : NF4];
+    __shared__ float4 ldsfp[XS3 ? 3 : 1][NP4];                   // F as bf16 pieces (stage-3 A operand)
+    __shared__ unsigned ldszl[XS3 ? 4 : 1][XS3 ? 16 * 64 * 2 : 1];   // third bf16 piece of Z, per wave [spectrum][lane][2]
     __shared__ float ldspart[2][4][NPART];
 #if QFA_ABL == 6                                                  // occupancy experiment: one workgroup per CU
     __shared__ float ldspad[22000];
@@ -558,8 +596,13 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
 #pragma unroll
         for (int t = 0; t < KQ; ++t) qA[t] = v ? sol[C::SOL_CI + 4 * t + g] : 0.f;
     }
-    // B operands of stage 3: spectra s0+4g+r, column b = lo
-    float Zr[4][KP], pr[4];
+    // B operands of stage 3, column b = lo.
+    //   f32 MFMA form (N_h > 16): Z of the lane's own spectra s0+4g+r, K = (spectrum, a).
+    //   XDL form: G_s = F_tile Z_s per spectrum (both operands static), K = a: the lane holds Z_s[a = 4g+j][b] of
+    //   ALL 16 spectra as bf16 pieces h, m (registers) and l (LDS); beta is applied to G_s on the VALU.
+    constexpr int NZR = XS3 ? 1 : 4, NZA = XS3 ? 1 : KP, NZS = XS3 ? 16 : 1;
+    float Zr[NZR][NZA], pr[4];
+    u32x2 Zh[NZS], Zm[NZS], ph = {0u, 0u}, pm = {0u, 0u}, pl = {0u, 0u};
     bool sv[4];
     int offN[4], offB[4];
 #pragma unroll
@@ -569,12 +612,37 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
         const int col = 16 * bhalf + lo;
         const bool v = sv[r] && col < KP;
         const float *sol = SOL + (size_t)(v ? s0 + srel : 0) * C::NSOL;
+        if constexpr (!XS3) {
 #pragma unroll
-        for (int a = 0; a < KP; ++a) Zr[r][a] = v ? sol[C::SOL_Z + a * KP + col] : 0.f;
+            for (int a = 0; a < KP; ++a) Zr[r][a] = v ? sol[C::SOL_Z + a * KP + col] : 0.f;
+        }
         pr[r] = v ? sol[C::SOL_P + col] : 0.f;
         const int sc = active ? min(srel, B - 1 - s0) : 0;
         offN[r] = sc * Npix;
         offB[r] = sc * Nb;
+    }
+    if constexpr (XS3) {
+        unsigned *zl = ldszl[wv];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bool v = active && (s0 + s) < B && lo < KP;
+            const float *sol = SOL + (size_t)(v ? s0 + s : 0) * C::NSOL + C::SOL_Z + lo;
+            float z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = (v && 4 * g + j < KP) ? sol[(4 * g + j) * KP] : 0.f;
+            unsigned h0, m0, l0, h1, m1, l1;
+            split2(z[0], z[1], h0, m0, l0);
+            split2(z[2], z[3], h1, m1, l1);
+            Zh[s] = u32x2{h0, h1};
+            Zm[s] = u32x2{m0, m1};
+            zl[(s * 64 + lane) * 2] = l0;
+            zl[(s * 64 + lane) * 2 + 1] = l1;
+        }
+        // p of the spectra 4g+j as the B operand of the gamma term (K = spectrum)
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2(pr[0], pr[1], h0, m0, l0);
+        split2(pr[2], pr[3], h1, m1, l1);
+        ph = u32x2{h0, h1}; pm = u32x2{m0, m1}; pl = u32x2{l0, l1};
     }
     const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
     const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
@@ -811,6 +879,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
 
         // ---- stage 3 of one tile: the F-gradient contraction, f_{px,a} re-read from the tile image
         auto stage3 = [&](const float *tile, const float (&betaR)[4], const float (&gamR)[4], float *part) {
+          if constexpr (!XS3) {
             float f[KP];
 #pragma unroll
             for (int a = 0; a < KP; ++a) f[a] = tile[a * 16 + lo];
@@ -829,6 +898,38 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
             // aG: col = b = lo, row = 4g + rr -> pixel 4g + rr
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = aG[rr];
+          }
+        };
+
+        // ---- stage 3 on the XDL pipe: per spectrum G_s = F_tile Z_s (16 px x 16 b, K = a, six bf16 MFMAs over
+        // static operands), then accF[px][b] += beta_{s,px} G_s[px][b] on the VALU; beta reaches the lane that
+        // holds rows px = 4g..4g+3 of G through the wave's LDS slot.  The gamma term sum_s gamma_{s,px} p_s[b] is
+        // one more product with K = spectrum (gamma split in the loop: 4 values per lane).
+        auto stage3x = [&](const float4 *fpt, const float (&betaR)[4], const float (&gamR)[4], float *part) {
+            if constexpr (XS3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[(4 * g + r) * 16 + lo] = betaR[r];
+                const u32x2 *fp = reinterpret_cast<const u32x2 *>(fpt) + lane;
+                const u32x2 Fh = fp[0], Fm = fp[64], Fl = fp[128];
+                unsigned h0, m0, l0, h1, m1, l1;
+                split2(gamR[0], gamR[1], h0, m0, l0);
+                split2(gamR[2], gamR[3], h1, m1, l1);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = xdl16_6(u32x2{h0, h1}, u32x2{m0, m1}, u32x2{l0, l1}, ph, pm, pl, zero);
+                const u32x2 *zl = reinterpret_cast<const u32x2 *>(ldszl[wv]) + lane;
+                const float4 *brow = reinterpret_cast<const float4 *>(part) + g;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const f32x4 G = xdl16_6(Fh, Fm, Fl, Zh[s], Zm[s], zl[s * 64], zero);
+                    const float4 bq = brow[s * 4];
+                    acc[0] = fmaf(bq.x, G[0], acc[0]);
+                    acc[1] = fmaf(bq.y, G[1], acc[1]);
+                    acc[2] = fmaf(bq.z, G[2], acc[2]);
+                    acc[3] = fmaf(bq.w, G[3], acc[3]);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = acc[rr];
+            }
         };
 
         // tile tg leaves the workgroup: every wave sums one quarter of the accF tile over the four
@@ -857,7 +958,25 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
                 if (ok) atomicAdd(accA + off, v);
             }
         };
-        auto tilebuf = [&](int c) { return reinterpret_cast<const float *>(lds4[c % 3]); };
+        auto tilebuf = [&](int c) { return reinterpret_cast<const float *>(lds4[c % RING_M]); };
+        // parameter tile c -> LDS.  XDL form: LDS-DMA, wave w moves the 1-KiB pieces w, w+4, ... (no staging
+        // registers; the tile barrier retires them).  f32 form: through the staging registers (get / put).
+        auto get_tile = [&](int c) {
+            if constexpr (XS3) {
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(PFT4 + (size_t)tile_of(c) * NF4) + lane * 16;
+#pragma unroll
+                for (int i = 0; i < (NCH + 3) / 4; ++i) {
+                    const int ch = wv + 4 * i;
+                    if (ch < NCH_MAIN) glds16(src + ch * 1024, reinterpret_cast<unsigned char *>(lds4[c % RING_M]) + ch * 1024);
+                    else if (ch < NCH) glds16(src + ch * 1024, reinterpret_cast<unsigned char *>(ldsfp[c % 3]) + (ch - NCH_MAIN) * 1024);
+                }
+            } else {
+                TC::load(PFT4 + (size_t)tile_of(c) * NF4, tid, tv0, tv1, tv2, tvx);
+            }
+        };
+        auto put_tile = [&](int c) {
+            if constexpr (!XS3) TC::store(lds4[c % RING_M], tid, tv0, tv1, tv2, tvx);
+        };
 
         // Software pipeline over tiles (one barrier per tile, ring of 3 parameter tiles):
         //   step c:  region 1 = stage 1 of tile c+1 (38 MFMAs, independent) beside stage 2 of tile c (VALU),
@@ -890,10 +1009,11 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
                 QFA_STAMP(q2)
             }
             // parameter tile c+2: issued here so that its latency runs under stage 3
-            if (c + 2 < n) TC::load(PFT4 + (size_t)tile_of(c + 2) * NF4, tid, tv0, tv1, tv2, tvx);
+            if (c + 2 < n) get_tile(c + 2);
             if (active) {
 #if QFA_ABL != 5
-                stage3(tilebuf(c), betaR, gamR, ldspart[pbuf][wv]);
+                if constexpr (XS3) stage3x(ldsfp[c % 3], betaR, gamR, ldspart[pbuf][wv]);
+                else stage3(tilebuf(c), betaR, gamR, ldspart[pbuf][wv]);
 #else
                 asm volatile("" ::"v"(betaR[0]), "v"(betaR[1]), "v"(betaR[2]), "v"(betaR[3]), "v"(gamR[0]), "v"(gamR[1]),
                              "v"(gamR[2]), "v"(gamR[3]));
@@ -905,7 +1025,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
 #endif
             }
             QFA_STAMP(q4)
-            if (c + 2 < n) TC::store(lds4[(c + 2) % 3], tid, tv0, tv1, tv2, tvx);
+            if (c + 2 < n) put_tile(c + 2);
             QFA_STAMP(q5)
             __syncthreads();
             QFA_STAMP(q6)
@@ -922,11 +1042,11 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
         };
 
         SpecRegs2 ra, rb;
-        TC::load(PFT4 + (size_t)tile_of(0) * NF4, tid, tv0, tv1, tv2, tvx);
-        TC::store(lds4[0], tid, tv0, tv1, tv2, tvx);
+        get_tile(0);
+        put_tile(0);
         if (n > 1) {
-            TC::load(PFT4 + (size_t)tile_of(1) * NF4, tid, tv0, tv1, tv2, tvx);
-            TC::store(lds4[1], tid, tv0, tv1, tv2, tvx);
+            get_tile(1);
+            put_tile(1);
         }
         if (active) load_spec(tile_of(0), ra);
         __syncthreads();

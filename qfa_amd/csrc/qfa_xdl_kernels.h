@@ -17,9 +17,6 @@
 #pragma once
 #include "qfa_common.h"
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 template <int KP>
 struct XCfg {
     using C = Cfg<KP>;
@@ -29,47 +26,6 @@ struct XCfg {
     static constexpr int TILE_B = (3 * PSTR + 256 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
     static constexpr int NCHUNK = TILE_B / 1024;
 };
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {       // [15:0] = bf16(a), [31:16] = bf16(b), RNE
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// two float32 values -> three packed bf16 pairs with x = h + m + l exactly
-__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-#if QFA_ABL == 12          // timing only: no split arithmetic
-    h = __float_as_uint(x0); m = __float_as_uint(x1); l = h ^ m;
-    return;
-#endif
-    h = cvt_pk_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = cvt_pk_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = cvt_pk_bf16(s0, s1);
-}
-__device__ __forceinline__ f32x4 xdl(const u32x4 &a, const u32x4 &b, f32x4 c) {
-#if QFA_ABL == 11          // timing only: no XDL MFMA
-    asm volatile("" ::"v"(a), "v"(b));
-    return c;
-#endif
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                   0, 0);
-}
-// float32-accurate product of split operands, small terms first
-__device__ __forceinline__ f32x4 xdl6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
-                                      const u32x4 &bm, const u32x4 &bl, f32x4 c) {
-    c = xdl(al, bh, c);
-    c = xdl(ah, bl, c);
-    c = xdl(am, bm, c);
-    c = xdl(am, bh, c);
-    c = xdl(ah, bm, c);
-    return xdl(ah, bh, c);
-}
-// LDS-DMA: the wave's 64 lanes move 64 x 16 B from per-lane global addresses to lds_base + 16 * lane
-__device__ __forceinline__ void glds16(const void *g, void *lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
-}
 
 // ------------------------------------------------------------------------------------------------
 template <int KP>
