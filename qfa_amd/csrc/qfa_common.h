@@ -144,6 +144,11 @@ __device__ __forceinline__ f32x4 xdl(const u32x4 &a, const u32x4 &b, f32x4 c) { 
                                                    0, 0);
 }
 __device__ __forceinline__ f32x4 xdl16(const u32x2 &a, const u32x2 &b, f32x4 c) {        // K = 16
+#if QFA_ABL == 13          // timing only: no K = 16 XDL MFMA (stage 3 of pass 2)
+    asm volatile("" ::"v"(a), "v"(b));
+    c[0] += 1.f;
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0,
                                                      0, 0);
 }
