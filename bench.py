@@ -17,8 +17,9 @@ no masks).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (pass 2, k_grads): its
 algorithmic flops over its mean duration measured with HIP events recorded by
-the library on the launch stream inside the timed region (pass 2 runs on the f32 MFMA, whose peak is the VALU's:
-157.3 TFLOP/s; pass 1 runs on the bf16 XDL pipe with split operands).  `cpu_baseline` times the dense
+the library on the launch stream inside the timed region (peak = the float32 MFMA / VALU peak, 157.3 TFLOP/s: the
+arithmetic is float32; where a contraction runs on the bf16 XDL pipe with split operands -- pass 1, stage 3 of pass 2,
+DESIGN.md section 4 -- that is an implementation of float32 products, so the fraction can exceed what the f32 pipe gives).  `cpu_baseline` times the dense
 O(N_pix^3) CPU port of the reference's per-spectrum step (oracle/dense_port.py) on a bounded
 sample of the same batch (rank 0, N = 1 only).
 """
@@ -184,7 +185,7 @@ def main():
                                f"{'random pixel masks' if masks else 'no masks'}, becker tau, "
                                f"forward + {'RCCL all-reduce + ' if world > 1 else ''}Adam + clip",
                    "spectra_per_gpu": B, "n_pix": npix, "n_b": nb, "n_h": nh, "parallelism": f"dp{world}",
-                   "arithmetic": "float32 throughout; pass 1 (N_h <= 16) issues its contraction as six bf16 XDL MFMAs "
+                   "arithmetic": "float32 throughout; pass 1 (N_h <= 16) and stage 3 of pass 2 (N_h = 16) issue their contractions as six bf16 XDL MFMAs "
                                  "over operands split into three bf16 pieces (float32-exact split, float32 accumulate; "
                                  "error vs float64 at or below the f32 MFMA's, tools/ubench/bf16x3_numerics.hip); "
                                  "k x k solve in float64"},
