@@ -253,6 +253,34 @@ def test_forward_vs_oracle_ragged_shapes(dev, B, npix, nh, masks, seed):
             assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
 
 
+@pytest.mark.parametrize("npix,nb,nh,B", [(36, 7, 3, 5), (40, 0, 3, 5), (40, 40, 3, 5), (33, 32, 16, 21), (64, 0, 16, 9),
+                                          (64, 64, 16, 9), (48, 17, 20, 6)])
+def test_blue_red_boundary_layouts(dev, npix, nb, nh, B):
+    """no blue side at all (scalar gradients 0/0 = NaN like the reference), no red side, a blue side that
+    ends one pixel before a 32-pixel tile does, fewer pixels than two tiles"""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    wav = np.linspace(1100.0, 1300.0, npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=npix + nb)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=3 * npix + nb, masks=True)
+    m = make_model(dev, p, mu, nb=nb)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    acc = m.accumulate(*batch_t(b, dev), nll=nll)
+    loss, gr = m._finalize(acc, True)
+    oloss, ogr = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
+    per = np.array([O.nll_and_grads_single(p, b["delta"][s], b["error"][s], b["zabs"][s], b["mask"][s])[0] for s in range(B)])
+    assert np.all(np.abs(nll.cpu().numpy() - per) <= TOL_NLL * np.abs(per))      # (a fully masked spectrum: exactly 0)
+    assert abs(loss.item() - oloss) / abs(oloss) < TOL_NLL
+    for k in KEYS:
+        ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
+        assert ours.shape == ref.shape, k
+        assert np.array_equal(np.isnan(ours), np.isnan(ref)), k
+        ok = ~np.isnan(ref)
+        if ok.any():
+            assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
+
+
 @pytest.mark.parametrize("B,npix,nh,seed", [(5, 200, 4, 11), (20, 900, 8, 12), (18, 640, 16, 13), (7, 450, 32, 14)])
 def test_predict_vs_oracle(dev, B, npix, nh, seed):
     from oracle import qfa_oracle as O
