@@ -1,6 +1,6 @@
 // qfa_host.h -- host side of the step: workspace layout, launch geometry, kernel sequences.
 // Shared by qfa_capi.hip (N_h <= 16; built with -amdgpu-mfma-vgpr-form so that the MFMA accumulators
-// stay in VGPRs) and qfa_k32.hip (N_h in 17..32: 280 accumulator registers per lane need the AGPR
+// stay in VGPRs; pass 1 and stage 3 of pass 2 on the bf16 XDL pipe) and qfa_k32.hip (N_h in 17..32: 280 accumulator registers per lane need the AGPR
 // half of the register file, so that translation unit is built without the flag).
 #pragma once
 #include "qfa_step_kernels.h"

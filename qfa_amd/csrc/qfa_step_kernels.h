@@ -1,18 +1,20 @@
 // qfa_step_kernels.h -- the hot kernels of one QFA training / prediction step on CDNA4 (gfx950).
 //
-//   k_prep_pf      F, Psi, omega -> PF image (pass 1 B operand) and tile-major PFT image (pass 2)
-//   k_moments      pass 1: C, T, b, b2 + scalar sums of 16 spectra per wave on v_mfma_f32_16x16x4_f32
-//   k_solve        k x k Gauss-Jordan in fp64 on KP lanes per spectrum (wavefront shuffles)
+//   k_prep_pf      F, Psi, omega -> PF image (pass 1 B operand, f32 form) and tile-major PFT image (pass 2)
+//   k_moments      pass 1, f32 form (N_h > 16): C, T, b, b2 + scalar sums of 16 spectra per wave on
+//                  v_mfma_f32_16x16x4_f32 (N_h <= 16 runs k_moments_x of qfa_xdl_kernels.h on the bf16 XDL pipe)
+//   k_solve        k x k Gauss-Jordan in fp64 on KP lanes per spectrum (DPP / readlane broadcasts)
 //   k_reduce_nll   sum NLL / spectrum counts (fp64, fixed order)
-//   k_grads        pass 2: u, diag(Sigma^-1), Psi/omega/scalar sums, F-gradient contraction on MFMA
+//   k_grads        pass 2: u, diag(Sigma^-1), Psi/omega/scalar sums (stage 1 on the f32 MFMA), F-gradient
+//                  contraction (stage 3: XDL pipe with split-bf16 static operands at N_h = 16, f32 MFMA otherwise)
 //   k_predict_out  cont = F hmean + mu, unc = sqrt(f^T hcov f)
 //
-// Both passes share one structure: a 256-thread workgroup = 4 waves = 4 x 16 spectra walks a
-// segment of the pixel axis in 16-pixel tiles; the tile of the parameter image every wave needs
-// (10 KB) is staged once per workgroup in LDS (double buffered, register-staged one tile ahead,
-// ONE barrier per tile) and the spectra of the next tile are prefetched into registers before the
-// MFMA block of the current one.  grid.y splits the pixel axis into segments so that
-// (#spectra tiles x #segments) fills 256 CUs evenly (tail quantisation, small batches).
+// Both passes share one structure: a 256-thread workgroup = 4 waves = 4 x 16 spectra walks a segment of the
+// pixel axis in tiles (16 pixels; 32 in k_moments_x); the tile of the parameter image every wave needs is staged
+// once per workgroup in LDS (LDS-DMA or register-staged, one or two tiles ahead, ONE barrier per tile) and the
+// spectra of the next tile are prefetched into registers before the arithmetic of the current one.  grid.y splits
+// the pixel axis into segments so that (#spectra tiles x #segments) fills 256 CUs evenly (tail quantisation,
+// small batches).
 #pragma once
 #include <type_traits>
 
@@ -92,20 +94,6 @@ struct TileCopy {
         if (N > 2) v2 = ld(src, 2, tid);
 #pragma unroll
         for (int i = 3; i < N; ++i) vx[i - 3] = ld(src, i, tid);
-    }
-    // same, the tile split over two LDS regions: float4 [0, NA) -> dstA, [NA, NF4) -> dstB
-    template <int NA>
-    static __device__ __forceinline__ void store2(float4 *dstA, float4 *dstB, int tid, const float4 &v0,
-                                                  const float4 &v1, const float4 &v2, const float4 (&vx)[NX]) {
-        auto put = [&](int idx, const float4 &v) {
-            if (idx < NA) dstA[idx] = v;
-            else if (idx < NF4) dstB[idx - NA] = v;
-        };
-        put(tid, v0);
-        if (N > 1) put(tid + 256, v1);
-        if (N > 2) put(tid + 512, v2);
-#pragma unroll
-        for (int i = 3; i < N; ++i) put(tid + 256 * i, vx[i - 3]);
     }
     static __device__ __forceinline__ void store(float4 *dst, int tid, const float4 &v0, const float4 &v1,
                                                  const float4 &v2, const float4 (&vx)[NX]) {
