@@ -3,6 +3,8 @@
 // stay in VGPRs; pass 1 and stage 3 of pass 2 on the bf16 XDL pipe) and qfa_k32.hip (N_h in 17..32: 280 accumulator registers per lane need the AGPR
 // half of the register file, so that translation unit is built without the flag).
 #pragma once
+#include <cstdlib>
+
 #include "qfa_step_kernels.h"
 #include "qfa_xdl_kernels.h"
 
@@ -45,6 +47,9 @@ Layout make_layout_t(int B, int Npix) {
     L.ntiles = L.NpixPad / 16;
     L.Bpad = round_up(B, 16);
     L.nseg = pick_nseg(B, L.ntiles);
+#ifdef QFA_TUNE_ENV
+    if (const char *e = getenv("QFA_NSEG2")) L.nseg = atoi(e);
+#endif
     L.seg_tiles = (L.ntiles + L.nseg - 1) / L.nseg;
     L.nseg = (L.ntiles + L.seg_tiles - 1) / L.seg_tiles;          // no empty segment
     size_t o = 0;
@@ -53,6 +58,9 @@ Layout make_layout_t(int B, int Npix) {
     L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
     L.ntiles32 = (Npix + 31) / 32;
     L.nseg1 = pick_nseg(B, L.ntiles32);
+#ifdef QFA_TUNE_ENV
+    if (const char *e = getenv("QFA_NSEG1")) L.nseg1 = atoi(e);
+#endif
     L.seg_tiles1 = (L.ntiles32 + L.nseg1 - 1) / L.nseg1;
     L.nseg1 = (L.ntiles32 + L.seg_tiles1 - 1) / L.seg_tiles1;
     L.oPFX = 0;
