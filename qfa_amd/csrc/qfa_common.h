@@ -64,6 +64,27 @@ __host__ __device__ constexpr int pair_index(int a, int b, int KP) {
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Work items of the two passes: one item = (block of 64 spectra, range of pixel tiles).  The first `full` blocks
+// walk the whole pixel axis (they fill whole rounds of the resident-workgroup slots, one prologue each); the
+// remaining `rem` blocks are cut into `nseg` pixel segments so that the last round is short (tail quantisation)
+// and small batches use every CU.  One launch, items in this order.
+struct WorkPlan {
+    int full, rem, nseg, seg_tiles;
+    __host__ __device__ int items() const { return full + rem * nseg; }
+};
+__device__ __forceinline__ void plan_item(const WorkPlan &w, int item, int ntiles, int &blk, int &seg, int &t0,
+                                          int &t1) {
+    if (item < w.full) {
+        blk = item; seg = 0; t0 = 0; t1 = ntiles;
+    } else {
+        const int j = item - w.full;
+        blk = w.full + j % w.rem;
+        seg = j / w.rem;
+        t0 = seg * w.seg_tiles;
+        t1 = min(t0 + w.seg_tiles, ntiles);
+    }
+}
+
 // scalars the kernels need, read once from device memory
 struct DevConsts {
     float tau0, c0, beta;

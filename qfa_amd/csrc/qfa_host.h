@@ -12,29 +12,40 @@ namespace {
 
 inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
 
-// Pixel-axis segmentation (grid.y): both passes run (#spectra tiles / 4) x nseg workgroups.  nseg is
-// the smallest split that fills the resident-workgroup slots of the chip to >= 90 % in the last
-// round (tail quantisation) -- it also lets small batches use every CU.
+// Work plan of a pass (WorkPlan, qfa_common.h): the blocks of 64 spectra that fill whole rounds of the 512
+// resident-workgroup slots walk the whole pixel axis; the remaining blocks are cut into 1..8 pixel segments.  The
+// plan minimises rounds x (tiles per item + prologue), the prologue of an item (operand loads, pipeline fill)
+// counted as `pro` tiles; small batches (no full round) get the uniform split that fills the chip.
 constexpr int kMaxSeg = 8;
 
-inline int pick_nseg(int B, int ntiles) {
+inline WorkPlan plan_work(int B, int ntiles, int pro) {
     const int slots = 256 * 2;                      // CUs x resident 256-thread workgroups per CU
     const int nblk = (B + 63) / 64;
-    int best = 1;
-    double best_eff = 0.0;
-    for (int n = 1; n <= kMaxSeg; ++n) {
-        if (n > 1 && ntiles / n < 8) break;         // keep segments >= 128 px
-        const double x = (double)nblk * n / slots;
-        const double eff = x / (double)(long long)(x + 0.999999);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = n; }
-        if (eff >= 0.9) { best = n; break; }
+    WorkPlan best{0, nblk, 1, ntiles};
+    double best_cost = 1e300;
+    for (int full = (nblk / slots) * slots; full >= 0; full -= slots) {       // whole rounds kept unsegmented
+        const int rem = nblk - full;
+        for (int n = 1; n <= kMaxSeg; ++n) {
+            if (n > 1 && ntiles / n < 8) break;     // keep segments >= 8 tiles
+            const int st = (ntiles + n - 1) / n;
+            const int nn = (ntiles + st - 1) / st;  // no empty segment
+            const double rounds_rem = rem ? (double)((long long)rem * nn + slots - 1) / slots : 0.0;
+            const double cost = (double)(full / slots) * (ntiles + pro) + (double)(long long)rounds_rem * (st + pro);
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                best = WorkPlan{full, rem, rem ? nn : 1, rem ? st : ntiles};
+            }
+            if (!rem) break;
+        }
+        if (full == 0) break;
     }
     return best;
 }
 
 struct Layout {
-    int KP, NpixPad, ntiles, Bpad, nseg, seg_tiles;
-    int ntiles32, nseg1, seg_tiles1;                   // pass 1 on the XDL pipe walks 32-pixel tiles (N_h <= 16)
+    int KP, NpixPad, ntiles, Bpad;
+    int ntiles32;                                      // pass 1 on the XDL pipe walks 32-pixel tiles (N_h <= 16)
+    WorkPlan wp1, wp2;                                 // work items of pass 1 / pass 2
     size_t oPF, oPFT, oPFX, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
 };
 
@@ -46,23 +57,13 @@ Layout make_layout_t(int B, int Npix) {
     L.NpixPad = round_up(Npix, 16);
     L.ntiles = L.NpixPad / 16;
     L.Bpad = round_up(B, 16);
-    L.nseg = pick_nseg(B, L.ntiles);
-#ifdef QFA_TUNE_ENV
-    if (const char *e = getenv("QFA_NSEG2")) L.nseg = atoi(e);
-#endif
-    L.seg_tiles = (L.ntiles + L.nseg - 1) / L.nseg;
-    L.nseg = (L.ntiles + L.seg_tiles - 1) / L.seg_tiles;          // no empty segment
+    L.ntiles32 = (Npix + 31) / 32;
+    L.wp2 = plan_work(B, L.ntiles, 4);
+    L.wp1 = KP <= 16 ? plan_work(B, L.ntiles32, 1) : plan_work(B, L.ntiles, 2);
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
     L.oPF = take((size_t)L.ntiles * C::TILE_PF);
     L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
-    L.ntiles32 = (Npix + 31) / 32;
-    L.nseg1 = pick_nseg(B, L.ntiles32);
-#ifdef QFA_TUNE_ENV
-    if (const char *e = getenv("QFA_NSEG1")) L.nseg1 = atoi(e);
-#endif
-    L.seg_tiles1 = (L.ntiles32 + L.nseg1 - 1) / L.nseg1;
-    L.nseg1 = (L.ntiles32 + L.seg_tiles1 - 1) / L.seg_tiles1;
     L.oPFX = 0;
     if constexpr (KP <= 16) L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4));
     L.oMOM = take((size_t)kMaxSeg * L.Bpad * C::NMOM);
@@ -99,16 +100,21 @@ void launch_prep(const qfa_params_t &p, int Npix, int Nb, int Nh, const Layout &
     k_prep_pf<KP><<<(L.NpixPad + 3) / 4, blk, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, L.NpixPad, PF, PFT);
 }
 
+// MOM[seg 0] += MOM[seg 1..] for the rows of the segmented blocks of pass 1
 template <int KP>
-void sum_segments(float *MOM, const Layout &L, int nseg, hipStream_t st) {
-    if (nseg <= 1) return;
-    const size_t n4 = (size_t)L.Bpad * Cfg<KP>::NMOM / 4;      // Bpad*NMOM is a multiple of 4
-    k_sum_segments<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(reinterpret_cast<float4 *>(MOM), nseg, n4);
+void sum_segments(float *MOM, const Layout &L, int B, hipStream_t st) {
+    const WorkPlan &w = L.wp1;
+    if (w.rem == 0 || w.nseg <= 1) return;
+    const size_t row0 = (size_t)w.full * 64;
+    const size_t rows = (size_t)L.Bpad - row0;                  // Bpad is a multiple of 16, NMOM of 4
+    const size_t n4 = rows * Cfg<KP>::NMOM / 4, stride4 = (size_t)L.Bpad * Cfg<KP>::NMOM / 4;
+    k_sum_segments<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(
+        reinterpret_cast<float4 *>(MOM + row0 * Cfg<KP>::NMOM), w.nseg, n4, stride4);
 }
 
 // pass 1: N_h <= 16 on the XDL pipe (split-bf16 operands, 32-pixel tiles), wider models on the f32 MFMA
 template <int KP, bool PREDICT>
-int launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, const float *mu, int B, int Npix,
+void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, const float *mu, int B, int Npix,
                    int Nb, int Nh, const Layout &L, float *ws, hipStream_t st) {
     float *MOM = ws + L.oMOM;
     if constexpr (KP <= 16) {
@@ -118,13 +124,10 @@ int launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t 
 #define QFA_XNW 4
 #endif
         constexpr int NW = QFA_XNW;
-        const dim3 grid((B + 16 * NW - 1) / (16 * NW), L.nseg1);
-        k_moments_x<KP, PREDICT, NW><<<grid, 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.seg_tiles1, PFX, MOM);
-        return L.nseg1;
+        static_assert(NW == 4, "the work plan counts blocks of 64 spectra");
+        k_moments_x<KP, PREDICT, NW><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, MOM);
     } else {
-        const dim3 grid((B + 63) / 64, L.nseg);
-        k_moments<KP, PREDICT><<<grid, 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.seg_tiles, ws + L.oPF, MOM);
-        return L.nseg;
+        k_moments<KP, PREDICT><<<L.wp1.items(), 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.wp1, ws + L.oPF, MOM);
     }
 }
 
@@ -141,10 +144,9 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     mark(0);
     launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
     mark(1);
-    const dim3 grid((B + 63) / 64, L.nseg);
-    const int nseg1 = launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, ws, st);
+    launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, ws, st);
     mark(2);
-    sum_segments<KP>(MOM, L, nseg1, st);
+    sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
     k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr);
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
@@ -152,9 +154,9 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
         if (16 * bh >= Nh) break;
         if (b.A_blue)
-            k_grads<KP, true><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, bh, PFT, SOL, accum);
+            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum);
         else
-            k_grads<KP, false><<<grid, 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.seg_tiles, bh, PFT, SOL, accum);
+            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum);
     }
     mark(4);
     return hip_status();
@@ -167,8 +169,8 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     const Layout L = make_layout_t<KP>(B, Npix);
     float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL;
     launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
-    const int nseg1 = launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, ws, st);
-    sum_segments<KP>(MOM, L, nseg1, st);
+    launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, ws, st);
+    sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
     k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, ll, nullptr, B, Nh, hmean, hcov);
     k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);

@@ -127,7 +127,7 @@ struct SpecRegs1 {
 template <int KP, bool PREDICT>
 __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                  const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
-                                                 int ntiles, int seg_tiles, const float *__restrict__ PF,
+                                                 int ntiles, WorkPlan wp, const float *__restrict__ PF,
                                                  float *__restrict__ MOM) {
     using C = Cfg<KP>;
     constexpr int NF4 = C::TILE_PF / 4;
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments(qfa_params_t p
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
-    const int s0 = (blockIdx.x * 4 + wv) * 16;
+    int blk, seg, t0, t1;
+    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
+    const int s0 = (blk * 4 + wv) * 16;
     const bool active = s0 < B;                                   // wave-uniform
-    const int t0 = blockIdx.y * seg_tiles;
-    const int t1 = min(t0 + seg_tiles, ntiles);
     const int nbt = (Nb + 15) >> 4;                               // tiles that contain blue pixels
     const DevConsts k = load_consts(p, tau);
     const int sl = lane & 15, j = lane >> 4;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments(qfa_params_t p
 
     if (!active) return;
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4j + r, column 16t + sl
-    float *momseg = MOM + (size_t)blockIdx.y * Bpad * C::NMOM;
+    float *momseg = MOM + (size_t)seg * Bpad * C::NMOM;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int ss = s0 + 4 * j + r;
@@ -349,12 +349,12 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments(qfa_params_t p
 // ------------------------------------------------------------------------------------------------
 // k_sum_segments : MOM[0] += MOM[1] + ... + MOM[nseg-1] (fixed order), float4-vectorised.
 // ------------------------------------------------------------------------------------------------
-static __global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t n4) {
+static __global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t n4, size_t seg_stride4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     float4 a = mom[i];
     for (int g = 1; g < nseg; ++g) {
-        const float4 b = mom[g * n4 + i];
+        const float4 b = mom[g * seg_stride4 + i];
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     mom[i] = a;
@@ -531,7 +531,7 @@ struct SpecRegs2 {
 
 template <int KP, bool HASA>
 __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B,
-                                                              int Npix, int Nb, int Nh, int ntiles, int seg_tiles,
+                                                              int Npix, int Nb, int Nh, int ntiles, WorkPlan wp,
                                                               int bhalf, const float *__restrict__ PFT,
                                                               const float *__restrict__ SOL,
                                                               float *__restrict__ accum) {
@@ -558,10 +558,10 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
-    const int s0 = (blockIdx.x * 4 + wv) * 16;
+    int blk, seg, t0, t1;
+    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
+    const int s0 = (blk * 4 + wv) * 16;
     const bool active = s0 < B;
-    const int t0 = blockIdx.y * seg_tiles;
-    const int t1 = min(t0 + seg_tiles, ntiles);
     const int nbt = (Nb + 15) >> 4;
     for (int i = tid; i < 2 * 4 * NPART; i += 256) (&ldspart[0][0][0])[i] = 0.f;   // inactive waves' slots stay 0
     const DevConsts k = load_consts(p, tau);
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
         const int n = tb - ta;
         if (n <= 0) return;                                       // block-uniform
         // de-phase the tile order between workgroups so that concurrent flushes hit different rows
-        const int rot = (int)(((unsigned)blockIdx.x * 2654435761u) % (unsigned)n);
+        const int rot = (int)(((unsigned)blk * 2654435761u) % (unsigned)n);
         auto tile_of = [&](int c) {
             int x = c + rot;
             if (x >= n) x -= n;
@@ -1049,8 +1049,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     run(std::false_type{}, max(t0, nbt), t1);
 
 #if QFA_ABL == 7
-    if (blockIdx.x == 300 && lane == 0 && wv == 0 && blockIdx.y < 4) {
-        for (int i = 0; i < 16; ++i) qfa_dbg_stamps[blockIdx.y * 16 + i] = st_t[i];
+    if (blk == 300 && lane == 0 && wv == 0 && seg < 4) {
+        for (int i = 0; i < 16; ++i) qfa_dbg_stamps[seg * 16 + i] = st_t[i];
     }
 #endif
     if (!active) return;

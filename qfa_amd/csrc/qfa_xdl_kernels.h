@@ -93,7 +93,7 @@ struct SpecRegsX {
 template <int KP, bool PREDICT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                       const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
-                                                      int ntiles, int seg_tiles, const unsigned char *__restrict__ PFX,
+                                                      int ntiles, WorkPlan wp, const unsigned char *__restrict__ PFX,
                                                       float *__restrict__ MOM) {
     using C = Cfg<KP>;
     using X = XCfg<KP>;
@@ -101,10 +101,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_para
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
-    const int s0 = (blockIdx.x * NW + wv) * 16;
+    int blk, seg, t0, t1;
+    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
+    const int s0 = (blk * NW + wv) * 16;
     const bool active = s0 < B;                                   // wave-uniform
-    const int t0 = blockIdx.y * seg_tiles;
-    const int t1 = min(t0 + seg_tiles, ntiles);
     const int nbt = (Nb + 31) >> 5;                               // tiles that contain blue pixels
     const DevConsts k = load_consts(p, tau);
     const int sl = lane & 15, g = lane >> 4;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_para
 
     if (!active) return;
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4g + r, column 16t + sl
-    float *momseg = MOM + (size_t)blockIdx.y * Bpad * C::NMOM;
+    float *momseg = MOM + (size_t)seg * Bpad * C::NMOM;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int ss = s0 + 4 * g + r;
