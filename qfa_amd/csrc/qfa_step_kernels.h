@@ -657,7 +657,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
         const int n = tb - ta;
         if (n <= 0) return;                                       // block-uniform
         // de-phase the tile order between workgroups so that concurrent flushes hit different rows
-        const int rot = (int)(((unsigned)blk * 2654435761u) % (unsigned)n);
+                // (within a window of 64 tiles: the workgroups running together then share 0.8 MB of the tile image in L2)
+        const int rot = (int)(((unsigned)blk * 2654435761u) % (unsigned)min(n, 64));
         auto tile_of = [&](int c) {
             int x = c + rot;
             if (x >= n) x -= n;
