@@ -28,6 +28,24 @@ struct XCfg {
     static constexpr int NCHUNK = TILE_B / 1024;
 };
 
+// LDS-DMA: the wave's 64 lanes move 64 x 16 B from per-lane global addresses to LDS byte address lds_dst + 16 * lane
+// (lds_dst wave-uniform).  Written as asm so that hipcc does not count it: with a tracked LDS-DMA in flight hipcc
+// waits vmcnt(0) at the next use of any load result, which would serialise the spectra prefetch behind the image
+// copy.  An untracked extra entry in the in-order vmcnt queue only makes the compiler's own counted waits more
+// conservative; its completion is waited for explicitly (dma_wait<N>: all but the N youngest requests retired).
+// Addresses are wave-uniform base (SGPR pair) + per-lane 32-bit byte offset (VGPR): no address VALU in the loop.
+// M0 (the LDS destination) is written and not restored: a restore behind the DMA waits until the texture path has
+// accepted the request (measured: ~150 cycles per piece, 1 250-2 500 per tile); nothing else in this kernel
+// depends on M0.
+__device__ __forceinline__ void glds16a(const void *sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }   // LDS aperture: low 32 bits
+
 // ------------------------------------------------------------------------------------------------
 template <int KP>
 __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, const float *__restrict__ Psi,
@@ -85,13 +103,33 @@ __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, c
 // (no staging registers) while the current one is consumed; one barrier per tile.
 // Red tiles first (A = 1: T and b2 receive what C and b receive), then the blue tiles.
 // ------------------------------------------------------------------------------------------------
-struct SpecRegsX {
-    float d[8], sg[8], z[8];
-    unsigned m0, m1;      // 8 mask bytes
+struct Pieces {         // bf16 pieces (h, m, l) of the four weight vectors of a lane's 8 pixels
+    u32x4 w1h, w1m, w1l, w2h, w2m, w2l, w3h, w3m, w3l, w4h, w4m, w4l;
 };
 
+struct SpecRegsX {        // one lane's 8 pixels of a tile: delta, sigma, zabs, 8 mask bytes
+    f32x4 d0, d1, s0, s1, z0, z1;
+    u32x2 m;
+};
+// Spectra loads as asm: hipcc cannot keep counted vmcnt waits across the loop back-edge (it falls back to
+// vmcnt(0) at the first use, which would also wait for the tile requested last), so these loads are invisible to
+// its bookkeeping and retired by dma_wait<N>() in front of the tile barrier.  land() makes every later use of the
+// registers depend on a point behind that wait (the compiler may otherwise schedule a use right after the load).
+template <int OFF>
+__device__ __forceinline__ void aload16(f32x4 &dst, const void *sbase, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void aload8(u32x2 &dst, const void *sbase, unsigned voff) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+template <bool BLUE>
+__device__ __forceinline__ void land(SpecRegsX &r) {
+    asm volatile("" : "+v"(r.d0), "+v"(r.d1), "+v"(r.s0), "+v"(r.s1), "+v"(r.m));
+    if (BLUE) asm volatile("" : "+v"(r.z0), "+v"(r.z1));
+}
+
 template <int KP, bool PREDICT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
+__global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                       const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
                                                       int ntiles, WorkPlan wp, const unsigned char *__restrict__ PFX,
                                                       float *__restrict__ MOM) {
@@ -103,7 +141,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_para
     const int wv = wave_uniform(tid >> 6);
     int blk, seg, t0, t1;
     plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
-    const int s0 = (blk * NW + wv) * 16;
+    const int s0 = (blk * 4 + wv) * 16;
     const bool active = s0 < B;                                   // wave-uniform
     const int nbt = (Nb + 31) >> 5;                               // tiles that contain blue pixels
     const DevConsts k = load_consts(p, tau);
@@ -116,6 +154,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_para
     const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
     const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
     const int offN = srow * Npix, offB = srow * Nb;
+    // per-lane byte offsets of the fast-path loads (base = the wave's row block + 32 * tile, in SGPRs)
+    const unsigned voffN = (unsigned)(offN + 8 * g) * 4u, voffB = (unsigned)(offB + 8 * g) * 4u,
+                   voffM = (unsigned)(offN + 8 * g);
 
     f32x4 accC[C::NT], accT[C::NT], accb[C::NFT], accb2[C::NFT];
 #pragma unroll
@@ -125,14 +166,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_para
     double qd = 0.0, ld = 0.0;        // float32 inside an 8-pixel group, float64 across groups
     float cn = 0.f, cblue = 0.f;
 
-    // LDS-DMA of one image tile: wave w moves the 1-KiB pieces w, w+NW, ...
+    // LDS-DMA of one image tile: wave w moves the 1-KiB pieces w, w+4, ...
+    constexpr int NPIECE = (X::NCHUNK + 3) / 4;                   // pieces per wave and tile
+    auto stage_piece = [&](int tg, int buf, int i) {
+        const int ch = wv + 4 * i;
+        if (ch < X::NCHUNK)
+            glds16a(PFX + (size_t)tg * X::TILE_B + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(&lds[buf][ch * 1024])));
+    };
     auto stage = [&](int tg, int buf) {
-        const unsigned char *src = PFX + (size_t)tg * X::TILE_B + lane * 16;
 #pragma unroll
-        for (int i = 0; i < (X::NCHUNK + NW - 1) / NW; ++i) {
-            const int ch = wv + NW * i;
-            if (ch < X::NCHUNK) glds16(src + ch * 1024, &lds[buf][ch * 1024]);
-        }
+        for (int i = 0; i < NPIECE; ++i) stage_piece(tg, buf, i);
     };
 
     auto run = [&](auto blue_tag, int ta, int tb) {
@@ -140,51 +183,51 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_para
         const int n = tb - ta;
         if (n <= 0) return;                                       // block-uniform
 
+        // returns true when the loads were issued as (untracked) asm loads
         auto load_spec = [&](int tg, SpecRegsX &r) {
             const int pb = 32 * tg + 8 * g;
             if (pb + 7 < Npix) {
-                const f4u vd0 = *reinterpret_cast<const f4u *>(dbase + offN + pb);
-                const f4u vd1 = *reinterpret_cast<const f4u *>(dbase + offN + pb + 4);
-                const f4u ve0 = *reinterpret_cast<const f4u *>(ebase + offN + pb);
-                const f4u ve1 = *reinterpret_cast<const f4u *>(ebase + offN + pb + 4);
-                const u4u vm0 = *reinterpret_cast<const u4u *>(mbase + offN + pb);
-                const u4u vm1 = *reinterpret_cast<const u4u *>(mbase + offN + pb + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    r.d[e] = vd0.v[e]; r.d[4 + e] = vd1.v[e];
-                    r.sg[e] = ve0.v[e]; r.sg[4 + e] = ve1.v[e];
-                }
-                r.m0 = (unsigned)vm0.v[0] | ((unsigned)vm0.v[1] << 8) | ((unsigned)vm0.v[2] << 16) |
-                       ((unsigned)vm0.v[3] << 24);
-                r.m1 = (unsigned)vm1.v[0] | ((unsigned)vm1.v[1] << 8) | ((unsigned)vm1.v[2] << 16) |
-                       ((unsigned)vm1.v[3] << 24);
-            } else {                                              // ragged end of the pixel axis
-                r.m0 = r.m1 = 0;
+                aload16<0>(r.d0, dbase + 32 * tg, voffN);
+                aload16<16>(r.d1, dbase + 32 * tg, voffN);
+                aload16<0>(r.s0, ebase + 32 * tg, voffN);
+                aload16<16>(r.s1, ebase + 32 * tg, voffN);
+                aload8(r.m, mbase + 32 * tg, voffM);
+            } else {                                              // ragged end of the pixel axis (ordinary loads)
+                unsigned m0 = 0, m1 = 0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int px = min(pb + e, Npix - 1);
-                    r.d[e] = dbase[offN + px];
-                    r.sg[e] = ebase[offN + px];
+                    const float dv = dbase[offN + px], sv = ebase[offN + px];
+                    if (e < 4) { r.d0[e] = dv; r.s0[e] = sv; }
+                    else { r.d1[e - 4] = dv; r.s1[e - 4] = sv; }
                     const unsigned bit = (pb + e < Npix && mbase[offN + px] != 0) ? (1u << (8 * (e & 3))) : 0u;
-                    if (e < 4) r.m0 |= bit;
-                    else r.m1 |= bit;
+                    if (e < 4) m0 |= bit;
+                    else m1 |= bit;
                 }
+                r.m[0] = m0;
+                r.m[1] = m1;
+                // retire these (tracked) loads here: pending at the join, they would make the compiler wait
+                // vmcnt(0) in front of the fast path's next loads into the same registers
+                asm volatile("" : "+v"(r.d0), "+v"(r.d1), "+v"(r.s0), "+v"(r.s1));
             }
             if (BLUE) {
                 if (pb + 7 < Nb) {
-                    const f4u vz0 = *reinterpret_cast<const f4u *>(zbase + offB + pb);
-                    const f4u vz1 = *reinterpret_cast<const f4u *>(zbase + offB + pb + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { r.z[e] = vz0.v[e]; r.z[4 + e] = vz1.v[e]; }
+                    aload16<0>(r.z0, zbase + 32 * tg, voffB);
+                    aload16<16>(r.z1, zbase + 32 * tg, voffB);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) r.z[e] = zbase[offB + min(pb + e, Nb - 1)];
+                    for (int e = 0; e < 8; ++e) {
+                        const float zv = zbase[offB + min(pb + e, Nb - 1)];
+                        if (e < 4) r.z0[e] = zv;
+                        else r.z1[e - 4] = zv;
+                    }
+                    asm volatile("" : "+v"(r.z0), "+v"(r.z1));
                 }
             }
         };
 
-        auto compute = [&](int tg, const SpecRegsX &cur, const unsigned char *tile) {
-            // ---- per-element weights on the VALU (QFA/model.py:125-131)
+        // ---- phase 1 of a tile: per-element weights on the VALU (QFA/model.py:125-131), split into bf16 pieces
+        auto weights = [&](int tg, const SpecRegsX &cur, const unsigned char *tile, Pieces &w) {
             const float *pp = reinterpret_cast<const float *>(tile + X::OFF_PSI) + 8 * g;
             float psi[8], om[8];
             {
@@ -198,65 +241,68 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_para
                     om[4] = d.x; om[5] = d.y; om[6] = d.z; om[7] = d.w;
                 }
             }
-            float c2[8], c3[8], cb[8], cb2[8];
             float qd8 = 0.f, ld8 = 0.f;
+            // pixel pair by pixel pair: weights of two pixels, then their bf16 pieces (short live ranges)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int px = 32 * tg + 8 * g + e;
-                const unsigned mb = ((e < 4 ? cur.m0 : cur.m1) >> (8 * (e & 3))) & 0xffu;
-                const bool w = svalid & (mb != 0);
-                float d = cur.d[e];
-                const float sg = cur.sg[e];
-                float D, wD;
-                if (BLUE) {
-                    const bool blue = px < Nb;
-                    const BlueTerms t = blue_terms(cur.z[e], k);
-                    float Ab = t.A;
-                    if (abase) Ab = abase[offB + min(px, Nb - 1)];        // custom tau callable (rare path)
-                    const float A = blue ? Ab : 1.f;
-                    const float zdom = blue ? t.zd * om[e] : 0.f;
-                    D = A * A * psi[e] + zdom + sg * sg;
-                    if (PREDICT) d = d - mu[min(px, Npix - 1)] * A;      // QFA/model.py:166
-                    wD = w ? fast_rcp(D) : 0.f;
-                    d = w ? d : 0.f;
-                    const float wDA = wD * A;
-                    c2[e] = wDA * A;
-                    c3[e] = c2[e] * A;
-                    cb[e] = wDA * d;
-                    cb2[e] = c2[e] * d;
-                    cblue += (w & blue) ? 1.f : 0.f;
-                } else {                                                 // red side: A = 1, no omega term
-                    D = psi[e] + sg * sg;
-                    if (PREDICT) d = d - mu[min(px, Npix - 1)];
-                    wD = w ? fast_rcp(D) : 0.f;
-                    d = w ? d : 0.f;
-                    c2[e] = wD;
-                    cb[e] = wD * d;
+            for (int q = 0; q < 4; ++q) {
+                float c2[2], c3[2], cb[2], cb2[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int e = 2 * q + h2;
+                    const int px = 32 * tg + 8 * g + e;
+                    const unsigned mb = (cur.m[e >> 2] >> (8 * (e & 3))) & 0xffu;
+                    const bool wv_ = svalid & (mb != 0);
+                    float d = e < 4 ? cur.d0[e & 3] : cur.d1[e & 3];
+                    const float sg = e < 4 ? cur.s0[e & 3] : cur.s1[e & 3];
+                    float D, wD;
+                    if (BLUE) {
+                        const bool blue = px < Nb;
+                        const BlueTerms t = blue_terms(e < 4 ? cur.z0[e & 3] : cur.z1[e & 3], k);
+                        float Ab = t.A;
+                        if (abase) Ab = abase[offB + min(px, Nb - 1)];        // custom tau callable (rare path)
+                        const float A = blue ? Ab : 1.f;
+                        const float zdom = blue ? t.zd * om[e] : 0.f;
+                        D = A * A * psi[e] + zdom + sg * sg;
+                        if (PREDICT) d = d - mu[min(px, Npix - 1)] * A;      // QFA/model.py:166
+                        wD = wv_ ? fast_rcp(D) : 0.f;
+                        d = wv_ ? d : 0.f;
+                        const float wDA = wD * A;
+                        c2[h2] = wDA * A;
+                        c3[h2] = c2[h2] * A;
+                        cb[h2] = wDA * d;
+                        cb2[h2] = c2[h2] * d;
+                        cblue += (wv_ & blue) ? 1.f : 0.f;
+                    } else {                                                 // red side: A = 1, no omega term
+                        D = psi[e] + sg * sg;
+                        if (PREDICT) d = d - mu[min(px, Npix - 1)];
+                        wD = wv_ ? fast_rcp(D) : 0.f;
+                        d = wv_ ? d : 0.f;
+                        c2[h2] = wD;
+                        cb[h2] = wD * d;
+                    }
+                    qd8 += wD * d * d;
+                    ld8 += wv_ ? fast_log(D) : 0.f;
+                    cn += wv_ ? 1.f : 0.f;
                 }
-                qd8 += wD * d * d;
-                ld8 += w ? fast_log(D) : 0.f;
-                cn += w ? 1.f : 0.f;
+                unsigned h, m, l;
+                split2(c2[0], c2[1], h, m, l);
+                w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = l;
+                split2(cb[0], cb[1], h, m, l);
+                w.w3h[q] = h; w.w3m[q] = m; w.w3l[q] = l;
+                if (BLUE) {
+                    split2(c3[0], c3[1], h, m, l);
+                    w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = l;
+                    split2(cb2[0], cb2[1], h, m, l);
+                    w.w4h[q] = h; w.w4m[q] = m; w.w4l[q] = l;
+                }
+                pin(qd8, ld8);
+                __builtin_amdgcn_sched_barrier(0);
             }
             qd += (double)qd8;
             ld += (double)ld8;
-            // ---- the weights as bf16 pieces: A operands of the four contractions
-            u32x4 w1h, w1m, w1l, w2h, w2m, w2l, w3h, w3m, w3l, w4h, w4m, w4l;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned h, m, l;
-                split2(c2[2 * q], c2[2 * q + 1], h, m, l);
-                w1h[q] = h; w1m[q] = m; w1l[q] = l;
-                split2(cb[2 * q], cb[2 * q + 1], h, m, l);
-                w3h[q] = h; w3m[q] = m; w3l[q] = l;
-                if (BLUE) {
-                    split2(c3[2 * q], c3[2 * q + 1], h, m, l);
-                    w2h[q] = h; w2m[q] = m; w2l[q] = l;
-                    split2(cb2[2 * q], cb2[2 * q + 1], h, m, l);
-                    w4h[q] = h; w4m[q] = m; w4l[q] = l;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- XDL: per 16-column tile of the image three ds_read_b128, then 6 (red) or 12 (blue) MFMAs
+        };
+        // ---- phase 3: per 16-column tile of the image three ds_read_b128, then 6 (red) or 12 (blue) XDL MFMAs
+        auto mfmas = [&](const unsigned char *tile, const Pieces &w) {
             const unsigned char *bcol = tile + lane * 16;            // lane-linear: conflict-free ds_read_b128
             auto rdB = [&](int piece, int ct) {
                 return *reinterpret_cast<const u32x4 *>(bcol + piece * X::PSTR + ct * 1024);
@@ -264,37 +310,53 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_moments_x(qfa_para
 #pragma unroll
             for (int t = 0; t < C::NFT; ++t) {
                 const u32x4 bh = rdB(0, t), bm = rdB(1, t), bl = rdB(2, t);
-                accb[t] = xdl6(w3h, w3m, w3l, bh, bm, bl, accb[t]);
-                if (BLUE) accb2[t] = xdl6(w4h, w4m, w4l, bh, bm, bl, accb2[t]);
+                accb[t] = xdl6(w.w3h, w.w3m, w.w3l, bh, bm, bl, accb[t]);
+                if (BLUE) accb2[t] = xdl6(w.w4h, w.w4m, w.w4l, bh, bm, bl, accb2[t]);
             }
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 const u32x4 bh = rdB(0, C::NFT + t), bm = rdB(1, C::NFT + t), bl = rdB(2, C::NFT + t);
-                accC[t] = xdl6(w1h, w1m, w1l, bh, bm, bl, accC[t]);
-                if (BLUE) accT[t] = xdl6(w2h, w2m, w2l, bh, bm, bl, accT[t]);
+                accC[t] = xdl6(w.w1h, w.w1m, w.w1l, bh, bm, bl, accC[t]);
+                if (BLUE) accT[t] = xdl6(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
             }
         };
 
-        // one tile: start the LDS-DMA of image tile c+1 and the spectra loads of tile c+1, compute tile c from
-        // LDS buffer `buf`, ONE barrier (it also retires the DMA: the compiler waits vmcnt(0) in front of it).
-        auto step = [&](int c, const SpecRegsX &cur, SpecRegsX &nxt, int buf) {
-            const bool more = c + 1 < n;
-            if (more) {
-                stage(ta + c + 1, buf ^ 1);
-                if (active) load_spec(ta + c + 1, nxt);
-            }
-            if (active) compute(ta + c, cur, lds[buf]);
-            __syncthreads();
+        // One tile.  Phase 1 consumes the spectra registers of tile c; phase 2 starts the LDS-DMA of image tile
+        // c+1 and reloads the same registers with tile c+2 (those loads have the MFMA phase of this step and the
+        // whole next step to land, so HBM requests are in flight all the time); phase 3 issues the MFMAs.  The
+        // raw barrier waits for the DMA only: vmcnt counts in issue order and the spectra loads come after it.
+        auto step = [&](int c, SpecRegsX &cur, int buf) {
+            Pieces w;
+            land<BLUE>(cur);
+            if (active) weights(ta + c, cur, lds[buf], w);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < n) stage(ta + c + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool reload = active & (c + 2 < n);
+            if (reload) load_spec(ta + c + 2, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) mfmas(lds[buf], w);
+            // retire everything up to and including the DMA: it was issued before the 5 (red: 2 delta, 2 sigma,
+            // 1 mask) / 7 (blue: + 2 zabs) spectra loads of this step (the ragged-end path issues more, smaller ones)
+            if (reload) dma_wait<BLUE ? 7 : 5>();
+            else dma_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         };
 
         SpecRegsX ra, rb;
         stage(ta, 0);
-        if (active) load_spec(ta, ra);
+        if (active) {
+            load_spec(ta, ra);
+            if (n > 1) load_spec(ta + 1, rb);
+        }
+        dma_wait<0>();
         __syncthreads();
         for (int c = 0; c < n; c += 2) {
-            step(c, ra, rb, 0);
-            if (c + 1 < n) step(c + 1, rb, ra, 1);
+            step(c, ra, 0);
+            if (c + 1 < n) step(c + 1, rb, 1);
         }
+        __syncthreads();
     };
     run(std::false_type{}, max(t0, nbt), t1);
 #pragma unroll
