@@ -611,13 +611,19 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     }
     if constexpr (XS3) {
         unsigned *zl = ldszl[wv];
+        // all 64 loads first (the LDS stores below otherwise serialise them: load 4, wait, split, store, ...)
+        float zraw[16][4];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const bool v = active && (s0 + s) < B && lo < KP;
             const float *sol = SOL + (size_t)(v ? s0 + s : 0) * C::NSOL + C::SOL_Z + lo;
-            float z[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) z[j] = (v && 4 * g + j < KP) ? sol[(4 * g + j) * KP] : 0.f;
+            for (int j = 0; j < 4; ++j) zraw[s][j] = (v && 4 * g + j < KP) ? sol[(4 * g + j) * KP] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float *z = zraw[s];
             unsigned h0, m0, l0, h1, m1, l1;
             split2(z[0], z[1], h0, m0, l0);
             split2(z[2], z[3], h1, m1, l1);
