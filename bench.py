@@ -85,8 +85,8 @@ def cpu_baseline(params, batch, n_sample, npix):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="spectra per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
