@@ -394,6 +394,36 @@ def test_full_size_properties_config2(dev):
         assert abs(nll[s].item() - o) / abs(o) < TOL_NLL
 
 
+@pytest.mark.parametrize("nh,B", [(16, 33280 + 37), (8, 65536 + 64 * 5 + 3), (20, 512 * 64 + 1)])
+def test_work_plan_full_rounds_plus_segmented_remainder(dev, nh, B):
+    """More than 512 blocks of 64 spectra: the work plan mixes full-length items with a segmented remainder
+    (and the remainder's MOM partials are summed for those rows only).  Same properties as above: additivity
+    over a split of the batch, per-spectrum NLL independent of the batch it is in, the oracle on samples."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    npix = 160
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=nh)
+    d, e, z, mk = synthetic.make_batch_torch(p, mu, wav, nb, B, 77 + nh, dev, masks=True)
+    m = make_model(dev, p, mu)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    acc = m.accumulate(d, e, z, mk, nll=nll).clone()
+    assert acc[-3].item() == B and torch.isfinite(nll).all()
+    cuts = [0, 700, min(700 + 64 * 512, B), B]           # a small batch, (up to) exactly one full round, the rest
+    tot = torch.zeros_like(acc)
+    for a, b_ in zip(cuts[:-1], cuts[1:]):
+        if b_ <= a:
+            continue
+        part = torch.empty(b_ - a, dtype=torch.float32, device=dev)
+        tot += m.accumulate(d[a:b_], e[a:b_], z[a:b_], mk[a:b_], nll=part)
+        assert rel_l2(part.cpu().numpy(), nll[a:b_].cpu().numpy()) < 1e-6
+    assert rel_l2(tot.cpu().numpy(), acc.cpu().numpy()) < 5e-5      # float32 atomics over 3e4 spectra re-associate
+    for s in (0, 699, min(700 + 64 * 512, B) - 1, B - 1):
+        o, _ = O.nll_and_grads_single(p, d[s].cpu().numpy(), e[s].cpu().numpy(), z[s].cpu().numpy(), mk[s].cpu().numpy())
+        assert abs(nll[s].item() - o) / abs(o) < TOL_NLL
+
+
 @pytest.mark.parametrize("npix,nh", [(2000, 8), (4000, 16), (8000, 32)])
 def test_tolerance_sweep_float64_oracle_vs_float32_hip(dev, npix, nh):
     """BASELINE configs 2 / 3 / 5 shapes (N_pix, N_h) on a small batch: float64 oracle vs float32 HIP.
