@@ -15,8 +15,9 @@ inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
 // Work plan of a pass (WorkPlan, qfa_common.h): the blocks of 64 spectra that fill whole rounds of the 512
 // resident-workgroup slots walk the whole pixel axis; the remaining blocks are cut into 1..8 pixel segments.  The
 // plan minimises rounds x (tiles per item + prologue), the prologue of an item (operand loads, pipeline fill)
-// counted as `pro` tiles; small batches (no full round) get the uniform split that fills the chip.
-constexpr int kMaxSeg = 8;
+// counted as `pro` tiles; small batches (no full round) get the uniform split that fills the chip -- down to three
+// tiles per item while the chip stays at most half full (the step of a small batch is latency-bound).
+constexpr int kMaxSeg = 32;
 
 inline WorkPlan plan_work(int B, int ntiles, int pro) {
     const int slots = 256 * 2;                      // CUs x resident 256-thread workgroups per CU
@@ -26,7 +27,9 @@ inline WorkPlan plan_work(int B, int ntiles, int pro) {
     for (int full = (nblk / slots) * slots; full >= 0; full -= slots) {       // whole rounds kept unsegmented
         const int rem = nblk - full;
         for (int n = 1; n <= kMaxSeg; ++n) {
-            if (n > 1 && ntiles / n < 8) break;     // keep segments >= 8 tiles
+            const bool latency_bound = full == 0 && (long long)rem * n <= slots / 2;     // chip at most half full
+            if (n > 1 && ntiles / n < (latency_bound ? 3 : 8)) break;  // keep segments >= 8 tiles (3 when latency-bound)
+            if (n > 8 && !latency_bound) break;     // more than 8 segments measured slower once the chip is full
             const int st = (ntiles + n - 1) / n;
             const int nn = (ntiles + st - 1) / st;  // no empty segment
             const double rounds_rem = rem ? (double)((long long)rem * nn + slots - 1) / slots : 0.0;
@@ -66,7 +69,8 @@ Layout make_layout_t(int B, int Npix) {
     L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
     L.oPFX = 0;
     if constexpr (KP <= 16) L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4));
-    L.oMOM = take((size_t)kMaxSeg * L.Bpad * C::NMOM);
+    // moment records: segment 0 for every row, segments 1.. for the rows of the segmented blocks only
+    L.oMOM = take(((size_t)L.Bpad + (size_t)(L.wp1.nseg - 1) * (L.Bpad - 64 * (size_t)L.wp1.full)) * C::NMOM);
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
     L.oNLL = take((size_t)L.Bpad);
     L.oNBL = take((size_t)L.Bpad);
@@ -107,9 +111,10 @@ void sum_segments(float *MOM, const Layout &L, int B, hipStream_t st) {
     if (w.rem == 0 || w.nseg <= 1) return;
     const size_t row0 = (size_t)w.full * 64;
     const size_t rows = (size_t)L.Bpad - row0;                  // Bpad is a multiple of 16, NMOM of 4
-    const size_t n4 = rows * Cfg<KP>::NMOM / 4, stride4 = (size_t)L.Bpad * Cfg<KP>::NMOM / 4;
+    const size_t n4 = rows * Cfg<KP>::NMOM / 4;
     k_sum_segments<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(
-        reinterpret_cast<float4 *>(MOM + row0 * Cfg<KP>::NMOM), w.nseg, n4, stride4);
+        reinterpret_cast<float4 *>(MOM + row0 * Cfg<KP>::NMOM),
+        reinterpret_cast<const float4 *>(MOM + (size_t)L.Bpad * Cfg<KP>::NMOM), w.nseg, n4);
 }
 
 // pass 1: N_h <= 16 on the XDL pipe (split-bf16 operands, 32-pixel tiles), wider models on the f32 MFMA

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments(qfa_params_t p
 
     if (!active) return;
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4j + r, column 16t + sl
-    float *momseg = MOM + (size_t)seg * Bpad * C::NMOM;
+    float *momseg = mom_segment<C::NMOM>(MOM, wp, seg, Bpad);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int ss = s0 + 4 * j + r;
@@ -349,12 +349,12 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments(qfa_params_t p
 // ------------------------------------------------------------------------------------------------
 // k_sum_segments : MOM[0] += MOM[1] + ... + MOM[nseg-1] (fixed order), float4-vectorised.
 // ------------------------------------------------------------------------------------------------
-static __global__ void k_sum_segments(float4 *__restrict__ mom, int nseg, size_t n4, size_t seg_stride4) {
+static __global__ void k_sum_segments(float4 *__restrict__ mom, const float4 *__restrict__ rest, int nseg, size_t n4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     float4 a = mom[i];
     for (int g = 1; g < nseg; ++g) {
-        const float4 b = mom[g * seg_stride4 + i];
+        const float4 b = rest[(size_t)(g - 1) * n4 + i];
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     mom[i] = a;

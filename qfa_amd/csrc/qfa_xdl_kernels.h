@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
 
     if (!active) return;
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4g + r, column 16t + sl
-    float *momseg = MOM + (size_t)seg * Bpad * C::NMOM;
+    float *momseg = mom_segment<C::NMOM>(MOM, wp, seg, Bpad);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int ss = s0 + 4 * g + r;

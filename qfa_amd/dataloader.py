@@ -88,13 +88,18 @@ class DeviceDataloader(object):
         return self._mu
 
     # ------------------------------------------------------------------ batches
-    def _build(self, rows):
+    def _build(self, rows, out=None):
         n = len(rows)
         idx = torch.as_tensor(np.asarray(rows, dtype=np.int32), device=self.device)
-        delta = torch.empty((n, self.Npix), dtype=f32, device=self.device)
-        err = torch.empty((n, self.Npix), dtype=f32, device=self.device)
-        zabs = torch.empty((n, self.Nb), dtype=f32, device=self.device)
-        mask = torch.empty((n, self.Npix), dtype=torch.bool, device=self.device)
+        if out is not None:                                   # caller-owned buffers (a captured step graph reads them)
+            delta, err, zabs, mask = out
+            if tuple(delta.shape) != (n, self.Npix) or tuple(zabs.shape) != (n, self.Nb):
+                raise _lib.QFAHipError("out buffers do not match the batch")
+        else:
+            delta = torch.empty((n, self.Npix), dtype=f32, device=self.device)
+            err = torch.empty((n, self.Npix), dtype=f32, device=self.device)
+            zabs = torch.empty((n, self.Nb), dtype=f32, device=self.device)
+            mask = torch.empty((n, self.Npix), dtype=torch.bool, device=self.device)
         _lib.check(_lib.lib().qfa_build_batch_f32(
             C.c_void_p(self.flux.data_ptr()), C.c_void_p(self.error.data_ptr()), C.c_void_p(self._zq_dev.data_ptr()),
             C.c_void_p(idx.data_ptr()), C.c_void_p(self._wav_dev.data_ptr()), float(self.wav_grid[0]),
@@ -106,12 +111,16 @@ class DeviceDataloader(object):
     def have_next_batch(self):
         return self.cur < self.data_size
 
-    def next_batch(self):
-        """delta, error, zabs, mask of the next batch (reference QFA/dataloader.py:124-138)."""
+    def next_batch(self, out=None):
+        """delta, error, zabs, mask of the next batch (reference QFA/dataloader.py:124-138); ``out`` = four
+        caller-owned tensors of the batch's shape to build into."""
         start = self.cur
         end = min(self.cur + self.batch_size, self.data_size)
         self.cur = end
-        return self._build(self._order[start:end])
+        return self._build(self._order[start:end], out)
+
+    def next_batch_size(self):
+        return min(self.cur + self.batch_size, self.data_size) - self.cur
 
     def rewind(self):
         """shuffle and reset (reference QFA/dataloader.py:154-167); only the row order is permuted,

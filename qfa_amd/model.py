@@ -331,23 +331,33 @@ class QFA(object):
             setattr(self, k, new[k])
         return loss
 
+    def step_graph(self, optimizer, batch_size):
+        """A captured hipGraph of one training step for batches of ``batch_size`` spectra (StepGraph)."""
+        return StepGraph(self, optimizer, batch_size)
+
     def train(self, optimizer, dataloader, n_epochs, output_dir="./result", save_interval=5, smooth_interval=5,
-              quiet=False, logger=None):
+              quiet=False, logger=None, use_graph=False):
         """Training loop with the reference's control flow (reference QFA/model.py:183-231):
         Niter = data_size // batch_size (quirk Q5), optimizer.step() once per epoch (Q4), early
-        stop the first time the epoch-mean NLL is negative (Q6), smooth / save cadence."""
+        stop the first time the epoch-mean NLL is negative (Q6), smooth / save cadence.
+        ``use_graph``: replay a captured hipGraph of the step for the full-size batches (small batches are
+        launch-bound: ~15 launches of a few microseconds each); same arithmetic, parameters updated in place."""
         os.makedirs(output_dir, exist_ok=True)
         output_dir = os.path.join(output_dir, "checkpoints")
         os.makedirs(output_dir, exist_ok=True)
         self.mu = torch.tensor(np.asarray(dataloader.mu), dtype=f32).to(self.device)
         Niter = dataloader.data_size // dataloader.batch_size
+        sg = self.step_graph(optimizer, dataloader.batch_size) if (use_graph and not self._dp) else None
         for epoch in range(n_epochs):
             dataloader.rewind()
             total = torch.zeros((), dtype=torch.float64, device=self.device)
             t0 = time.time()
             while dataloader.have_next_batch():
-                d, e, z, m = dataloader.next_batch()
-                loss = self.step(optimizer, d, e, z, m)
+                if sg is not None and sg.fits(dataloader):
+                    loss = sg.run_next(dataloader)
+                else:
+                    d, e, z, m = dataloader.next_batch()
+                    loss = self.step(optimizer, d, e, z, m)
                 total += loss.reshape(()).double()
             optimizer.step()
             total_loss = total.item() / Niter          # one host sync per epoch; ZeroDivisionError if Niter == 0
@@ -389,6 +399,78 @@ class QFA(object):
         self.tau0 = T(f["tau0"])
         self.beta = T(f["beta"])
         self.c0 = T(f["beta"] if reference_c0_quirk else f["c0"])
+
+
+class StepGraph(object):
+    """One training step (forward -> sum/count -> Adam + clip, model.py:212-214) captured as a hipGraph.
+
+    The step of a small batch is launch-bound; the graph replays its ~15 kernels with one submission.  Inputs
+    live in fixed buffers (a DeviceDataloader builds its batches straight into them, other loaders are copied),
+    parameters and Adam moments are updated in place.  The learning rate and the bias-correction index are
+    kernel arguments by value, so the graph is re-captured when they (or a parameter tensor) change -- once per
+    epoch in ``QFA.train``.  The first step after such a change runs eagerly (it also warms the workspace up)."""
+
+    def __init__(self, model, optimizer, batch_size):
+        self.model, self.opt, self.B = model, optimizer, int(batch_size)
+        dev = model.device
+        self.buf = (torch.empty((self.B, model.Npix), dtype=f32, device=dev),
+                    torch.empty((self.B, model.Npix), dtype=f32, device=dev),
+                    torch.empty((self.B, model.Nb), dtype=f32, device=dev),
+                    torch.empty((self.B, model.Npix), dtype=torch.bool, device=dev))
+        self.graph, self.key, self.loss = None, None, None
+        self.replays = 0
+
+    def _key(self):
+        m = self.model
+        return (self.opt.i, float(self.opt.scheduled_lr)) + tuple(getattr(m, k).data_ptr() for k in PARAM_KEYS)
+
+    def _body(self):
+        m = self.model
+        loss, grads = m.forward(*self.buf)
+        self.opt.update(m.parameters, grads, clip=m._clip_table(), inplace=True)
+        return loss
+
+    def fits(self, dataloader):
+        n = dataloader.next_batch_size() if hasattr(dataloader, "next_batch_size") else None
+        return n is None or n == self.B
+
+    def _fill(self, dataloader):
+        if hasattr(dataloader, "next_batch_size"):
+            dataloader.next_batch(out=self.buf)
+            return True
+        batch = dataloader.next_batch()
+        if batch[0].shape[0] != self.B:
+            return batch
+        for dst, src in zip(self.buf, batch):
+            dst.copy_(src)
+        return True
+
+    def run_next(self, dataloader):
+        filled = self._fill(dataloader)
+        if filled is not True:                                   # a short last batch of a foreign loader
+            return self.model.step(self.opt, *filled)
+        return self.run()
+
+    def run(self):
+        """one step on the batch in ``self.buf``"""
+        m = self.model
+        for k in PARAM_KEYS:                                     # in-place updates need plain float32 storage
+            p = getattr(m, k)
+            if p.dtype != f32 or not p.is_contiguous():
+                setattr(m, k, p.to(f32).contiguous())
+        key = self._key()
+        if key != self.key:
+            self.graph, self.key = None, key
+            return self._body()                                  # eager: first step with these scalars
+        if self.graph is None:
+            torch.cuda.synchronize(m.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.loss = self._body()
+            self.graph = g
+        self.graph.replay()
+        self.replays += 1
+        return self.loss
 
 
 QFAModel = QFA

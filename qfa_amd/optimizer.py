@@ -49,10 +49,11 @@ class Adam(object):
             return self.scheduler(self.i, self.learning_rate)
         return self.learning_rate
 
-    def update(self, params, g, clip: Optional[Dict[str, Tuple[float, float]]] = None):
+    def update(self, params, g, clip: Optional[Dict[str, Tuple[float, float]]] = None, inplace: bool = False):
         """reference QFA/optimizer.py:37-52.  ``clip`` (key -> (lo, hi)) optionally fuses the
         clamp of QFA.clip into the same launch; the plain reference call leaves it out and the
-        ``QFA.parameters`` setter clips afterwards."""
+        ``QFA.parameters`` setter clips afterwards.  ``inplace`` writes the new values over ``params``
+        (fixed addresses: what a captured hipGraph of the step needs) instead of returning new tensors."""
         h = _lib.lib()
         lr = float(self.scheduled_lr)
         out = {}
@@ -65,7 +66,9 @@ class Adam(object):
                 grad = grad.to(f32).contiguous()
             pp = _lib.require_device_tensor(p, f32, f"params[{k}]")
             gp = _lib.require_device_tensor(grad, f32, f"g[{k}]")
-            q = torch.empty_like(p)
+            if inplace and p is not params[k]:
+                raise ValueError(f"in-place update needs contiguous float32 params[{k}]")
+            q = p if inplace else torch.empty_like(p)
             lo, hi = clip[k] if (clip is not None and k in clip) else (1.0, 0.0)
             _lib.check(h.qfa_adam_clip_f32(pp, gp, C.c_void_p(self.m[k].data_ptr()), C.c_void_p(self.v[k].data_ptr()),
                                            C.c_void_p(q.data_ptr()), p.numel(), lr, self.b1, self.b2, self.eps,

@@ -176,3 +176,43 @@ def test_predict_writer_and_checkpoint_resume(tmp_path):
     m2.step(o2, *args)
     for k in KEYS:
         assert rel_l2(m2.parameters[k].cpu().numpy(), m1.parameters[k].cpu().numpy()) < 1e-6, k
+
+
+@pytest.mark.parametrize("loader_kind", ["device", "foreign"])
+def test_train_with_step_graph_matches_eager(tmp_path, loader_kind):
+    """hipGraph replay of the step (StepGraph) against the eager loop: same parameters after three epochs with
+    a trailing partial batch, smoothing in between and a learning-rate change per epoch (re-capture)."""
+    import torch
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+    from qfa_amd.dataloader import DeviceDataloader
+    from qfa_amd.model import StepGraph
+    dev = torch.device("cuda:0")
+    wav, nb, nr = synthetic.wavelength_grid(320)
+    p, mu0 = synthetic.mock_parameters(320, nb, 4, seed=5)
+    b = synthetic.make_batch_numpy(p, mu0, wav, nb, 27, seed=51, masks=False)
+
+    def run(use_graph):
+        if loader_kind == "device":
+            dl = DeviceDataloader(b["flux"], b["error"], b["zqso"], wav, batch_size=6, device=dev, shuffle=False)
+        else:
+            dl = FakeLoader(b, mu0, 6, dev)
+        model = QFA(nb, nr, 4, dev, model_params=p)
+        opt = Adam(model.parameters, dev, scheduler=step_scheduler(0.5, 1), learning_rate=1e-3, weight_decay=1e-1)
+        model.train(opt, dl, 3, str(tmp_path / ("g" if use_graph else "e")), quiet=True, smooth_interval=2,
+                    use_graph=use_graph)
+        return {k: model.parameters[k].cpu().numpy() for k in KEYS}
+
+    eager, graph = run(False), run(True)
+    for k in KEYS:
+        assert rel_l2(graph[k], eager[k]) < 1e-6, k
+    # the graph really replays: 4 full batches per epoch, the first one of an epoch eager, the second captured
+    model = QFA(nb, nr, 4, dev, model_params=p)
+    opt = Adam(model.parameters, dev, learning_rate=1e-3)
+    sg = StepGraph(model, opt, 6)
+    dl = FakeLoader(b, mu0, 6, dev)
+    n = 0
+    while dl.have_next_batch() and sg.fits(dl) and n < 4:
+        loss = sg.run_next(dl)
+        n += 1
+    torch.cuda.synchronize()
+    assert sg.replays == 3 and torch.isfinite(loss).all()
