@@ -126,6 +126,23 @@ int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float 
                       double lr, double b1, double b2, double eps, double wd, int i,
                       float lo, float hi, void *stream);
 
+/* Adam.update + clip for up to QFA_ADAM_MAX tensors in ONE launch (reference QFA/optimizer.py:37-52 loops over the
+ * parameter dict, QFA/model.py:233-241 clips each entry): same arithmetic as qfa_adam_clip_f32 per tensor.
+ * lo[k] > hi[k] disables the clip of tensor k; p_out[k] may equal p[k] (in place). */
+#define QFA_ADAM_MAX 8
+typedef struct {
+    const float *p[QFA_ADAM_MAX];
+    const float *g[QFA_ADAM_MAX];
+    float *m[QFA_ADAM_MAX];
+    float *v[QFA_ADAM_MAX];
+    float *p_out[QFA_ADAM_MAX];
+    size_t n[QFA_ADAM_MAX];
+    float lo[QFA_ADAM_MAX], hi[QFA_ADAM_MAX];
+    int count;
+} qfa_adam_multi_t;
+int qfa_adam_clip_multi_f32(const qfa_adam_multi_t *t, double lr, double b1, double b2, double eps, double wd, int i,
+                            void *stream);
+
 /* Replaces QFA.clip for one tensor (reference QFA/model.py:233-241): y = clamp(x, lo, hi), NaN kept. */
 int qfa_clip_f32(const float *x, float *y, size_t n, float lo, float hi, void *stream);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("QFA_HIP_LIB", os.path.join(_HERE, "libqfa_hip.so"))
 EXPORTS = (
     "qfa_abi_version", "qfa_tau_model", "qfa_workspace_bytes", "qfa_accum_floats",
     "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_adam_clip_f32",
-    "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32", "qfa_build_batch_f32", "qfa_mu_estimate_f64",
+    "qfa_adam_clip_multi_f32", "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32", "qfa_build_batch_f32", "qfa_mu_estimate_f64",
 )
 
 TAU_IDS = {"becker": 0, "fg": 1, "kamble": 2, "mock": 3}
@@ -30,6 +30,15 @@ class TauModel(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("F", "Psi", "omega", "tau0", "c0", "beta")]
+
+
+ADAM_MAX = 8
+
+
+class AdamMulti(C.Structure):       # qfa_adam_multi_t
+    _fields_ = [("p", C.c_void_p * ADAM_MAX), ("g", C.c_void_p * ADAM_MAX), ("m", C.c_void_p * ADAM_MAX),
+                ("v", C.c_void_p * ADAM_MAX), ("p_out", C.c_void_p * ADAM_MAX), ("n", C.c_size_t * ADAM_MAX),
+                ("lo", C.c_float * ADAM_MAX), ("hi", C.c_float * ADAM_MAX), ("count", C.c_int)]
 
 
 class Batch(C.Structure):
@@ -65,6 +74,7 @@ def lib():
         "qfa_predict_f32": (i, [C.POINTER(Params), p, C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i,
                                 p, p, p, p, p, p, sz, p]),
         "qfa_adam_clip_f32": (i, [p, p, p, p, p, sz, d, d, d, d, d, i, f, f, p]),
+        "qfa_adam_clip_multi_f32": (i, [C.POINTER(AdamMulti), d, d, d, d, d, i, p]),
         "qfa_clip_f32": (i, [p, p, sz, f, f, p]),
         "qfa_smooth_f32": (i, [p, p, i, i, i, p]),
         "qfa_tau_f32": (i, [p, p, sz, C.POINTER(TauModel), p]),

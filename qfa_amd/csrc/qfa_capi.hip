@@ -123,6 +123,26 @@ int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float 
     return hip_status();
 }
 
+int qfa_adam_clip_multi_f32(const qfa_adam_multi_t *t, double lr, double b1, double b2, double eps, double wd, int i,
+                            void *stream) {
+    if (!t) return QFA_E_NULL;
+    if (t->count < 0 || t->count > QFA_ADAM_MAX || i < 0) return QFA_E_SIZE;
+    AdamMultiArgs a;
+    a.t = *t;
+    unsigned nblk = 0;
+    for (int k = 0; k < t->count; ++k) {
+        if (!t->p[k] || !t->g[k] || !t->m[k] || !t->v[k] || !t->p_out[k]) return QFA_E_NULL;
+        a.blk0[k] = nblk;
+        nblk += (unsigned)((t->n[k] + 255) / 256);
+    }
+    for (int k = t->count; k <= QFA_ADAM_MAX; ++k) a.blk0[k] = nblk;
+    if (nblk == 0) return 0;
+    const float bc1 = (float)(1.0 - pow(b1, (double)(i + 1))), bc2 = (float)(1.0 - pow(b2, (double)(i + 1)));
+    k_adam_clip_multi<<<nblk, 256, 0, (hipStream_t)stream>>>(a, (float)lr, (float)b1, (float)b2, (float)(1.0 - b1),
+                                                             (float)(1.0 - b2), (float)eps, (float)wd, bc1, bc2);
+    return hip_status();
+}
+
 int qfa_clip_f32(const float *x, float *y, size_t n, float lo, float hi, void *stream) {
     if (!x || !y) return QFA_E_NULL;
     if (n == 0) return 0;

@@ -51,6 +51,31 @@ __global__ void k_adam_clip(const float *__restrict__ p, const float *__restrict
     pout[i] = q;
 }
 
+// all parameter tensors in one launch: block b works on tensor k with blk0[k] <= b < blk0[k+1]
+struct AdamMultiArgs {
+    qfa_adam_multi_t t;
+    unsigned blk0[QFA_ADAM_MAX + 1];
+};
+__global__ void k_adam_clip_multi(AdamMultiArgs a, float lr, float b1, float b2, float omb1, float omb2, float eps,
+                                  float wd, float bc1, float bc2) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < QFA_ADAM_MAX; ++j)
+        if (j < a.t.count && blockIdx.x >= a.blk0[j]) k = j;
+    const size_t i = (size_t)(blockIdx.x - a.blk0[k]) * blockDim.x + threadIdx.x;
+    if (i >= a.t.n[k]) return;
+    const float pi = a.t.p[k][i];
+    const float gi = a.t.g[k][i] + wd * pi;
+    const float mi = omb1 * gi + b1 * a.t.m[k][i];
+    const float vi = omb2 * gi * gi + b2 * a.t.v[k][i];
+    a.t.m[k][i] = mi;
+    a.t.v[k][i] = vi;
+    float q = pi - lr * (mi / bc1) / (__fsqrt_rn(vi / bc2) + eps);
+    const float lo = a.t.lo[k], hi = a.t.hi[k];
+    if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
+    a.t.p_out[k][i] = q;
+}
+
 __global__ void k_clip(const float *__restrict__ x, float *__restrict__ y, size_t n, float lo, float hi) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {

@@ -4,7 +4,7 @@
 * the bias-correction exponent and the learning-rate schedule use ``self.i``, which only
   advances in ``step()`` -- once per epoch in ``QFA.train`` (model.py:215), quirk Q4;
 * ``update`` is functional: it returns a new parameter dict and leaves its input untouched.
-The arithmetic runs in ``qfa_adam_clip_f32`` (one launch per tensor).
+The arithmetic runs in ``qfa_adam_clip_multi_f32`` (all tensors of the dict in one launch).
 """
 from __future__ import annotations
 
@@ -56,25 +56,33 @@ class Adam(object):
         (fixed addresses: what a captured hipGraph of the step needs) instead of returning new tensors."""
         h = _lib.lib()
         lr = float(self.scheduled_lr)
-        out = {}
-        for k in params:
-            p = params[k]
-            if p.dtype != f32 or not p.is_contiguous():
-                p = p.to(f32).contiguous()
-            grad = g[k]
-            if grad.dtype != f32 or not grad.is_contiguous():
-                grad = grad.to(f32).contiguous()
-            pp = _lib.require_device_tensor(p, f32, f"params[{k}]")
-            gp = _lib.require_device_tensor(grad, f32, f"g[{k}]")
-            if inplace and p is not params[k]:
-                raise ValueError(f"in-place update needs contiguous float32 params[{k}]")
-            q = p if inplace else torch.empty_like(p)
-            lo, hi = clip[k] if (clip is not None and k in clip) else (1.0, 0.0)
-            _lib.check(h.qfa_adam_clip_f32(pp, gp, C.c_void_p(self.m[k].data_ptr()), C.c_void_p(self.v[k].data_ptr()),
-                                           C.c_void_p(q.data_ptr()), p.numel(), lr, self.b1, self.b2, self.eps,
-                                           self.weight_decay, int(self.i), lo, hi, _lib.current_stream(p.device)),
-                       "qfa_adam_clip_f32")
-            out[k] = q
+        out, keep = {}, []
+        keys = list(params)
+        for c0 in range(0, len(keys), _lib.ADAM_MAX):               # one launch per (up to) 8 tensors
+            t = _lib.AdamMulti()
+            chunk = keys[c0:c0 + _lib.ADAM_MAX]
+            for j, k in enumerate(chunk):
+                p = params[k]
+                if p.dtype != f32 or not p.is_contiguous():
+                    p = p.to(f32).contiguous()
+                grad = g[k]
+                if grad.dtype != f32 or not grad.is_contiguous():
+                    grad = grad.to(f32).contiguous()
+                _lib.require_device_tensor(p, f32, f"params[{k}]")
+                _lib.require_device_tensor(grad, f32, f"g[{k}]")
+                if inplace and p is not params[k]:
+                    raise ValueError(f"in-place update needs contiguous float32 params[{k}]")
+                q = p if inplace else torch.empty_like(p)
+                lo, hi = clip[k] if (clip is not None and k in clip) else (1.0, 0.0)
+                t.p[j], t.g[j], t.m[j], t.v[j], t.p_out[j] = (p.data_ptr(), grad.data_ptr(), self.m[k].data_ptr(),
+                                                              self.v[k].data_ptr(), q.data_ptr())
+                t.n[j], t.lo[j], t.hi[j] = p.numel(), lo, hi
+                keep += [p, grad]
+                out[k] = q
+            t.count = len(chunk)
+            dev = params[chunk[0]].device
+            _lib.check(h.qfa_adam_clip_multi_f32(C.byref(t), lr, self.b1, self.b2, self.eps, self.weight_decay,
+                                                 int(self.i), _lib.current_stream(dev)), "qfa_adam_clip_multi_f32")
         return out
 
     # checkpoint support for the optimiser state (absent in the reference; SURVEY 8(f) N2)

@@ -64,8 +64,10 @@ def test_python_surface_matches_reference_names():
                  "fit", "predict"):
         assert hasattr(model.QFA, name), name
     assert list(inspect.signature(model.QFA.forward).parameters)[1:5] == ["delta", "error", "zabs", "mask"]
-    assert list(inspect.signature(model.QFA.train).parameters)[1:] == [
+    # the reference's parameters first and in its order; extensions (hipGraph replay) only behind them
+    assert list(inspect.signature(model.QFA.train).parameters)[1:9] == [
         "optimizer", "dataloader", "n_epochs", "output_dir", "save_interval", "smooth_interval", "quiet", "logger"]
+    assert inspect.signature(model.QFA.train).parameters["use_graph"].default is False
     assert model.QFAModel is model.QFA
     a = inspect.signature(optimizer.Adam.__init__)
     assert list(a.parameters)[1:] == ["params", "device", "scheduler", "learning_rate", "b1", "b2", "eps",
