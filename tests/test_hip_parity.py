@@ -394,6 +394,43 @@ def test_full_size_properties_config2(dev):
         assert abs(nll[s].item() - o) / abs(o) < TOL_NLL
 
 
+def test_full_size_properties_config3_shape(dev):
+    """BASELINE config 3 shape (N_pix = 4000, N_h = 16, masks) on 40 000 spectra (one full round of work items
+    plus a segmented remainder, both passes on the XDL pipe): additivity over a split, per-spectrum NLL independent
+    of the batch, the float64 oracle on sample spectra, gradients of a 64-spectrum sub-batch against the oracle."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    npix, nh, B = 4000, 16, 40000
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=3)
+    parts = [synthetic.make_batch_torch(p, mu, wav, nb, 20000, 20220703 + i, dev, masks=True) for i in range(2)]
+    d, e, z, mk = (torch.cat([q[j] for q in parts]) for j in range(4))
+    del parts
+    m = make_model(dev, p, mu)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    acc = m.accumulate(d, e, z, mk, nll=nll).clone()
+    h = 17003
+    nll_a = torch.empty(h, dtype=torch.float32, device=dev)
+    tot = m.accumulate(d[:h], e[:h], z[:h], mk[:h], nll=nll_a).clone()
+    tot += m.accumulate(d[h:], e[h:], z[h:], mk[h:])
+    # (full-length items vs pixel segments re-associate the float32 sums over 4000 pixels)
+    assert rel_l2(nll[:h].cpu().numpy(), nll_a.cpu().numpy()) < 3e-6
+    assert rel_l2(tot.cpu().numpy(), acc.cpu().numpy()) < 5e-5
+    assert acc[-3].item() == B and torch.isfinite(acc).all()
+    for s in (0, h - 1, h, B - 1):
+        o, _ = O.nll_and_grads_single(p, d[s].cpu().numpy(), e[s].cpu().numpy(), z[s].cpu().numpy(), mk[s].cpu().numpy())
+        assert abs(nll[s].item() - o) / abs(o) < TOL_NLL
+    sub = slice(h - 32, h + 32)
+    loss, gr = m.forward(d[sub], e[sub], z[sub], mk[sub])
+    oloss, ogr = O.forward(p, d[sub].cpu().numpy(), e[sub].cpu().numpy(), z[sub].cpu().numpy(), mk[sub].cpu().numpy())
+    assert abs(loss.item() - oloss) / abs(oloss) < TOL_NLL
+    for k in KEYS:
+        ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
+        ok = ~np.isnan(ref)
+        assert rel_l2(ours[ok], ref[ok]) < (5e-4 if k == "F" else TOL_G[k]), k
+
+
 @pytest.mark.parametrize("nh,B", [(16, 33280 + 37), (8, 65536 + 64 * 5 + 3), (20, 512 * 64 + 1)])
 def test_work_plan_full_rounds_plus_segmented_remainder(dev, nh, B):
     """More than 512 blocks of 64 spectra: the work plan mixes full-length items with a segmented remainder
