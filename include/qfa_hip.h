@@ -114,6 +114,14 @@ int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b
                     float *ll, float *hmean, float *hcov, float *cont, float *unc,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same call with stage timing for benchmarks: `events` is NULL or an array of 4 hipEvent_t (entries
+ * may be NULL) recorded on `stream` at {start, after the parameter images + pass 1 (moments),
+ * after the k x k solve (ll, hmean, hcov written), after the continuum / uncertainty writer}. */
+int qfa_predict_events_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b,
+                           const qfa_tau_t *tau, int B, int Npix, int Nb, int Nh,
+                           float *ll, float *hmean, float *hcov, float *cont, float *unc,
+                           void *workspace, size_t workspace_bytes, void *stream, void *const *events);
+
 /* Replaces Adam.update (reference QFA/optimizer.py:37-52) followed by the clamp of QFA.clip
  * (QFA/model.py:233-241) for ONE tensor of n elements:
  *   g' = g + wd*p; m = (1-b1) g' + b1 m; v = (1-b2) g'^2 + b2 v;
@@ -173,6 +181,15 @@ int qfa_build_batch_f32(const float *flux, const float *error, const double *zqs
 int qfa_mu_estimate_f64(const float *flux, const float *error, const double *zqso, const double *wav,
                         double wav0, int which, int B, int Npix, int Nb, int window_len, double *scratch,
                         double *mu_raw, double *mu_smooth, void *stream);
+
+/* The two halves of qfa_mu_estimate_f64 for a data-parallel loader (each rank holds a shard of the
+ * spectra): qfa_mu_sums_f64 ADDS this shard's per-pixel sums to scratch = [num Npix | den Npix]
+ * (caller zeroes it), the caller all-reduces scratch over the ranks, qfa_mu_finish_f64 divides and
+ * smooths.  Same arithmetic as the one-call form. */
+int qfa_mu_sums_f64(const float *flux, const float *error, const double *zqso, const double *wav,
+                    double wav0, int which, int B, int Npix, int Nb, double *scratch, void *stream);
+int qfa_mu_finish_f64(const double *scratch, int Npix, int window_len, double *mu_raw, double *mu_smooth,
+                      void *stream);
 
 /* Replace MatrixInverse / MatrixLogDet (reference QFA/utils.py:12-54) for one (n,k) M and (n,) D:
  * inv (n,n) dense, logdet scalar (Cholesky-free Gauss-Jordan on the k x k core, finite where the

@@ -71,6 +71,20 @@ def load_data(cfg, device):
                             window_length_for_mu=cfg.TRAIN.WINDOW_LENGTH_FOR_MU, mode=cfg.TYPE, paths=paths)
 
 
+def load_model_file(model, path, cfg, optimizer=None):
+    """A file written by QFA.save_checkpoint (it carries adam_* keys and the true c0) goes through load_checkpoint;
+    anything else through the reference's loader, with its c0 <- beta quirk unless MODEL.REFERENCE_C0_QUIRK is off.
+    Returns True when the optimiser state was restored too."""
+    import numpy as np
+    with np.load(path) as f:
+        full = "adam_i" in f.files
+    if full:
+        model.load_checkpoint(path, optimizer)
+        return optimizer is not None
+    model.load_from_npz(path, reference_c0_quirk=bool(cfg.MODEL.REFERENCE_C0_QUIRK))
+    return False
+
+
 def main(argv=None):
     from .config import get_config
     args = build_parser().parse_args(argv)
@@ -93,18 +107,22 @@ def main(argv=None):
         handler = logging.FileHandler(os.path.join(cfg.DATA.OUTPUT_DIR, "log.txt"))
         handler.setFormatter(logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s"))
         logger.addHandler(handler)
-        if cfg.MODEL.RESUME and os.path.exists(cfg.MODEL.RESUME):
-            print(f"=> Resume from {cfg.MODEL.RESUME}")
-            model.load_from_npz(cfg.MODEL.RESUME)
         scheduler = step_scheduler(cfg.TRAIN.DECAY_ALPHA, cfg.TRAIN.DECAY_STEP)
         optimizer = Adam(params=model.parameters, learning_rate=cfg.TRAIN.LEARNING_RATE, device=device,
                          scheduler=scheduler, weight_decay=cfg.TRAIN.WEIGHT_DECAY)
-        model.random_init_func()                              # as main.py:84 (also after a resume)
+        full_state = False
+        if cfg.MODEL.RESUME and os.path.exists(cfg.MODEL.RESUME):
+            print(f"=> Resume from {cfg.MODEL.RESUME}")
+            full_state = load_model_file(model, cfg.MODEL.RESUME, cfg, optimizer)
+        if not full_state:
+            # as main.py:83: the reference re-randomises even after a resume (quirk Q8); a checkpoint of this
+            # package that carries the Adam state (QFA.save_checkpoint) continues instead
+            model.random_init_func()
         model.train(optimizer, dataloader, cfg.TRAIN.NEPOCHS, cfg.DATA.OUTPUT_DIR, logger=logger)
     else:
         print(f"try to predict {len(dataloader)} spectra...")
         print(f"=> Resume from {cfg.MODEL.RESUME}")
-        model.load_from_npz(cfg.MODEL.RESUME)                 # parameters and mu of the trained model
+        load_model_file(model, cfg.MODEL.RESUME, cfg)         # parameters and mu of the trained model
         ts = time.time()
         model.predict_to_npz(dataloader, os.path.join(cfg.DATA.OUTPUT_DIR, "predict"))
         print(f"Finish predicting {len(dataloader)} spectra in {time.time() - ts} seconds...")

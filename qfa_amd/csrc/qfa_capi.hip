@@ -97,6 +97,13 @@ int qfa_finalize_grads_f32(const float *accum, const float *F, int Npix, int Nb,
 int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b, const qfa_tau_t *tau, int B,
                     int Npix, int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc,
                     void *workspace, size_t workspace_bytes, void *stream) {
+    return qfa_predict_events_f32(p, mu, b, tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, workspace, workspace_bytes,
+                                  stream, nullptr);
+}
+
+int qfa_predict_events_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b, const qfa_tau_t *tau, int B,
+                           int Npix, int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc,
+                           void *workspace, size_t workspace_bytes, void *stream, void *const *events) {
     if (!p || !b || !tau || !mu || !ll || !hmean || !hcov || !cont || !unc || !workspace) return QFA_E_NULL;
     if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
     if (!b->delta || !b->error || !b->mask || (Nb > 0 && !b->zabs)) return QFA_E_NULL;
@@ -104,15 +111,15 @@ int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b
     if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (kp_for(Nh) == 8) return run_predict<8>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st);
-    if (kp_for(Nh) == 16) return run_predict<16>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st);
-    return qfa_k32_predict(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st);
+    if (kp_for(Nh) == 8) return run_predict<8>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events);
+    if (kp_for(Nh) == 16) return run_predict<16>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events);
+    return qfa_k32_predict(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events);
 }
 
 int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float *p_out, size_t n, double lr, double b1,
                       double b2, double eps, double wd, int i, float lo, float hi, void *stream) {
-    if (!p || !g || !m || !v || !p_out) return QFA_E_NULL;
     if (n == 0) return 0;
+    if (!p || !g || !m || !v || !p_out) return QFA_E_NULL;
     if (i < 0) return QFA_E_SIZE;
     // The reference mixes Python floats (double) with float32 tensors: every scalar below is
     // formed in double and rounded to float32 once, exactly where torch would round it.
@@ -131,7 +138,8 @@ int qfa_adam_clip_multi_f32(const qfa_adam_multi_t *t, double lr, double b1, dou
     a.t = *t;
     unsigned nblk = 0;
     for (int k = 0; k < t->count; ++k) {
-        if (!t->p[k] || !t->g[k] || !t->m[k] || !t->v[k] || !t->p_out[k]) return QFA_E_NULL;
+        // an empty tensor (omega of a model without blue pixels) is a no-op, whatever its pointers are
+        if (t->n[k] != 0 && (!t->p[k] || !t->g[k] || !t->m[k] || !t->v[k] || !t->p_out[k])) return QFA_E_NULL;
         a.blk0[k] = nblk;
         nblk += (unsigned)((t->n[k] + 255) / 256);
     }
@@ -144,13 +152,14 @@ int qfa_adam_clip_multi_f32(const qfa_adam_multi_t *t, double lr, double b1, dou
 }
 
 int qfa_clip_f32(const float *x, float *y, size_t n, float lo, float hi, void *stream) {
+    if (n == 0) return 0;                      // empty tensors (N_b = 0) carry NULL data pointers
     if (!x || !y) return QFA_E_NULL;
-    if (n == 0) return 0;
     k_clip<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, lo, hi);
     return hip_status();
 }
 
 int qfa_smooth_f32(const float *x, float *y, int n, int cols, int half, void *stream) {
+    if (n == 0) return 0;                      // empty tensors (N_b = 0) carry NULL data pointers
     if (!x || !y) return QFA_E_NULL;
     if (n < 1 || cols < 1 || half < 0) return QFA_E_SIZE;
     const size_t tot = (size_t)n * cols;
@@ -225,6 +234,27 @@ int qfa_mu_estimate_f64(const float *flux, const float *error, const double *zqs
     const dim3 grid((Npix + 255) / 256, (B + chunk - 1) / chunk);
     k_mu_accumulate<<<grid, 256, 0, st>>>(flux, error, zqso, wav, tab, B, Npix, Nb, chunk, scratch, scratch + Npix);
     k_mu_finish<<<(Npix + 255) / 256, 256, 0, st>>>(scratch, scratch + Npix, Npix, window_len, mu_raw, mu_smooth);
+    return hip_status();
+}
+
+int qfa_mu_sums_f64(const float *flux, const float *error, const double *zqso, const double *wav, double wav0, int which,
+                    int B, int Npix, int Nb, double *scratch, void *stream) {
+    if (!flux || !error || !zqso || !wav || !scratch) return QFA_E_NULL;
+    if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix) return QFA_E_SIZE;
+    LymanTable tab;
+    if (int e = fill_lyman(which, wav0, &tab)) return e;
+    const int chunk = 64;
+    const dim3 grid((Npix + 255) / 256, (B + chunk - 1) / chunk);
+    k_mu_accumulate<<<grid, 256, 0, (hipStream_t)stream>>>(flux, error, zqso, wav, tab, B, Npix, Nb, chunk, scratch,
+                                                           scratch + Npix);
+    return hip_status();
+}
+
+int qfa_mu_finish_f64(const double *scratch, int Npix, int window_len, double *mu_raw, double *mu_smooth, void *stream) {
+    if (!scratch || !mu_raw) return QFA_E_NULL;
+    if (Npix < 1 || window_len < 2 || window_len > Npix) return QFA_E_SIZE;
+    k_mu_finish<<<(Npix + 255) / 256, 256, 0, (hipStream_t)stream>>>(scratch, scratch + Npix, Npix, window_len, mu_raw,
+                                                                  mu_smooth);
     return hip_status();
 }
 

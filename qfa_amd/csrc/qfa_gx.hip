@@ -1,0 +1,16 @@
+// qfa_gx.hip -- pass 2 on the XDL pipe (qfa_grads_x.h) in its own translation unit: the kernel is large and
+// is iterated on separately from the rest of the library.
+#include "qfa_grads_x.h"
+
+#include "qfa_host.h"
+
+size_t qfa_gx_image_bytes(int ntiles32) { return (size_t)ntiles32 * GX::TILE_B; }
+
+void qfa_gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, hipStream_t st) {
+    k_prep_pgx<<<ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, PGX);
+    if (b.A_blue)
+        k_grads_x<true><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum);
+    else
+        k_grads_x<false><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum);
+}

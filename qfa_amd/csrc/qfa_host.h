@@ -8,6 +8,11 @@
 #include "qfa_step_kernels.h"
 #include "qfa_xdl_kernels.h"
 
+// pass 2 for N_h in 9..16 with every contraction on the XDL pipe (qfa_grads_x.h, built in qfa_gx.hip)
+size_t qfa_gx_image_bytes(int ntiles32);
+void qfa_gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, hipStream_t st);
+
 namespace {
 
 inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
@@ -19,8 +24,8 @@ inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
 // tiles per item while the chip stays at most half full (the step of a small batch is latency-bound).
 constexpr int kMaxSeg = 32;
 
-inline WorkPlan plan_work(int B, int ntiles, int pro) {
-    const int slots = 256 * 2;                      // CUs x resident 256-thread workgroups per CU
+inline WorkPlan plan_work(int B, int ntiles, int pro, int slots = 256 * 2) {
+    // slots = CUs x resident workgroups per CU (2 for the 256-thread kernels, 1 for the 512-thread k_grads_x)
     const int nblk = (B + 63) / 64;
     WorkPlan best{0, nblk, 1, ntiles};
     double best_cost = 1e300;
@@ -49,7 +54,8 @@ struct Layout {
     int KP, NpixPad, ntiles, Bpad;
     int ntiles32;                                      // pass 1 on the XDL pipe walks 32-pixel tiles (N_h <= 16)
     WorkPlan wp1, wp2;                                 // work items of pass 1 / pass 2
-    size_t oPF, oPFT, oPFX, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
+    WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
+    size_t oPF, oPFT, oPFX, oPGX, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
 };
 
 template <int KP>
@@ -69,6 +75,12 @@ Layout make_layout_t(int B, int Npix) {
     L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
     L.oPFX = 0;
     if constexpr (KP <= 16) L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4));
+    L.oPGX = 0;
+    L.wp2x = WorkPlan{0, 0, 1, 0};
+    if constexpr (KP == 16) {
+        L.oPGX = take(qfa_gx_image_bytes(L.ntiles32) / 4);
+        L.wp2x = plan_work(B, L.ntiles32, 3, 256);
+    }
     // moment records: segment 0 for every row, segments 1.. for the rows of the segmented blocks only
     L.oMOM = take(((size_t)L.Bpad + (size_t)(L.wp1.nseg - 1) * (L.Bpad - 64 * (size_t)L.wp1.full)) * C::NMOM);
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
@@ -90,6 +102,13 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
     if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || Nh < 1 || Nh > 32) return QFA_E_SIZE;
     if ((long long)64 * Npix >= (1LL << 31)) return QFA_E_SIZE;      // 32-bit byte offsets inside a wave's 16 rows
     return 0;
+}
+
+// QFA_PASS2_F32=1 in the environment selects the float32-MFMA form of pass 2 at N_h = 9..16 too (A/B timing and the
+// cross-check of the two forms in tests/); read at every call, nothing is cached
+inline bool pass2_f32_forced() {
+    const char *e = std::getenv("QFA_PASS2_F32");
+    return e && e[0] == '1';
 }
 
 inline int hip_status() {
@@ -156,6 +175,14 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr);
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
     mark(3);
+    bool pass2_xdl = false;
+    if constexpr (KP == 16) pass2_xdl = !pass2_f32_forced();
+    if (pass2_xdl) {
+        qfa_gx_launch(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
+                      accum, st);
+        mark(4);
+        return hip_status();
+    }
     for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
         if (16 * bh >= Nh) break;
         if (b.A_blue)
@@ -170,15 +197,22 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
 template <int KP>
 int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
                 int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
-                hipStream_t st) {
+                hipStream_t st, void *const *events) {
     const Layout L = make_layout_t<KP>(B, Npix);
     float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL;
+    auto mark = [&](int i) {
+        if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
+    };
+    mark(0);
     launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
     launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, ws, st);
+    mark(1);
     sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
     k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, ll, nullptr, B, Nh, hmean, hcov);
+    mark(2);
     k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);
+    mark(3);
     return hip_status();
 }
 
@@ -190,4 +224,4 @@ int qfa_k32_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_
                      float *nll, float *accum, float *ws, hipStream_t st, void *const *events);
 int qfa_k32_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
                     int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
-                    hipStream_t st);
+                    hipStream_t st, void *const *events);

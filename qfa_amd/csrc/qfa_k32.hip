@@ -9,6 +9,6 @@ int qfa_k32_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_
 
 int qfa_k32_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
                     int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
-                    hipStream_t st) {
-    return run_predict<32>(p, mu, b, tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st);
+                    hipStream_t st, void *const *events) {
+    return run_predict<32>(p, mu, b, tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events);
 }

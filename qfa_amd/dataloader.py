@@ -9,6 +9,12 @@ in HBM, and what the reference computes on the host with numpy for every batch -
 the smoothed mean continuum ``mu`` -- runs in HIP kernels (``qfa_build_batch_f32``,
 ``qfa_mu_estimate_f64``).  Reading spectra from disk and the catalogue selection (row N3) are host code in ``qfa_amd.io``
 (``from_files`` / ``from_catalog`` below).
+
+Data parallelism (no counterpart in the reference): ``DeviceDataloader(..., rank=r, world=w,
+seed=s)`` keeps only rank r's contiguous shard of the spectra in HBM, draws the epoch order from
+``qfa_amd.distributed.ShardPlan`` (shared seed, disjoint shards, the SAME number of steps on every rank -- an
+exhausted rank returns empty batches, which ``QFA.forward`` turns into zeros for the all-reduce) and estimates
+``mu`` from the all-reduced per-pixel sums, so every rank trains against the same mean continuum.
 """
 from __future__ import annotations
 
@@ -26,7 +32,11 @@ LYA = 1215.67
 class DeviceDataloader(object):
 
     def __init__(self, flux, error, zqso, wav_grid, batch_size, device, tau="becker", window_length_for_mu=16,
-                 shuffle=True, mode="train", paths=None):
+                 shuffle=True, mode="train", paths=None, rank=0, world=1, seed=0, group=None, sharded_input=False,
+                 global_size=None):
+        """``rank`` / ``world`` / ``seed`` / ``group``: data parallelism (see the module docstring).  By default the
+        arrays hold ALL spectra and the loader keeps rows ``shard_bounds(N, rank, world)``; with
+        ``sharded_input=True`` they already are this rank's shard of ``global_size`` spectra."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.QFAHipError("DeviceDataloader needs a HIP device (torch device 'cuda')")
@@ -40,18 +50,41 @@ class DeviceDataloader(object):
         self.type = mode
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
-        self.flux = torch.as_tensor(np.asarray(flux, dtype=np.float32), device=self.device).contiguous()
-        self.error = torch.as_tensor(np.asarray(error, dtype=np.float32), device=self.device).contiguous()
-        if tuple(self.flux.shape) != tuple(self.error.shape) or self.flux.shape[1] != self.Npix:
-            raise _lib.QFAHipError("flux / error must be (N, len(wav_grid))")
-        self.zqso = np.asarray(zqso, dtype=np.float64).reshape(-1)
-        self.data_size = int(self.flux.shape[0])
-        self.pathlist = np.asarray(paths) if paths is not None else np.arange(self.data_size)
+        from .distributed import ShardPlan, shard_bounds
+        self.rank, self.world, self.group = int(rank), int(world), group
+        flux, error = np.asarray(flux, dtype=np.float32), np.asarray(error, dtype=np.float32)
+        zqso = np.asarray(zqso, dtype=np.float64).reshape(-1)
+        if flux.shape != error.shape or flux.ndim != 2 or flux.shape[1] != self.Npix or len(zqso) != flux.shape[0]:
+            raise _lib.QFAHipError("flux / error must be (N, len(wav_grid)) and zqso (N,)")
+        paths = np.asarray(paths) if paths is not None else None
+        if self.world > 1 and sharded_input:
+            if global_size is None:
+                raise ValueError("sharded_input=True needs global_size (the number of spectra over all ranks)")
+            n_global = int(global_size)
+            lo, hi = shard_bounds(n_global, self.rank, self.world)
+            if hi - lo != flux.shape[0]:
+                raise ValueError(f"rank {rank} must hold rows [{lo}, {hi}) of the data set, got {flux.shape[0]} rows")
+        else:
+            n_global = int(flux.shape[0])
+            lo, hi = shard_bounds(n_global, self.rank, self.world)
+            flux, error, zqso = flux[lo:hi], error[lo:hi], zqso[lo:hi]
+            paths = paths[lo:hi] if paths is not None else None
+        self._row0 = lo                                         # global index of the first resident row
+        self.flux = torch.as_tensor(flux, device=self.device).contiguous()
+        self.error = torch.as_tensor(error, device=self.device).contiguous()
+        self.zqso = zqso
+        self.data_size = n_global                               # what QFA.train divides by (model.py:205)
+        self.local_size = int(self.flux.shape[0])
+        self.pathlist = paths if paths is not None else np.arange(lo, hi)
         self._zq_dev = torch.as_tensor(self.zqso, device=self.device)
         self._wav_dev = torch.as_tensor(self.wav_grid, device=self.device)
-        self._order = np.arange(self.data_size)
+        self._plan = ShardPlan(n_global, self.batch_size, self.rank, self.world, seed, shuffle) if self.world > 1 else None
+        self._epoch = -1
+        self._steps = None                                      # DP: list of local row arrays of the current epoch
+        self._order = np.arange(self.local_size)
         self.cur = 0
-        self._mu_raw, self._mu = self._estimate_mu(int(window_length_for_mu))
+        self._window = int(window_length_for_mu)
+        self._mu_raw, self._mu = self._estimate_mu(self._window)
         self._mu_dev = torch.as_tensor(self._mu, device=self.device)
 
     # ------------------------------------------------------------------ from disk (row N3)
@@ -59,6 +92,13 @@ class DeviceDataloader(object):
     def from_files(cls, paths, wav_grid, batch_size, device, nprocs=1, **kw):
         """spectra read from per-spectrum .npz files (reference QFA/dataloader.py:18-45,84-88)"""
         from . import io
+        world, rank = int(kw.get("world", 1)), int(kw.get("rank", 0))
+        if world > 1:                                          # every rank reads its own shard of the files only
+            from .distributed import shard_bounds
+            paths = list(paths)
+            lo, hi = shard_bounds(len(paths), rank, world)
+            kw.update(sharded_input=True, global_size=len(paths))
+            paths = paths[lo:hi]
         flux, error, zqso, plist = io.read_spectra(paths, nprocs)
         return cls(flux, error, zqso, wav_grid, batch_size, device, paths=plist, **kw)
 
@@ -73,14 +113,22 @@ class DeviceDataloader(object):
 
     # ------------------------------------------------------------------ mu
     def _estimate_mu(self, window):
-        scratch = torch.empty(2 * self.Npix, dtype=torch.float64, device=self.device)
+        """reference QFA/dataloader.py:109-111; under data parallelism the per-pixel sums of the shards are
+        all-reduced between the two halves (qfa_mu_sums_f64 / qfa_mu_finish_f64)."""
+        h, st = _lib.lib(), _lib.current_stream(self.device)
+        scratch = torch.zeros(2 * self.Npix, dtype=torch.float64, device=self.device)
         raw = torch.empty(self.Npix, dtype=torch.float64, device=self.device)
         sm = torch.empty(self.Npix, dtype=torch.float64, device=self.device)
-        _lib.check(_lib.lib().qfa_mu_estimate_f64(
-            C.c_void_p(self.flux.data_ptr()), C.c_void_p(self.error.data_ptr()), C.c_void_p(self._zq_dev.data_ptr()),
-            C.c_void_p(self._wav_dev.data_ptr()), float(self.wav_grid[0]), self._which, self.data_size, self.Npix,
-            self.Nb, window, C.c_void_p(scratch.data_ptr()), C.c_void_p(raw.data_ptr()), C.c_void_p(sm.data_ptr()),
-            _lib.current_stream(self.device)), "qfa_mu_estimate_f64")
+        if self.local_size > 0:
+            _lib.check(h.qfa_mu_sums_f64(
+                C.c_void_p(self.flux.data_ptr()), C.c_void_p(self.error.data_ptr()), C.c_void_p(self._zq_dev.data_ptr()),
+                C.c_void_p(self._wav_dev.data_ptr()), float(self.wav_grid[0]), self._which, self.local_size, self.Npix,
+                self.Nb, C.c_void_p(scratch.data_ptr()), st), "qfa_mu_sums_f64")
+        if self.world > 1:
+            from .distributed import all_reduce_
+            all_reduce_(scratch, self.group)
+        _lib.check(h.qfa_mu_finish_f64(C.c_void_p(scratch.data_ptr()), self.Npix, window, C.c_void_p(raw.data_ptr()),
+                                       C.c_void_p(sm.data_ptr()), st), "qfa_mu_finish_f64")
         return raw.cpu().numpy(), sm.cpu().numpy()
 
     @property
@@ -89,7 +137,13 @@ class DeviceDataloader(object):
 
     # ------------------------------------------------------------------ batches
     def _build(self, rows, out=None):
+        """rows: LOCAL row indices (into this rank's resident spectra)"""
         n = len(rows)
+        if n == 0:                                            # an exhausted rank's step under data parallelism
+            return (torch.empty((0, self.Npix), dtype=f32, device=self.device),
+                    torch.empty((0, self.Npix), dtype=f32, device=self.device),
+                    torch.empty((0, self.Nb), dtype=f32, device=self.device),
+                    torch.empty((0, self.Npix), dtype=torch.bool, device=self.device))
         idx = torch.as_tensor(np.asarray(rows, dtype=np.int32), device=self.device)
         if out is not None:                                   # caller-owned buffers (a captured step graph reads them)
             delta, err, zabs, mask = out
@@ -109,28 +163,72 @@ class DeviceDataloader(object):
         return delta, err, zabs, mask
 
     def have_next_batch(self):
-        return self.cur < self.data_size
+        if self._plan is not None:
+            if self._steps is None:
+                self.rewind()
+            return self.cur < len(self._steps)
+        return self.cur < self.local_size
 
     def next_batch(self, out=None):
         """delta, error, zabs, mask of the next batch (reference QFA/dataloader.py:124-138); ``out`` = four
-        caller-owned tensors of the batch's shape to build into."""
+        caller-owned tensors of the batch's shape to build into.  Under data parallelism: this rank's part of the
+        global batch (possibly empty)."""
+        if self._plan is not None:
+            if self._steps is None:
+                self.rewind()
+            rows = self._steps[self.cur]
+            self.cur += 1
+            return self._build(rows, out)
         start = self.cur
-        end = min(self.cur + self.batch_size, self.data_size)
+        end = min(self.cur + self.batch_size, self.local_size)
         self.cur = end
         return self._build(self._order[start:end], out)
 
     def next_batch_size(self):
-        return min(self.cur + self.batch_size, self.data_size) - self.cur
+        if self._plan is not None:
+            return len(self._steps[self.cur]) if self._steps is not None and self.cur < len(self._steps) else 0
+        return min(self.cur + self.batch_size, self.local_size) - self.cur
 
     def rewind(self):
         """shuffle and reset (reference QFA/dataloader.py:154-167); only the row order is permuted,
-        the spectra stay where they are in HBM."""
-        if self.shuffle:
+        the spectra stay where they are in HBM.  Data parallel: the next epoch of the shard plan."""
+        if self._plan is not None:
+            self._epoch += 1
+            self._steps = [r - self._row0 for r in self._plan.epoch_rows(self._epoch)]
+        elif self.shuffle:
             np.random.shuffle(self._order)
         self.cur = 0
 
+    def sample(self):
+        """a random batch with replacement (reference QFA/dataloader.py:140-152; the reference's version cannot run:
+        it asks for ``torch.tensor32``, quirk Q9)"""
+        return self._build(np.random.randint(0, self.local_size, size=(self.batch_size,)))
+
+    def set_device(self, device):
+        """reference QFA/dataloader.py:175-179.  The spectra already live on the device given to the constructor;
+        any other device is refused (there is no host path)."""
+        if torch.device(device) != self.device and torch.device(device).index is not None:
+            raise _lib.QFAHipError(f"DeviceDataloader is resident on {self.device}; cannot serve {device}")
+
+    def set_tau(self, tau):
+        """reference QFA/dataloader.py:169-173: choose the mean optical depth (a built-in name, or
+        ``functools.partial(qfa_amd.utils.tau, which=...)``); mu is re-estimated with it."""
+        which = tau if isinstance(tau, str) else dict(getattr(tau, "keywords", None) or {}).get("which")
+        if which not in _lib.TAU_IDS:
+            raise NotImplementedError("currently available mean optical depth function: ['becker', 'fg', 'kamble']")
+        self._which = _lib.TAU_IDS[which]
+        self._mu_raw, self._mu = self._estimate_mu(self._window)
+        self._mu_dev = torch.as_tensor(self._mu, device=self.device)
+
     def __len__(self):
-        return self.data_size
+        return self.local_size
+
+    def get_rows(self, lo, hi):
+        """raw flux, error, zabs, mask, paths of the resident rows [lo, hi) in ONE launch -- what ``__getitem__``
+        returns per spectrum, for a whole slice (the batched predict writer)."""
+        rows = np.arange(int(lo), min(int(hi), self.local_size))
+        _, err, zabs, mask = self._build(rows)
+        return self.flux[rows[0]:rows[-1] + 1], err, zabs, mask, self.pathlist[rows]
 
     def __getitem__(self, i):
         """raw flux (not delta), error, zabs, mask, path of spectrum i (reference dataloader.py:184-187)."""

@@ -71,3 +71,79 @@ def all_reduce_accum(acc, group=None):
     else:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     return acc
+
+
+def _via_host(t, group):
+    import torch.distributed as dist
+    return dist.get_backend(group) == "gloo" and t.device.type != "cpu"
+
+
+def broadcast_(t, src=0, group=None):
+    """In-place broadcast of one tensor from rank ``src`` (host staging under Gloo, as above)."""
+    import torch.distributed as dist
+    if _via_host(t, group):
+        host = t.cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def all_reduce_(t, group=None):
+    """In-place sum of an arbitrary tensor (the mu estimator's float64 per-pixel sums)."""
+    return all_reduce_accum(t, group)
+
+
+def replicas_in_sync(tensors, group=None):
+    """True when every rank holds bit-identical copies of ``tensors`` (a list).  Each rank reduces its copy to
+    four float64 moments; max - min of those over the ranks must be exactly zero."""
+    import torch
+    import torch.distributed as dist
+    sig = []
+    for t in tensors:
+        x = t.detach().double().reshape(-1)
+        w = torch.arange(1, x.numel() + 1, dtype=torch.float64, device=x.device)
+        sig += [x.sum(), (x * x).sum(), (x * w).sum(), torch.nan_to_num(x).abs().max() if x.numel() else x.sum()]
+    s = torch.stack(sig) if sig else torch.zeros(1, dtype=torch.float64)
+    s = torch.nan_to_num(s, nan=12345.678)
+    if _via_host(s, group):
+        s = s.cpu()
+    hi, lo = s.clone(), s.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    return bool((hi == lo).all())
+
+
+class ShardPlan(object):
+    """Which rows a rank feeds into each step of an epoch under data parallelism.
+
+    The reference's loop (QFA/model.py:204-215, QFA/dataloader.py:124-138,154-167) shuffles the whole data set
+    and walks it in batches of ``batch_size``.  Here rank r owns the contiguous shard ``shard_bounds(n, r, world)``
+    of the spectra (they stay where they are in that GPU's HBM); an epoch shuffles every shard with a generator
+    seeded by (seed, epoch, rank) -- the same call on every rank yields the same plan, so any rank can recompute
+    any other's -- and step i of the epoch takes rows ``[i*local, (i+1)*local)`` of the shuffled shard, with
+    ``local = ceil(batch_size / world)``.  EVERY rank runs ``steps = ceil(max_shard / local)`` steps; a rank whose
+    shard is exhausted contributes an empty batch (zeros to the all-reduce), so the collective never deadlocks on
+    an uneven tail.  The union of the ranks' step-i rows is the global batch of step i (about ``batch_size`` rows).
+    """
+
+    def __init__(self, n: int, batch_size: int, rank: int = 0, world: int = 1, seed: int = 0, shuffle: bool = True):
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError("need 0 <= rank < world")
+        self.n, self.batch_size, self.rank, self.world = int(n), int(batch_size), int(rank), int(world)
+        self.seed, self.shuffle = int(seed), bool(shuffle)
+        self.lo, self.hi = shard_bounds(self.n, self.rank, self.world)
+        self.local = -(-self.batch_size // self.world)
+        max_shard = -(-self.n // self.world)
+        self.steps = -(-max_shard // self.local) if self.n > 0 else 0
+
+    def epoch_rows(self, epoch: int, rank=None):
+        """list (one entry per step, possibly empty arrays) of GLOBAL row indices for ``rank`` (default: own)"""
+        import numpy as np
+        r = self.rank if rank is None else int(rank)
+        lo, hi = shard_bounds(self.n, r, self.world)
+        rows = np.arange(lo, hi)
+        if self.shuffle:
+            np.random.default_rng([self.seed, int(epoch), r]).shuffle(rows)
+        return [rows[i * self.local:(i + 1) * self.local] for i in range(self.steps)]

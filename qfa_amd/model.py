@@ -78,6 +78,7 @@ class QFA(object):
         self._ws = {}
         self._dp_group = None
         self._dp = False
+        self._dp_checked = False
 
     # ------------------------------------------------------------------ parameters
     def random_init_func(self) -> None:
@@ -88,6 +89,8 @@ class QFA(object):
         self.tau0 = torch.tensor(0.02, dtype=f32, device=self.device)
         self.c0 = torch.tensor(0.3, dtype=f32, device=self.device)
         self.beta = torch.tensor(2., dtype=f32, device=self.device)
+        if getattr(self, "_dp", False):                 # every process drew its own F: rank 0's wins
+            self.sync_replicas()
 
     @property
     def parameters(self):
@@ -109,6 +112,8 @@ class QFA(object):
         st = _lib.current_stream(self.device)
         for k, (lo, hi) in self._clip_table().items():
             x = getattr(self, k).to(f32).contiguous()
+            if x.numel() == 0:                          # omega of a model without blue pixels
+                continue
             y = torch.empty_like(x)
             _lib.check(h.qfa_clip_f32(_lib.require_device_tensor(x, f32, k), C.c_void_p(y.data_ptr()), x.numel(),
                                       lo, hi, st), "qfa_clip_f32")
@@ -120,6 +125,8 @@ class QFA(object):
         st = _lib.current_stream(self.device)
         for k, half in (("omega", 7), ("Psi", 7), ("F", 15)):
             x = getattr(self, k).to(f32).contiguous()
+            if x.numel() == 0:
+                continue
             y = torch.empty_like(x)
             n = x.shape[0]
             cols = x.numel() // max(n, 1)
@@ -188,14 +195,50 @@ class QFA(object):
         return B
 
     # ------------------------------------------------------------------ data parallel
-    def enable_data_parallel(self, group=None):
+    def enable_data_parallel(self, group=None, optimizer=None, sync=True):
         """Shard spectra across ranks: every rank calls forward/step on its own shard; the packed
-        [sums | counts | sum NLL | B] buffer is all-reduced (RCCL) before sum/count."""
+        [sums | counts | sum NLL | B] buffer is all-reduced (RCCL) before sum/count.
+        Parameters (and the Adam state of ``optimizer``) are replicated: ``sync`` broadcasts rank 0's copy, because
+        gF = F_local * sumA_global - accF_global silently trains garbage once the replicas differ (each process
+        draws its own random F, or resumes from its own file)."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self._dp = True
         self._dp_group = group
+        self._dp_checked = False
+        if sync:
+            self.sync_replicas(optimizer)
+
+    def _replica_tensors(self, optimizer=None):
+        ts = [getattr(self, k) for k in PARAM_KEYS]
+        if self.mu is not None:
+            ts.append(self.mu)
+        if optimizer is not None:
+            ts += [optimizer.m[k] for k in PARAM_KEYS] + [optimizer.v[k] for k in PARAM_KEYS]
+        return ts
+
+    def sync_replicas(self, optimizer=None, src=0):
+        """Broadcast parameters, mu and (optionally) the Adam moments and epoch index from rank ``src``."""
+        from .distributed import broadcast_
+        self._params_struct()                           # contiguous float32 tensors on the device
+        for t in self._replica_tensors(optimizer):
+            if t.numel():
+                broadcast_(t, src, self._dp_group)
+        if optimizer is not None:
+            i = torch.tensor([int(optimizer.i)], dtype=torch.int64, device=self.device)
+            broadcast_(i, src, self._dp_group)
+            optimizer.i = int(i.item())
+        self._dp_checked = False
+
+    def check_replicas(self, optimizer=None):
+        """Raise unless every rank holds bit-identical parameters (and Adam state): a collective, call it on all ranks."""
+        from .distributed import replicas_in_sync
+        ts = [t for t in self._replica_tensors(optimizer) if t.numel()]
+        if not replicas_in_sync(ts, self._dp_group):
+            raise _lib.QFAHipError("data-parallel replicas differ (parameters / mu / Adam state): call "
+                                   "sync_replicas(optimizer) after random_init_func / load_* on every rank")
+        self._dp_checked = True
 
     def accumulate(self, delta, error, zabs, mask, accum=None, nll=None, events=None):
         """Raw sums of one (shard of a) batch into the packed buffer; no normalisation.
@@ -235,7 +278,12 @@ class QFA(object):
     def forward(self, delta: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor,
                 events=None):
         """Batch loss (1,1) and count-normalised gradient dict (reference QFA/model.py:74-105)."""
-        acc = self.accumulate(delta, error, zabs, mask, events=events)
+        if delta.shape[0] == 0:
+            if not self._dp:
+                raise _lib.QFAHipError("forward: empty batch")
+            acc = self._accum()                         # an exhausted rank adds zeros to the global sums and counts
+        else:
+            acc = self.accumulate(delta, error, zabs, mask, events=events)
         if self._dp:
             from .distributed import all_reduce_accum
             all_reduce_accum(acc, self._dp_group)
@@ -247,9 +295,12 @@ class QFA(object):
         acc = self.accumulate(delta[None, :], error[None, :], zabs[None, :], mask[None, :])
         return self._finalize(acc, False)
 
-    def predict(self, flux: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor):
+    def predict(self, flux: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor, events=None,
+                out=None):
         """Batched posterior prediction: ll (B,), hmean (B,Nh), hcov (B,Nh,Nh), cont (B,Npix),
-        unc (B,Npix) (reference QFA/model.py:160-180 applied to every row)."""
+        unc (B,Npix) (reference QFA/model.py:160-180 applied to every row).  ``events``: optional list of 4 recorded
+        torch.cuda.Event(enable_timing=True), re-recorded at {start, images + pass 1, solve, continuum writer};
+        ``out``: the five output tensors to write into (bench.py re-uses them)."""
         if self.mu is None:
             raise _lib.QFAHipError("predict needs model.mu (load_from_npz or train first)")
         B = self._check_batch_shapes(flux, error, zabs, mask)
@@ -258,16 +309,27 @@ class QFA(object):
         mu = self.mu.to(device=self.device, dtype=f32).contiguous()
         ws = self._workspace(B)
         dev = self.device
-        ll = torch.empty((B,), dtype=f32, device=dev)
-        hmean = torch.empty((B, self.Nh), dtype=f32, device=dev)
-        hcov = torch.empty((B, self.Nh, self.Nh), dtype=f32, device=dev)
-        cont = torch.empty((B, self.Npix), dtype=f32, device=dev)
-        unc = torch.empty((B, self.Npix), dtype=f32, device=dev)
-        _lib.check(_lib.lib().qfa_predict_f32(
+        if out is not None:
+            ll, hmean, hcov, cont, unc = out
+            for t, shp in ((ll, (B,)), (hmean, (B, self.Nh)), (hcov, (B, self.Nh, self.Nh)), (cont, (B, self.Npix)),
+                           (unc, (B, self.Npix))):
+                if tuple(t.shape) != shp:
+                    raise _lib.QFAHipError(f"predict(out=...): expected shape {shp}, got {tuple(t.shape)}")
+                _lib.require_device_tensor(t, f32, "out")
+        else:
+            ll = torch.empty((B,), dtype=f32, device=dev)
+            hmean = torch.empty((B, self.Nh), dtype=f32, device=dev)
+            hcov = torch.empty((B, self.Nh, self.Nh), dtype=f32, device=dev)
+            cont = torch.empty((B, self.Npix), dtype=f32, device=dev)
+            unc = torch.empty((B, self.Npix), dtype=f32, device=dev)
+        evs = None
+        if events is not None:
+            evs = (C.c_void_p * 4)(*[C.c_void_p(e.cuda_event) for e in events])
+        _lib.check(_lib.lib().qfa_predict_events_f32(
             C.byref(ps), C.c_void_p(mu.data_ptr()), C.byref(bs), C.byref(self._tau_model), B, self.Npix, self.Nb,
             self.Nh, C.c_void_p(ll.data_ptr()), C.c_void_p(hmean.data_ptr()), C.c_void_p(hcov.data_ptr()),
             C.c_void_p(cont.data_ptr()), C.c_void_p(unc.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
-            _lib.current_stream(dev)), "qfa_predict_f32")
+            _lib.current_stream(dev), evs), "qfa_predict_f32")
         return ll, hmean, hcov, cont, unc
 
     def predict_to_npz(self, dataloader, output_dir, batch_size=4096):
@@ -278,11 +340,15 @@ class QFA(object):
         n = len(dataloader)
         written = []
         for s in range(0, n, batch_size):
-            items = [dataloader[i] for i in range(s, min(s + batch_size, n))]
-            f, e, z, m = (torch.stack([it[j] for it in items]) for j in range(4))
+            if hasattr(dataloader, "get_rows"):                  # one launch for the whole slice
+                f, e, z, m, paths = dataloader.get_rows(s, min(s + batch_size, n))
+            else:                                                # the reference's per-spectrum contract
+                items = [dataloader[i] for i in range(s, min(s + batch_size, n))]
+                f, e, z, m = (torch.stack([it[j] for it in items]) for j in range(4))
+                paths = [it[4] for it in items]
             ll, hmean, hcov, cont, unc = (x.cpu().numpy() for x in self.predict(f, e, z, m))
-            for r, it in enumerate(items):
-                name = os.path.basename(str(it[4]))
+            for r, path in enumerate(paths):
+                name = os.path.basename(str(path))
                 if not name.endswith(".npz"):
                     name += ".npz"
                 np.savez(os.path.join(output_dir, name), ll=ll[r].reshape(1, 1), hmean=hmean[r].reshape(self.Nh, 1),
@@ -313,9 +379,10 @@ class QFA(object):
         if "mu" in f.files:
             self.mu = T(f["mu"])
         if optimizer is not None and "adam_i" in f.files:
-            optimizer.i = int(f["adam_i"])
-            optimizer.m = {k: T(f["adam_m_" + k]) for k in PARAM_KEYS}
-            optimizer.v = {k: T(f["adam_v_" + k]) for k in PARAM_KEYS}
+            optimizer.load_state_dict({"i": int(f["adam_i"]), "m": {k: T(f["adam_m_" + k]) for k in PARAM_KEYS},
+                                       "v": {k: T(f["adam_v_" + k]) for k in PARAM_KEYS}})
+        if self._dp:
+            self.sync_replicas(optimizer)
 
     def prediction_for_single_spectra(self, flux, error, zabs, mask):
         """reference QFA/model.py:160-180: ll (1,1), hmean (Nh,1), hcov (Nh,Nh), cont (Npix,), unc (Npix,)."""
@@ -347,6 +414,16 @@ class QFA(object):
         os.makedirs(output_dir, exist_ok=True)
         self.mu = torch.tensor(np.asarray(dataloader.mu), dtype=f32).to(self.device)
         Niter = dataloader.data_size // dataloader.batch_size
+        if self._dp:
+            # replicated state must be identical before the first update (and the loader must be the sharded kind:
+            # same number of steps on every rank, or the all-reduce deadlocks on an uneven tail)
+            import torch.distributed as dist
+            if getattr(dataloader, "world", 1) != dist.get_world_size(self._dp_group):
+                raise _lib.QFAHipError("data-parallel train() needs a dataloader sharded over the same ranks "
+                                       "(DeviceDataloader(rank=, world=))")
+            self.check_replicas(optimizer)
+        # the captured step graph is a single-process tool (launch-bound small batches); under data parallelism the
+        # per-rank batch is large (c4: 125 000 spectra) and the collective stays an eager RCCL call
         sg = self.step_graph(optimizer, dataloader.batch_size) if (use_graph and not self._dp) else None
         for epoch in range(n_epochs):
             dataloader.rewind()
@@ -398,7 +475,14 @@ class QFA(object):
         self.Psi = T(f["Psi"])
         self.tau0 = T(f["tau0"])
         self.beta = T(f["beta"])
+        if reference_c0_quirk and "c0" in f.files and float(np.asarray(f["c0"])) != float(np.asarray(f["beta"])):
+            import warnings
+            warnings.warn(f"{path}: c0 is read from the file's 'beta' entry ({float(np.asarray(f['beta'])):g}) as the "
+                          f"reference does (QFA/model.py:295); the file's own c0 is {float(np.asarray(f['c0'])):g}. "
+                          "Pass reference_c0_quirk=False (config MODEL.REFERENCE_C0_QUIRK) to read c0.", stacklevel=2)
         self.c0 = T(f["beta"] if reference_c0_quirk else f["c0"])
+        if self._dp:
+            self.sync_replicas()
 
 
 class StepGraph(object):
@@ -421,8 +505,11 @@ class StepGraph(object):
         self.replays = 0
 
     def _key(self):
-        m = self.model
-        return (self.opt.i, float(self.opt.scheduled_lr)) + tuple(getattr(m, k).data_ptr() for k in PARAM_KEYS)
+        # everything the captured launches bake in: scalars passed by value and every buffer address
+        m, o = self.model, self.opt
+        return ((o.i, float(o.scheduled_lr), float(o.b1), float(o.b2), float(o.eps), float(o.weight_decay))
+                + tuple(getattr(m, k).data_ptr() for k in PARAM_KEYS)
+                + tuple(o.m[k].data_ptr() for k in PARAM_KEYS) + tuple(o.v[k].data_ptr() for k in PARAM_KEYS))
 
     def _body(self):
         m = self.model

@@ -72,3 +72,38 @@ def test_train_with_device_dataloader_matches_host_prepared_batches(tmp_path):
     for k in params:
         assert rel_l2(model.parameters[k].cpu().numpy(), params[k]) < 2e-5, k
     assert rel_l2(model.mu.cpu().numpy(), mu) < 1e-6
+
+
+def test_reference_loader_methods_get_rows_sample_set_device_set_tau():
+    """the rest of the reference Dataloader surface main.py touches (QFA/dataloader.py:140-179): set_device (main.py:63),
+    set_tau, sample; plus get_rows (one launch per slice for the batched predict writer)"""
+    import torch
+    from functools import partial
+    from qfa_amd import utils
+    from qfa_amd.dataloader import DeviceDataloader
+    dev = torch.device("cuda:0")
+    g = golden("g11_dataprep.npz")
+    wav, flux, zq = g["wav_c1"], g["flux_c1"], g["zqso"]
+    err = np.where(flux != -999.0, 0.1, -999.0)
+    dl = DeviceDataloader(flux, err, zq, wav, batch_size=4, device=dev, shuffle=False)
+    dl.set_device(dev)
+    dl.set_device(torch.device("cuda"))
+    with pytest.raises(Exception):
+        dl.set_device(torch.device("cuda:7"))
+    f, e, z, m, paths = dl.get_rows(1, 5)
+    assert f.shape[0] == 4 and list(paths) == [1, 2, 3, 4]
+    for r, i in enumerate(range(1, 5)):
+        fi, ei, zi, mi, pi = dl[i]
+        assert torch.equal(f[r], fi) and torch.equal(e[r], ei) and torch.equal(z[r], zi) and torch.equal(m[r], mi)
+    np.random.seed(3)
+    d, e2, z2, m2 = dl.sample()
+    assert d.shape == (4, len(wav)) and m2.dtype == torch.bool
+    np.random.seed(3)
+    sig = np.random.randint(0, 6, size=(4,))
+    dref = dl._build(sig)[0]
+    assert torch.equal(d, dref)
+    mu_becker = dl.mu.copy()
+    dl.set_tau(partial(utils.tau, which="fg"))
+    assert not np.allclose(dl.mu, mu_becker)
+    dl.set_tau("becker")
+    assert np.array_equal(dl.mu, mu_becker)

@@ -491,3 +491,40 @@ def test_tolerance_sweep_float64_oracle_vs_float32_hip(dev, npix, nh):
         assert abs(ll[s] - o[0]) / abs(o[0]) < TOL_NLL
         assert np.max(np.abs(cont[s] - o[3])) / np.max(np.abs(o[3])) < 1e-4
         assert rel_l2(unc[s], o[4]) < 1e-4
+
+
+@pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 9, 33), (1000, 12, 130), (64, 16, 1), (33, 13, 17)])
+def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatch):
+    """N_h = 9..16 runs pass 2 on the XDL pipe (qfa_grads_x.h: two roles per SIMD, 32-pixel tiles); QFA_PASS2_F32=1
+    selects the float32-MFMA form.  Ragged shapes (pixel axis not a multiple of 32, blue/red boundary inside a tile,
+    spectra not a multiple of 16/64): both forms against each other section by section and against the oracle."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    from tools import parity_sections as PS
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=npix + nh)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=3 * npix + nh)
+    m = make_model(dev, p, mu)
+    bt = batch_t(b, dev)
+    monkeypatch.delenv("QFA_PASS2_F32", raising=False)
+    acc_x = m.accumulate(*bt).clone()
+    lx, gx = m._finalize(acc_x, True)
+    monkeypatch.setenv("QFA_PASS2_F32", "1")
+    acc_f = m.accumulate(*bt).clone()
+    monkeypatch.delenv("QFA_PASS2_F32", raising=False)
+    for name, sl in PS.sections(m).items():
+        a, r = acc_x[sl].double().cpu().numpy(), acc_f[sl].double().cpu().numpy()
+        if name in ("cnt", "n_blue", "n_spectra"):
+            assert np.array_equal(a, r), name
+        elif a.size == 1:
+            assert abs(a[0] - r[0]) <= 1e-4 * abs(r[0]) + 1e-6, (name, a, r)
+        else:
+            assert rel_l2(a, r) < 2e-5, (name, rel_l2(a, r))
+    oloss, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
+    assert abs(lx.item() - oloss) / abs(oloss) < TOL_NLL
+    for k in KEYS:
+        ours, ref = gx[k].cpu().numpy(), np.asarray(og[k])
+        ok = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(ours), np.isnan(ref)), k
+        assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k

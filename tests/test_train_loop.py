@@ -216,3 +216,68 @@ def test_train_with_step_graph_matches_eager(tmp_path, loader_kind):
         n += 1
     torch.cuda.synchronize()
     assert sg.replays == 3 and torch.isfinite(loss).all()
+
+
+@pytest.mark.gpu
+def test_model_without_blue_pixels_trains(tmp_path):
+    """N_b = 0 (omega is an empty tensor with a NULL data pointer): forward supported it, step / clip / smooth /
+    train must too."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+    dev = torch.device("cuda:0")
+    npix, nh, B = 96, 3, 9
+    rng = np.random.default_rng(3)
+    p = {"F": (0.3 * rng.standard_normal((npix, nh))).astype(np.float32), "Psi": np.full(npix, 0.1, np.float32),
+         "omega": np.zeros(0, np.float32), "tau0": np.float32(0.1), "c0": np.float32(0.2), "beta": np.float32(1.5)}
+    d = rng.standard_normal((B, npix)).astype(np.float32)
+    e = (0.1 + 0.1 * rng.random((B, npix))).astype(np.float32)
+    mk = rng.random((B, npix)) > 0.05
+    z = np.zeros((B, 0), np.float32)
+    T = lambda x: torch.tensor(x, device=dev)
+    m = QFA(0, npix, nh, dev, model_params=p)
+    opt = Adam(m.parameters, dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3, weight_decay=1e-1)
+    loss, g = m.forward(T(d), T(e), T(z), T(mk))
+    oloss, og = O.forward(p, d, e, z, mk)
+    assert abs(loss.item() - oloss) / abs(oloss) < 1e-5
+    assert g["omega"].numel() == 0
+    m.step(opt, T(d), T(e), T(z), T(mk))
+    m.clip()
+    m.smooth()
+    assert m.omega.numel() == 0 and torch.isfinite(m.F).all() and torch.isfinite(m.Psi).all()
+
+    class L:                                          # a foreign loader with the reference's contract
+        mu, data_size, batch_size = np.ones(npix, np.float32), B, 4
+        def rewind(self): self.cur = 0
+        def have_next_batch(self): return self.cur < B
+        def next_batch(self):
+            a, self.cur = self.cur, min(self.cur + 4, B)
+            return T(d[a:self.cur]), T(e[a:self.cur]), T(z[a:self.cur]), T(mk[a:self.cur])
+    m.train(opt, L(), 2, str(tmp_path), quiet=True)
+    assert torch.isfinite(m.F).all()
+
+
+@pytest.mark.gpu
+def test_step_graph_key_follows_adam_buffers():
+    """Adam.reset / load_state_dict allocate new moment tensors: the captured graph must not replay into the old ones"""
+    import torch
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+    dev = torch.device("cuda:0")
+    wav, nb, nr = synthetic.wavelength_grid(128)
+    p, mu = synthetic.mock_parameters(128, nb, 4, seed=2)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 8, seed=22)
+    m = QFA(nb, nr, 4, dev, model_params=p)
+    opt = Adam(m.parameters, dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3, weight_decay=1e-1)
+    sg = m.step_graph(opt, 8)
+    for dst, key in zip(sg.buf, ("delta", "error", "zabs", "mask")):
+        dst.copy_(torch.tensor(b[key], device=dev))
+    for _ in range(3):
+        sg.run()
+    assert sg.replays >= 1
+    k0 = sg._key()
+    opt.reset(m.parameters)
+    assert sg._key() != k0
+    sg.run()                                          # eager step with the new buffers, then re-capture
+    sg.run()
+    torch.cuda.synchronize()
+    assert all(float(opt.m[k].abs().sum()) > 0 for k in ("F", "Psi"))      # the LIVE moments were updated
