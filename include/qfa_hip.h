@@ -97,6 +97,17 @@ int qfa_nll_grad_events_f32(const qfa_params_t *p, const qfa_batch_t *b, const q
                             float *nll, float *accum, void *workspace, size_t workspace_bytes,
                             void *stream, void *const *events);
 
+/* Deterministic accumulation (SURVEY.md section 7 hard part 5, 8(e)).  By default the tiles of a block of 64 spectra
+ * are added to `accum` with float32 atomics, whose arrival order -- and so the last bits of the sums -- changes
+ * from run to run.  With a slab of qfa_det_slab_bytes() bytes every block writes its tile partials to its own
+ * row of the slab (plain stores) and a reducer adds the rows to `accum` in block order: two runs on the same
+ * inputs (and the same B, which fixes the work plan) are bit-identical.  slab == NULL is qfa_nll_grad_events_f32. */
+size_t qfa_det_slab_bytes(int B, int Npix, int Nb, int Nh);
+int qfa_nll_grad_det_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau,
+                         int B, int Npix, int Nb, int Nh,
+                         float *nll, float *accum, void *workspace, size_t workspace_bytes,
+                         void *slab, size_t slab_bytes, void *stream, void *const *events);
+
 /* Replaces the normalisation of QFA.forward (reference QFA/model.py:104): elementwise
  * grad = sum / count (0/0 = NaN), loss = sum_nll / n_spectra (model.py:100).  Reads `accum`
  * (after the optional all-reduce) and writes gradients with the reference's shapes.

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("QFA_HIP_LIB", os.path.join(_HERE, "libqfa_hip.so"))
 
 EXPORTS = (
     "qfa_abi_version", "qfa_tau_model", "qfa_workspace_bytes", "qfa_accum_floats",
-    "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_predict_events_f32",
+    "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_nll_grad_det_f32", "qfa_det_slab_bytes", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_predict_events_f32",
     "qfa_adam_clip_f32",
     "qfa_adam_clip_multi_f32", "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32", "qfa_build_batch_f32", "qfa_mu_estimate_f64",
     "qfa_mu_sums_f64", "qfa_mu_finish_f64",
@@ -72,6 +72,9 @@ def lib():
         "qfa_nll_grad_f32": (i, [C.POINTER(Params), C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i, p, p, p, sz, p]),
         "qfa_nll_grad_events_f32": (i, [C.POINTER(Params), C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i, p, p, p, sz,
                                         p, C.POINTER(C.c_void_p)]),
+        "qfa_nll_grad_det_f32": (i, [C.POINTER(Params), C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i, p, p, p, sz,
+                                     p, sz, p, C.POINTER(C.c_void_p)]),
+        "qfa_det_slab_bytes": (sz, [i, i, i, i]),
         "qfa_finalize_grads_f32": (i, [p, p, i, i, i, i, p, p, p, p, p, p, p, p]),
         "qfa_predict_f32": (i, [C.POINTER(Params), p, C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i,
                                 p, p, p, p, p, p, sz, p]),

@@ -71,16 +71,29 @@ int qfa_nll_grad_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_
 int qfa_nll_grad_events_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix,
                             int Nb, int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes,
                             void *stream, void *const *events) {
+    return qfa_nll_grad_det_f32(p, b, tau, B, Npix, Nb, Nh, nll, accum, workspace, workspace_bytes, nullptr, 0, stream,
+                                events);
+}
+
+size_t qfa_det_slab_bytes(int B, int Npix, int Nb, int Nh) {
+    if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || Nh < 1 || Nh > 32) return 0;
+    return det_slab_bytes(B, Npix, Nb, Nh);
+}
+
+int qfa_nll_grad_det_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix, int Nb,
+                         int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes, void *slab,
+                         size_t slab_bytes, void *stream, void *const *events) {
     if (!p || !b || !tau || !accum || !workspace) return QFA_E_NULL;
     if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
     if (!b->delta || !b->error || !b->mask || (Nb > 0 && !b->zabs)) return QFA_E_NULL;
     if (int e = check_shape(B, Npix, Nb, Nh)) return e;
     if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
+    if (slab && slab_bytes < det_slab_bytes(B, Npix, Nb, Nh)) return QFA_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events);
-    if (kp_for(Nh) == 16) return run_nll_grad<16>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events);
-    return qfa_k32_nll_grad(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events);
+    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab);
+    if (kp_for(Nh) == 16) return run_nll_grad<16>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab);
+    return qfa_k32_nll_grad(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab);
 }
 
 int qfa_finalize_grads_f32(const float *accum, const float *F, int Npix, int Nb, int Nh, int normalize, float *gF,

@@ -23,8 +23,38 @@
 // pixels 2 lo + h in column lo.
 #pragma once
 #include "qfa_common.h"
+#include "qfa_xdl_kernels.h"      // glds16a / dma_wait / lds_addr: the untracked LDS-DMA and counted-vmcnt helpers
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Memory protocol of the tile loop (the one k_moments_x uses, qfa_xdl_kernels.h): the image DMA and the spectra
+// prefetch are asm statements, invisible to hipcc's s_waitcnt bookkeeping -- with a tracked LDS-DMA in flight hipcc
+// waits vmcnt(0) at the next use of ANY load result and again at __syncthreads(), which exposed the whole memory
+// latency twice per tile (measured with in-kernel stamps: 40 % of role A's step).  Per step a wave issues, in this
+// order: [role B: the flush stores/atomics of older tiles] -> the DMA pieces of tile c + 1 -> its arithmetic ->
+// [role A: the 16 spectra loads of tile c + 2 into the registers it has just consumed] -> s_waitcnt vmcnt(N) with N
+// = the loads issued after the DMA (vmcnt retires in issue order) -> s_waitcnt lgkmcnt(0) -> raw s_barrier.
+__device__ __forceinline__ void aload8f(f32x2 &dst, const void *sbase, unsigned voff) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload2b(unsigned &dst, const void *sbase, unsigned voff) {
+    asm volatile("global_load_ushort %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// a pointer the compiler can see is wave-uniform (an "s" asm operand needs that; values derived from blockIdx through
+// divisions are not always proven uniform)
+template <typename T>
+__device__ __forceinline__ const T *uniform_ptr(const T *p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                   hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return reinterpret_cast<const T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void step_barrier() {        // LDS writes of this step done, then the workgroup barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 struct GX {                                              // KP = 16
     static constexpr int KP = 16, KK2 = 136;
@@ -43,7 +73,8 @@ struct GX {                                              // KP = 16
     static constexpr int L_GAM = L_BETA + 2 * 4 * 2048;              // [2][4][32 rows][GROW] float
     static constexpr int L_PART = L_GAM + 2 * 4 * 32 * GROW * 4;     // [2][4][32 px][16 b] float
     static constexpr int L_PSUM = L_PART + 2 * 4 * 2048;             // [2][4][4 sums][2 h][64 lanes] float
-    static constexpr int L_TOTAL = L_PSUM + 2 * 4 * 2048;
+    static constexpr int L_SCAL = L_PSUM + 2 * 4 * 2048;             // [4 waves][3 sums][64 lanes] double (role A)
+    static constexpr int L_TOTAL = L_SCAL + 4 * 3 * 64 * 8;
 };
 static_assert(GX::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
 
@@ -145,9 +176,24 @@ struct __attribute__((packed, aligned(4))) f2u { float v[2]; };       // 4-byte 
 struct __attribute__((packed, aligned(1))) u2u { unsigned char v[2]; };
 
 struct SpecA {                       // role A: one lane's 4 spectra x 2 pixels of a tile
-    float d[4][2], sg[4][2], z[4][2];
+    f32x2 d[4], sg[4], z[4];
     unsigned m[4];                   // 2 mask bytes
 };
+// No "landing" pins on these registers: the loads of a step are its LAST statements before the counted wait and the
+// barrier, and every use sits in a later iteration of the tile loop, so no use can be scheduled between a load and
+// its wait.  (Pins -- asm volatile("" : "+v"(reg)) at the first use, as k_moments_x has them -- made the allocator
+// spill 190 registers here.)  tools/audit_asm_loads.py checks the compiled code for that property: no instruction
+// may read the destination of an asm load before the next s_waitcnt vmcnt.
+
+#ifdef QFA_GX_STAMPS      // diagnostic build only: where a tile step spends its cycles (never shipped)
+__device__ unsigned long long qfa_gx_stamps[32];
+#define GX_STAMP(var)                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define GX_STAMP(var)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_grads_x.  One work item = (block of 64 spectra, range of 32-pixel tiles) as in the other passes (WorkPlan).
@@ -156,7 +202,9 @@ template <bool HASA>
 __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix, int Nb,
                                                     int Nh, int ntiles, WorkPlan wp,
                                                     const unsigned char *__restrict__ PGX,
-                                                    const float *__restrict__ SOL, float *__restrict__ accum) {
+                                                    const float *__restrict__ SOL, float *__restrict__ accum,
+                                                    float *__restrict__ slab, double *__restrict__ slabS) {
+    // slab != NULL: deterministic mode (see k_grads / k_reduce_slab in qfa_step_kernels.h)
     using C = Cfg<16>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GX::L_TOTAL];
     const int tid = threadIdx.x;
@@ -172,45 +220,63 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
     const int nbt = (Nb + 31) >> 5;                        // tiles that contain blue pixels
     const DevConsts k = load_consts(p, tau);
 
-    float *accF = accum;
+    const bool det = slab != nullptr;
+    float *accF = det ? slab + (size_t)blk * ((size_t)Npix * Nh + 3 * (size_t)Npix + Nb) : accum;
     float *accA = accF + (size_t)Npix * Nh;                // sumA | gPsi | gOmega | cnt (contiguous)
-    float *accS = accA + 3 * (size_t)Npix + Nb;
+    float *accS = accum + (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
+    auto add_to = [&](float *q, float v) {
+        if (det) *q = v;                                   // every (block, tile) element is written exactly once
+        else atomicAdd(q, v);
+    };
 
     // zero the slots that inactive groups never write
     for (int i = tid; i < (GX::L_TOTAL - GX::L_BETA) / 4; i += 512) reinterpret_cast<float *>(lds + GX::L_BETA)[i] = 0.f;
 
     // de-phase the tile order between workgroups (concurrent flushes then hit different rows; the workgroups running
     // together still share a window of the image in L2)
+#ifdef QFA_GX_NOROT
+    const int rot = 0;
+#else
     const int rot = n > 0 ? (int)(((unsigned)blk * 2654435761u) % (unsigned)min(n, 32)) : 0;
+#endif
     auto tile_of = [&](int c) {
         int x = c + rot;
         if (x >= n) x -= n;
         return t0 + x;
     };
-    // LDS-DMA of image tile c: wave v moves the 1-KiB pieces v, v + 8, ... (40 pieces, 5 per wave)
+    // LDS-DMA of image tile c by the four role-B waves: wave w moves the 1-KiB pieces w, w + 4, ... (40 pieces, 10 per
+    // wave).  Role A issues none: its queue holds its spectra loads only, so its counted wait sits in the MIDDLE of its
+    // step (behind stage 1) instead of in front of the barrier.
     auto get_tile = [&](int c) {
         const unsigned char *src = PGX + (size_t)tile_of(c) * GX::TILE_B + lane * 16;
         unsigned char *img = lds + GX::L_IMG + (c & 1) * GX::IMG_B;
         unsigned char *fp = lds + GX::L_FP + (c % 3) * 3072;
+        const unsigned char *sbase = uniform_ptr(PGX + (size_t)tile_of(c) * GX::TILE_B);
+        (void)src;
 #pragma unroll
-        for (int i = 0; i < GX::NCHUNK / 8; ++i) {
-            const int ch = wv8 + 8 * i;
+        for (int i = 0; i < GX::NCHUNK / 4; ++i) {
+            const int ch = w + 4 * i;
             unsigned char *dst = ch < GX::IMG_B / 1024 ? img + ch * 1024 : fp + (ch - GX::IMG_B / 1024) * 1024;
-            glds16(src + ch * 1024, dst);
+            glds16a(sbase + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(dst)));
         }
     };
     // tile tg leaves the workgroup: thread (px = tid >> 4, b = tid & 15) sums the four groups' partials (fixed order)
     // and adds them to the packed buffer: a wave's 64 lanes cover 4 pixel rows = 256 contiguous bytes at N_h = 16
+    // (role B's 256 threads: two outputs each)
     auto flush_F = [&](int tg, int buf) {
         const float *pp = reinterpret_cast<const float *>(lds + GX::L_PART + buf * 4 * 2048);
-        const float v = (pp[tid] + pp[512 + tid]) + (pp[1024 + tid] + pp[1536 + tid]);
-        const int px = 32 * tg + (tid >> 4), b = tid & 15;
-        if ((b < Nh) & (px < Npix)) atomicAdd(accF + (size_t)px * Nh + b, v);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int o = (tid & 255) + 256 * k2;
+            const float v = (pp[o] + pp[512 + o]) + (pp[1024 + o] + pp[1536 + o]);
+            const int px = 32 * tg + (o >> 4), b = o & 15;
+            if ((b < Nh) & (px < Npix)) add_to(accF + (size_t)px * Nh + b, v);
+        }
     };
     // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = tid >> 5, pxl = tid & 31), tid < 128
     auto flush_P = [&](int tg, int buf) {
-        if (tid < 128) {
-            const int which = tid >> 5, pxl = tid & 31, lo = pxl >> 1, h = pxl & 1;
+        if ((tid & 255) < 128) {
+            const int which = (tid & 255) >> 5, pxl = tid & 31, lo = pxl >> 1, h = pxl & 1;
             const float *q = reinterpret_cast<const float *>(lds + GX::L_PSUM + buf * 4 * 2048) + which * 128 + h * 64 + lo;
             float v = 0.f;
 #pragma unroll
@@ -218,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             const int px = 32 * tg + pxl;
             const int off = which * Npix - (which == 3 ? Npix - Nb : 0) + px;
             const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
-            if (ok) atomicAdd(accA + off, v);
+            if (ok) add_to(accA + off, v);
         }
     };
 
@@ -226,6 +292,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #define QFA_GX_ROLE 0      // register-pressure experiments: 1 = role A only, 2 = role B only
 #endif
     if (roleA && QFA_GX_ROLE != 2) {
+#ifdef QFA_GX_PRIO
+        __builtin_amdgcn_s_setprio(QFA_GX_PRIO);       // static priority of the VALU-heavy role on its SIMD
+#endif
         // ================================================================ role A: stage 1 + stage 2
         const int lo = lane & 15, g = lane >> 4;
         // A operand of stage 1: spectrum s0 + lo, k = 32 ks + 8 g + j
@@ -252,65 +321,80 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             }
         }
         bool sv[4];
-        unsigned offN[4], offB[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int srel = 4 * g + r;
-            sv[r] = active && (s0 + srel) < B;
-            const int sc = active ? min(srel, B - 1 - s0) : 0;
-            offN[r] = (unsigned)(sc * Npix);
-            offB[r] = (unsigned)(sc * Nb);
-        }
-        const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
-        const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
-        const uint8_t *mbase = bt.mask + (size_t)(active ? s0 : 0) * Npix;
-        const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
+        for (int r = 0; r < 4; ++r) sv[r] = active && (s0 + 4 * g + r) < B;
+        // row offsets of the lane's four spectra are recomputed where they are used (a handful of VALU instructions
+        // per tile) instead of living in eight registers for the whole loop: this role is at the register limit
+        const int last_row = active ? min(15, B - 1 - s0) : 0;          // wave-uniform
+        const int g4 = 4 * g;
+        auto row_of = [&](int r) {
+            int q = g4;
+            asm volatile("" : "+v"(q));                                // keep the product out of the loop-invariant set
+            return (unsigned)min(q + r, last_row);
+        };
+        auto offN_of = [&](int r) { return row_of(r) * (unsigned)Npix; };
+        auto offB_of = [&](int r) { return row_of(r) * (unsigned)Nb; };
+        const float *dbase = uniform_ptr(bt.delta + (size_t)(active ? s0 : 0) * Npix);
+        const float *ebase = uniform_ptr(bt.error + (size_t)(active ? s0 : 0) * Npix);
+        const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)(active ? s0 : 0) * Npix);
+        const float *zbase = uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
         const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
-        double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;     // float32 per tile, float64 across tiles
+        // scalar-gradient sums: float32 inside a tile, float64 across tiles -- the float64 running sums live in LDS
+        // (three doubles per lane), not in six registers
+        double *scal = reinterpret_cast<double *>(lds + GX::L_SCAL) + (size_t)w * 3 * 64 + lane;
+        scal[0] = 0.0; scal[64] = 0.0; scal[128] = 0.0;
 
-        auto load_spec = [&](int tg, SpecA &rg) {
+        // Spectra of one tile: 16 loads per lane (4 spectra x {delta, sigma, zabs: 8 bytes; mask: 2 bytes}), wave-uniform
+        // base in SGPRs + a 32-bit byte offset per lane.  Fast path: asm loads (see the protocol note at the top of
+        // the file); returns true.  Ragged end of the pixel axis / of the blue side: ordinary loads, retired on the spot.
+        // zabs is loaded for EVERY tile (red tiles re-read the last blue pixels: cache hits, values unused) so that the
+        // load count per step is fixed.
+        auto load_spec = [&](int tg, SpecA &rg) -> bool {
+#ifdef QFA_GX_LOADT0      // timing only: every step re-reads the first tile (cache hits)
+            tg = t0;
+#endif
             const int pb = 32 * tg + 2 * lo;
-            if (32 * tg + 31 < Npix) {
+            const int tz = min(tg, nbt - 1), pz = 32 * tz + 2 * lo;
+            const bool fast = (32 * tg + 31 < Npix) && (Nb == 0 || 32 * tz + 31 < Nb);       // wave-uniform
+            if (fast) {
+                // (no blue side: zabs is NULL, any valid address keeps the load count; branch-free on purpose)
+                const float *zb = Nb > 0 ? zbase : dbase;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const f2u vd = *reinterpret_cast<const f2u *>(dbase + offN[r] + pb);
-                    const f2u ve = *reinterpret_cast<const f2u *>(ebase + offN[r] + pb);
-                    const u2u vm = *reinterpret_cast<const u2u *>(mbase + offN[r] + pb);
-                    rg.d[r][0] = vd.v[0]; rg.d[r][1] = vd.v[1];
-                    rg.sg[r][0] = ve.v[0]; rg.sg[r][1] = ve.v[1];
-                    rg.m[r] = (unsigned)vm.v[0] | ((unsigned)vm.v[1] << 8);
+                    const unsigned o = offN_of(r) + (unsigned)pb;
+                    const unsigned oz = Nb > 0 ? offB_of(r) + (unsigned)pz : o;
+                    aload8f(rg.d[r], dbase, 4u * o);
+                    aload8f(rg.sg[r], ebase, 4u * o);
+                    aload2b(rg.m[r], mbase, o);
+                    aload8f(rg.z[r], zb, 4u * oz);
                 }
-            } else {                                                  // ragged end of the pixel axis
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    rg.m[r] = 0;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const unsigned px = (unsigned)min(pb + h, Npix - 1);
-                        rg.d[r][h] = dbase[offN[r] + px];
-                        rg.sg[r][h] = ebase[offN[r] + px];
-                        rg.m[r] |= (pb + h < Npix && mbase[offN[r] + px] != 0) ? (1u << (8 * h)) : 0u;
-                    }
-                }
+                return true;
             }
-            if (tg < nbt) {
-                if (32 * tg + 31 < Nb) {
+            // ragged end: ordinary loads into temporaries, retired HERE (the empty asm reads them), then handed over --
+            // a tracked load still pending at the join would make hipcc wait vmcnt(0) in front of the fast path's next
+            // (untracked) loads into the same registers
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const f2u vz = *reinterpret_cast<const f2u *>(zbase + offB[r] + pb);
-                        rg.z[r][0] = vz.v[0]; rg.z[r][1] = vz.v[1];
-                    }
-                } else {
+            for (int r = 0; r < 4; ++r) {
+                f32x2 td, ts, tzv;
+                unsigned mm = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) rg.z[r][h] = zbase[offB[r] + (unsigned)min(pb + h, Nb - 1)];
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned o = offN_of(r) + (unsigned)min(pb + h, Npix - 1);
+                    td[h] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dbase) + 4u * o);
+                    ts[h] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ebase) + 4u * o);
+                    mm |= (pb + h < Npix && mbase[o] != 0) ? (1u << (8 * h)) : 0u;
+                    tzv[h] = Nb > 0 ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(zbase) +
+                                                                       4u * (offB_of(r) + (unsigned)min(pz + h, Nb - 1)))
+                                    : 0.f;
                 }
+                asm volatile("" : "+v"(td), "+v"(ts), "+v"(tzv), "+v"(mm));
+                rg.d[r] = td; rg.sg[r] = ts; rg.z[r] = tzv; rg.m[r] = mm;
             }
+            return false;
         };
 
         // stage 1 + stage 2 of one tile
-        auto tileA = [&](auto blue_tag, int tg, const SpecA &cur, int buf) {
+        auto tileA = [&](auto blue_tag, int tg, const SpecA &cur, int buf, bool next_counted) {
             constexpr bool BLUE = decltype(blue_tag)::value;
             const unsigned char *img = lds + GX::L_IMG + buf * GX::IMG_B;
             float *bslot = reinterpret_cast<float *>(lds + GX::L_BETA + (buf * 4 + w) * 2048);
@@ -318,19 +402,41 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             float *psum = reinterpret_cast<float *>(lds + GX::L_PSUM + (buf * 4 + w) * 2048);
             float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
             const float *po = reinterpret_cast<const float *>(img + GX::OFF_PO);
-            // one 16-pixel half at a time: stage 1 (36 MFMAs), then stage 2 of its 4 elements
+            // stage 1 of BOTH 16-pixel halves first (72 MFMAs; needs the image and the static operands only), THEN the wait
+            // for this tile's spectra: their loads were issued at the end of step c - 2 and so get a step and a third
+            f32x4 afy2[2], aq2[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const unsigned char *bp = img + h * GX::S1_HALF + lane * 16;
                 f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+                // B pieces of K-step ks + 1 are read while the six MFMAs of K-step ks run; the fences keep the compiler
+                // from reading further ahead (every K-step in flight costs 12 registers)
+                u32x4 bq[2][3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
 #pragma unroll
                 for (int ks = 0; ks < GX::NKS; ++ks) {
-                    const u32x4 bh = *reinterpret_cast<const u32x4 *>(bp + ks * 3072),
-                                bm = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 1024),
-                                bl = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 2048);
+                    if (ks + 1 < GX::NKS) {
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
                     if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
                     else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                afy2[h] = afy;
+                aq2[h] = aq;
+            }
+            // all but the loads of the NEXT tile (16, when they were issued by the asm path) have landed after this
+            if (next_counted) dma_wait<16>();
+            else dma_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 afy = afy2[h], aq = aq2[h];
                 const float Psi = po[2 * lo + h], om = po[32 + 2 * lo + h];
                 const int px = 32 * tg + 2 * lo + h;
                 const bool inb = px < Npix;
@@ -348,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                         const float pw = fast_exp2(k.beta * l2);
                         const float tauv = k.t_amp * fast_exp2(k.t_expo * (l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
                         float Ab = fast_exp2(-tauv * QFA_LOG2E);                                          // QFA/model.py:125
-                        if (HASA) Ab = abase[offB[r] + (unsigned)min(px, Nb - 1)];                        // custom tau callable
+                        if (HASA) Ab = abase[offB_of(r) + (unsigned)min(px, Nb - 1)];                        // custom tau callable
                         const float re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);               // QFA/utils.py:91
                         const float Av = blue ? Ab : 1.f;
                         const float zd = blue ? re * re : 0.f;
@@ -381,6 +487,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                         sA += wD;
                         gamR[r] = uu;
                     }
+#ifndef QFA_GX_NOFENCE
+                    if (r & 1) __builtin_amdgcn_sched_barrier(0);      // two elements at a time: bounds the live temporaries
+#endif
                 }
                 // beta[s = 4g + r][pxl = 2 lo + h]
 #pragma unroll
@@ -394,36 +503,62 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 psum[3 * 128 + h * 64 + lane] = cnt;
             }
             if (BLUE) {
-                s_tau0 += (double)t_tau0;
-                s_c0 += (double)t_c0;
-                s_beta += (double)t_beta;
+                scal[0] += (double)t_tau0;
+                scal[64] += (double)t_c0;
+                scal[128] += (double)t_beta;
             }
         };
 
-        SpecA ra, rb;
-        if (n > 0) {
-            get_tile(0);
-            if (active) load_spec(tile_of(0), ra);
+        SpecA ra, rb;                        // ra: tiles c = 0, 2, 4 ...; rb: the odd ones; each is reloaded two tiles ahead
+        bool cnt_a = false, cnt_b = false;   // were the loads now in flight into ra / rb issued by the (counted) asm path
+#ifdef QFA_GX_STAMPS
+        unsigned long long st_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        if (n > 0 && active) {
+            cnt_a = load_spec(tile_of(0), ra);
+            if (n > 1) cnt_b = load_spec(tile_of(1), rb);
         }
-        __syncthreads();
-        for (int c = 0; c < n + 2; ++c) {
-            auto stepA = [&](const SpecA &cur, SpecA &nxt) {
-                if (c + 1 < n) {
-                    get_tile(c + 1);
-                    if (active) load_spec(tile_of(c + 1), nxt);
-                }
-                if (c < n && active) {
-                    const int tg = tile_of(c);
-                    if (tg < nbt) tileA(std::true_type{}, tg, cur, c & 1);
-                    else tileA(std::false_type{}, tg, cur, c & 1);
-                }
-                if (c >= 1 && c <= n) flush_P(tile_of(c - 1), (c - 1) & 1);
-                if (c >= 2) flush_F(tile_of(c - 2), c & 1);
-            };
-            if (c & 1) stepA(rb, ra);
-            else stepA(ra, rb);
-            __syncthreads();
+        step_barrier();                      // (role B's wait in front of this barrier covers the image of tile 0)
+        // one step: stage 1, wait for the spectra of this tile, stage 2, refill the registers with tile c + 2
+        auto stepA = [&](int c, SpecA &cur, bool &cnt_cur, bool cnt_other) {
+#ifdef QFA_GX_STAMPS
+            unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+#endif
+            GX_STAMP(q0)
+            GX_STAMP(q1)
+            if (c < n && active) {
+                const int tg = tile_of(c);
+                const bool nc = (c + 1 < n) && cnt_other;
+                if (tg < nbt) tileA(std::true_type{}, tg, cur, c & 1, nc);
+                else tileA(std::false_type{}, tg, cur, c & 1, nc);
+            }
+            GX_STAMP(q2)
+            cnt_cur = false;
+#ifdef QFA_GX_NOLOAD      // timing only
+            if (c + 2 < n && active && c < 2) cnt_cur = load_spec(tile_of(c + 2), cur);
+#else
+            if (c + 2 < n && active) cnt_cur = load_spec(tile_of(c + 2), cur);
+#endif
+            GX_STAMP(q3)
+            step_barrier();
+#ifdef QFA_GX_STAMPS
+            GX_STAMP(q4)
+            if (c >= 2 && c < n) {
+                const int o = tile_of(c) < nbt ? 0 : 8;
+                st_t[o + 0] += q1 - q0; st_t[o + 1] += q2 - q1; st_t[o + 2] += q3 - q2; st_t[o + 3] += q4 - q3; st_t[o + 4] += 1;
+            }
+#endif
+        };
+        for (int c = 0; c < n + 2; c += 2) {
+            stepA(c, ra, cnt_a, cnt_b);
+            if (c + 1 < n + 2) stepA(c + 1, rb, cnt_b, cnt_a);
         }
+        dma_wait<0>();
+#ifdef QFA_GX_STAMPS
+        if (blk == 300 && w == 0 && lane == 0 && seg == 0)
+            for (int i = 0; i < 16; ++i) qfa_gx_stamps[i] = st_t[i];
+#endif
+        double s_tau0 = scal[0], s_c0 = scal[64], s_beta = scal[128];
         if (active) {
             for (int o = 32; o >= 1; o >>= 1) {
                 s_tau0 += __shfl_xor(s_tau0, o);
@@ -431,10 +566,18 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 s_beta += __shfl_xor(s_beta, o);
             }
             if (lane == 0) {
-                atomicAdd(accS + 0, (float)s_tau0);
-                atomicAdd(accS + 1, (float)s_c0);
-                atomicAdd(accS + 2, (float)s_beta);
+                if (det) {
+                    double *q = slabS + ((size_t)blockIdx.x * 4 + w) * 3;
+                    q[0] = s_tau0; q[1] = s_c0; q[2] = s_beta;
+                } else {
+                    atomicAdd(accS + 0, (float)s_tau0);
+                    atomicAdd(accS + 1, (float)s_c0);
+                    atomicAdd(accS + 2, (float)s_beta);
+                }
             }
+        } else if (det && lane == 0) {
+            double *q = slabS + ((size_t)blockIdx.x * 4 + w) * 3;
+            q[0] = 0.0; q[1] = 0.0; q[2] = 0.0;
         }
     } else if (QFA_GX_ROLE != 1) {
         // ================================================================ role B: stage 3
@@ -462,6 +605,31 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             }
             split8(x, Ph, Pm, Pl);
         }
+#ifndef QFA_GX_PFD
+#define QFA_GX_PFD 3          // prefetch distance in tiles
+#endif
+        // lane (row = lane & 15, arr = lane >> 4) touches the segment of array arr = {delta, sigma, zabs, mask} of
+        // spectrum s0 + row that tile c covers; pf_sink is the (never read) destination, live for the whole loop
+        unsigned pf_sink = 0;
+        const unsigned char *pf_base;
+        unsigned pf_stride, pf_esize, pf_len;          // row stride, bytes per pixel, pixels on the axis of this array
+        {
+            const int arr = lane >> 4, row = active ? min(lane & 15, B - 1 - s0) : 0;
+            const size_t s = (size_t)(active ? s0 : 0) + row;
+            if (arr == 0) { pf_base = reinterpret_cast<const unsigned char *>(bt.delta + s * Npix); pf_esize = 4; pf_len = Npix; }
+            else if (arr == 1) { pf_base = reinterpret_cast<const unsigned char *>(bt.error + s * Npix); pf_esize = 4; pf_len = Npix; }
+            else if (arr == 2 && Nb > 0) { pf_base = reinterpret_cast<const unsigned char *>(bt.zabs + s * Nb); pf_esize = 4; pf_len = Nb; }
+            else { pf_base = reinterpret_cast<const unsigned char *>(bt.mask + s * Npix); pf_esize = 1; pf_len = Npix; }
+            pf_stride = 0;
+        }
+        auto prefetch = [&](int c) {
+            const int tg = n > 0 ? tile_of(max(c, 0)) : 0;
+            const unsigned p0 = (unsigned)min(32 * tg, (int)pf_len - 1), p1 = (unsigned)min(32 * tg + 31, (int)pf_len - 1);
+            const unsigned char *a0 = pf_base + (size_t)p0 * pf_esize, *a1 = pf_base + (size_t)p1 * pf_esize + (pf_esize - 1);
+            asm volatile("global_load_ubyte %0, %1, off" : "+v"(pf_sink) : "v"(a0) : "memory");
+            asm volatile("global_load_ubyte %0, %1, off" : "+v"(pf_sink) : "v"(a1) : "memory");
+        };
+        (void)pf_stride;
         auto tileB = [&](int c) {
             const int buf = c & 1;
             const unsigned char *fp = lds + GX::L_FP + (c % 3) * 3072 + lane * 16;
@@ -505,14 +673,52 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 part[((ii & 3) + 8 * (ii >> 2) + 4 * h2) * 16 + b] = v;
             }
         };
+#ifdef QFA_GX_STAMPS
+        unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         if (n > 0) get_tile(0);
-        __syncthreads();
+        dma_wait<0>();
+        step_barrier();
         for (int c = 0; c < n + 2; ++c) {
-            if (c + 1 < n) get_tile(c + 1);
-            if (c >= 1 && c <= n && active) tileB(c - 1);
+#ifdef QFA_GX_STAMPS
+            unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+#endif
+            GX_STAMP(q0)
+            // the flushes first: their stores / atomics are the oldest requests of the step and have the whole of
+            // stage 3 to drain before the vmcnt(0) in front of the barrier
+#ifndef QFA_GX_NOFLUSH    // (defined: timing only)
             if (c >= 1 && c <= n) flush_P(tile_of(c - 1), (c - 1) & 1);
             if (c >= 2) flush_F(tile_of(c - 2), c & 1);
-            __syncthreads();
+#endif
+            GX_STAMP(q1)
+#ifdef QFA_GX_NODMA       // timing only
+            if (c + 1 < n && c < 2) get_tile(c + 1);
+#else
+            if (c + 1 < n) get_tile(c + 1);
+#endif
+            GX_STAMP(q2)
+            if (c >= 1 && c <= n && active) tileB(c - 1);
+#ifndef QFA_GX_NOPF
+            // L2 prefetch of the spectra role A will load QFA_GX_PFD tiles from now: two loads per lane (first and last
+            // byte of its row segment: every 128-byte line of it), results never read.  They are the youngest requests
+            // of the step: the counted wait below leaves them in flight.
+            prefetch(c + QFA_GX_PFD < n ? c + QFA_GX_PFD : n - 1);
+            dma_wait<2>();                         // everything but the two prefetch loads: retires the DMA of tile c + 1
+#else
+            dma_wait<0>();
+#endif
+            GX_STAMP(q3)
+            step_barrier();
+#ifdef QFA_GX_STAMPS
+            GX_STAMP(q4)
+            if (c >= 2 && c < n) { st_t[0] += q1 - q0; st_t[1] += q2 - q1; st_t[2] += q3 - q2; st_t[3] += q4 - q3; st_t[4] += 1; }
+#endif
         }
+        dma_wait<0>();
+        asm volatile("" ::"v"(pf_sink));               // the prefetch destination stayed reserved up to here
+#ifdef QFA_GX_STAMPS
+        if (blk == 300 && w == 0 && lane == 0 && seg == 0)
+            for (int i = 0; i < 8; ++i) qfa_gx_stamps[16 + i] = st_t[i];
+#endif
     }
 }

@@ -11,7 +11,8 @@
 // pass 2 for N_h in 9..16 with every contraction on the XDL pipe (qfa_grads_x.h, built in qfa_gx.hip)
 size_t qfa_gx_image_bytes(int ntiles32);
 void qfa_gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, hipStream_t st);
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
+                   double *slabS, hipStream_t st);
 
 namespace {
 
@@ -104,11 +105,15 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
     return 0;
 }
 
-// QFA_PASS2_F32=1 in the environment selects the float32-MFMA form of pass 2 at N_h = 9..16 too (A/B timing and the
-// cross-check of the two forms in tests/); read at every call, nothing is cached
-inline bool pass2_f32_forced() {
-    const char *e = std::getenv("QFA_PASS2_F32");
-    return e && e[0] == '1';
+// Which form of pass 2 runs at N_h = 9..16: 0 = the float32-MFMA form with stage 3 on the XDL pipe (k_grads), 1 = the
+// all-XDL two-role form (k_grads_x).  Default (measured at c3 on MI355X, profiles/r2_ablation_k_grads_x.txt): k_grads is
+// faster there (3.25 vs 3.5 ms), k_grads_x is the one that is bit-reproducible under the deterministic slab mode, so
+// it serves that mode.  QFA_PASS2_XDL=1 / QFA_PASS2_XDL=0 in the environment force one form (A/B timing, and the
+// cross-check of the two forms in tests/); read at every call, nothing is cached.
+inline bool pass2_use_xdl(bool deterministic) {
+    const char *e = std::getenv("QFA_PASS2_XDL");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return deterministic;
 }
 
 inline int hip_status() {
@@ -155,10 +160,24 @@ void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t
     }
 }
 
+// deterministic mode: slab = [nblk rows of NF floats | scalar sums: (max items) x 4 waves x 3 doubles]
+inline size_t det_rows_floats(int Npix, int Nb, int Nh) { return (size_t)Npix * Nh + 3 * (size_t)Npix + Nb; }
+inline size_t det_slab_bytes(int B, int Npix, int Nb, int Nh) {
+    const Layout L = make_layout(B, Npix, Nh);
+    const size_t nblk = (size_t)(B + 63) / 64;
+    const size_t items = (size_t)(L.wp2.items() > L.wp2x.items() ? L.wp2.items() : L.wp2x.items());
+    return (nblk * det_rows_floats(Npix, Nb, Nh) * sizeof(float) + 15) / 16 * 16 + items * 4 * 3 * sizeof(double);
+}
+
 template <int KP>
 int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                 float *nll, float *accum, float *ws, hipStream_t st, void *const *events) {
+                 float *nll, float *accum, float *ws, hipStream_t st, void *const *events, void *slabv = nullptr) {
     const Layout L = make_layout_t<KP>(B, Npix);
+    const size_t NF = det_rows_floats(Npix, Nb, Nh);
+    const int nblk = (B + 63) / 64;
+    float *slab = reinterpret_cast<float *>(slabv);
+    double *slabS = slab ? reinterpret_cast<double *>(reinterpret_cast<char *>(slab) + ((size_t)nblk * NF * sizeof(float) + 15) / 16 * 16)
+                         : nullptr;
     float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL, *NBL = ws + L.oNBL;
     float *nllbuf = nll ? nll : ws + L.oNLL;
     const size_t accS = (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
@@ -176,20 +195,23 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
     mark(3);
     bool pass2_xdl = false;
-    if constexpr (KP == 16) pass2_xdl = !pass2_f32_forced();
+    if constexpr (KP == 16) pass2_xdl = pass2_use_xdl(slab != nullptr);
     if (pass2_xdl) {
         qfa_gx_launch(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
-                      accum, st);
+                      accum, slab, slabS, st);
+        if (slab)
+            k_reduce_slab<<<(unsigned)((NF + 255) / 256), 256, 0, st>>>(slab, slabS, nblk, L.wp2x.items() * 4, NF, accum);
         mark(4);
         return hip_status();
     }
     for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
         if (16 * bh >= Nh) break;
         if (b.A_blue)
-            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum);
+            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS);
         else
-            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum);
+            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS);
     }
+    if (slab) k_reduce_slab<<<(unsigned)((NF + 255) / 256), 256, 0, st>>>(slab, slabS, nblk, L.wp2.items() * 4, NF, accum);
     mark(4);
     return hip_status();
 }
@@ -221,7 +243,7 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
 
 // N_h in 17..32 (defined in qfa_k32.hip)
 int qfa_k32_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                     float *nll, float *accum, float *ws, hipStream_t st, void *const *events);
+                     float *nll, float *accum, float *ws, hipStream_t st, void *const *events, void *slab);
 int qfa_k32_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
                     int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
                     hipStream_t st, void *const *events);

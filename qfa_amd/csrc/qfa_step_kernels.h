@@ -534,7 +534,10 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
                                                               int Npix, int Nb, int Nh, int ntiles, WorkPlan wp,
                                                               int bhalf, const float *__restrict__ PFT,
                                                               const float *__restrict__ SOL,
-                                                              float *__restrict__ accum) {
+                                                              float *__restrict__ accum, float *__restrict__ slab,
+                                                              double *__restrict__ slabS) {
+    // slab != NULL: deterministic mode -- the block's tile partials go to row blk of the slab (plain stores), its
+    // scalar sums to slabS[item][wave][3]; k_reduce_slab adds the rows to accum in block order.
     // bhalf: which 16 columns of the F gradient this launch produces (N_h > 16 runs the kernel once per
     // half; the per-pixel and scalar sums are added by the bhalf == 0 launch only)
     using C = Cfg<KP>;
@@ -567,12 +570,14 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     const DevConsts k = load_consts(p, tau);
     const int lo = lane & 15, g = lane >> 4;
 
-    float *accF = accum;
+    const bool det = slab != nullptr;
+    float *accF = det ? slab + (size_t)blk * ((size_t)Npix * Nh + 3 * (size_t)Npix + Nb) : accum;
     float *accA = accF + (size_t)Npix * Nh;
-    float *accPsi = accA + Npix;
-    float *accOm = accPsi + Npix;
-    float *accCnt = accOm + Nb;
-    float *accS = accCnt + Npix;
+    float *accS = accum + (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
+    auto add_to = [&](float *q, float v) {
+        if (det) *q = v;                     // every (block, tile) element is written exactly once
+        else atomicAdd(q, v);
+    };
 
     // A operands of stage 1: spectrum s0+lo, k = 4t + g
     float yA[KF], qA[KQ];
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
                 const int idx = lane + 64 * wv;
                 const float v = (pp[0][idx] + pp[1][idx]) + (pp[2][idx] + pp[3][idx]);
                 const int px = base + (idx >> 4), b = 16 * bhalf + (idx & 15);
-                if ((b < Nh) & (px < Npix)) atomicAdd(accF + (size_t)px * Nh + b, v);
+                if ((b < Nh) & (px < Npix)) add_to(accF + (size_t)px * Nh + b, v);
             }
             if (extra & (bhalf == 0)) {
                 const int which = lane >> 4, px = base + (lane & 15);
@@ -950,7 +955,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
                 // accA = sumA (Npix) | gPsi (Npix) | gOmega (Nb) | cnt (Npix), contiguous
                 const int off = which * Npix - (which == 3 ? Npix - Nb : 0) + px;
                 const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
-                if (ok) atomicAdd(accA + off, v);
+                if (ok) add_to(accA + off, v);
             }
         };
         auto tilebuf = [&](int c) { return reinterpret_cast<const float *>(lds4[c % RING_M]); };
@@ -1060,16 +1065,46 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
         for (int i = 0; i < 16; ++i) qfa_dbg_stamps[seg * 16 + i] = st_t[i];
     }
 #endif
-    if (!active) return;
+    if (!active) {
+        if (det && lane == 0 && bhalf == 0) {              // the reducer reads every (item, wave) record
+            double *q = slabS + ((size_t)blockIdx.x * 4 + wv) * 3;
+            q[0] = 0.0; q[1] = 0.0; q[2] = 0.0;
+        }
+        return;
+    }
     for (int o = 32; o >= 1; o >>= 1) {
         s_tau0 += __shfl_xor(s_tau0, o);
         s_c0 += __shfl_xor(s_c0, o);
         s_beta += __shfl_xor(s_beta, o);
     }
     if (lane == 0 && bhalf == 0) {
-        atomicAdd(accS + 0, (float)s_tau0);
-        atomicAdd(accS + 1, (float)s_c0);
-        atomicAdd(accS + 2, (float)s_beta);
+        if (det) {
+            double *q = slabS + ((size_t)blockIdx.x * 4 + wv) * 3;
+            q[0] = s_tau0; q[1] = s_c0; q[2] = s_beta;
+        } else {
+            atomicAdd(accS + 0, (float)s_tau0);
+            atomicAdd(accS + 1, (float)s_c0);
+            atomicAdd(accS + 2, (float)s_beta);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_reduce_slab (deterministic mode): accum[j] += sum over blocks of slab[blk][j] in block order (float64 partial),
+// and the three scalar gradients from slabS[item][wave] in item order.
+// ------------------------------------------------------------------------------------------------
+static __global__ void k_reduce_slab(const float *__restrict__ slab, const double *__restrict__ slabS, int nblk,
+                                     int nitemwaves, size_t NF, float *__restrict__ accum) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < NF) {
+        double a = 0.0;
+        for (int bq = 0; bq < nblk; ++bq) a += (double)slab[(size_t)bq * NF + j];
+        accum[j] += (float)a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        double a = 0.0;
+        for (int q = 0; q < nitemwaves; ++q) a += slabS[(size_t)q * 3 + threadIdx.x];
+        accum[NF + threadIdx.x] += (float)a;
     }
 }
 

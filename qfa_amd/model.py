@@ -79,6 +79,9 @@ class QFA(object):
         self._dp_group = None
         self._dp = False
         self._dp_checked = False
+        # deterministic=True: per-block slab + fixed-order reducer instead of float32 atomics in pass 2
+        # (qfa_nll_grad_det_f32): bit-identical sums from run to run, at the price of a (B/64) x accum-sized slab
+        self.deterministic = False
 
     # ------------------------------------------------------------------ parameters
     def random_init_func(self) -> None:
@@ -252,10 +255,19 @@ class QFA(object):
         evs = None
         if events is not None:
             evs = (C.c_void_p * 5)(*[C.c_void_p(e.cuda_event) for e in events])
-        _lib.check(_lib.lib().qfa_nll_grad_events_f32(
+        slab, slab_bytes = None, 0
+        if self.deterministic:
+            slab_bytes = _lib.lib().qfa_det_slab_bytes(B, self.Npix, self.Nb, self.Nh)
+            sl = self._ws.get("slab")
+            if sl is None or sl.numel() < slab_bytes:
+                sl = torch.empty(slab_bytes, dtype=torch.uint8, device=self.device)
+                self._ws["slab"] = sl
+            slab = C.c_void_p(sl.data_ptr())
+        _lib.check(_lib.lib().qfa_nll_grad_det_f32(
             C.byref(ps), C.byref(bs), C.byref(self._tau_model), B, self.Npix, self.Nb, self.Nh,
             C.c_void_p(nll.data_ptr()) if nll is not None else None, C.c_void_p(acc.data_ptr()),
-            C.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream(self.device), evs), "qfa_nll_grad_f32")
+            C.c_void_p(ws.data_ptr()), ws.numel(), slab, slab_bytes, _lib.current_stream(self.device), evs),
+            "qfa_nll_grad_f32")
         return acc
 
     def _finalize(self, acc, normalize=True):

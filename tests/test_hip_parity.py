@@ -495,8 +495,9 @@ def test_tolerance_sweep_float64_oracle_vs_float32_hip(dev, npix, nh):
 
 @pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 9, 33), (1000, 12, 130), (64, 16, 1), (33, 13, 17)])
 def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatch):
-    """N_h = 9..16 runs pass 2 on the XDL pipe (qfa_grads_x.h: two roles per SIMD, 32-pixel tiles); QFA_PASS2_F32=1
-    selects the float32-MFMA form.  Ragged shapes (pixel axis not a multiple of 32, blue/red boundary inside a tile,
+    """N_h = 9..16 has two forms of pass 2: k_grads (float32-MFMA stage 1) and k_grads_x (qfa_grads_x.h: everything on
+    the XDL pipe, two roles per SIMD, 32-pixel tiles; the engine of the deterministic mode); QFA_PASS2_XDL=1 / 0 in
+    the environment selects one.  Ragged shapes (pixel axis not a multiple of 32, blue/red boundary inside a tile,
     spectra not a multiple of 16/64): both forms against each other section by section and against the oracle."""
     import torch
     from oracle import qfa_oracle as O
@@ -507,12 +508,12 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
     b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=3 * npix + nh)
     m = make_model(dev, p, mu)
     bt = batch_t(b, dev)
-    monkeypatch.delenv("QFA_PASS2_F32", raising=False)
+    monkeypatch.setenv("QFA_PASS2_XDL", "1")
     acc_x = m.accumulate(*bt).clone()
     lx, gx = m._finalize(acc_x, True)
-    monkeypatch.setenv("QFA_PASS2_F32", "1")
+    monkeypatch.setenv("QFA_PASS2_XDL", "0")
     acc_f = m.accumulate(*bt).clone()
-    monkeypatch.delenv("QFA_PASS2_F32", raising=False)
+    monkeypatch.delenv("QFA_PASS2_XDL", raising=False)
     for name, sl in PS.sections(m).items():
         a, r = acc_x[sl].double().cpu().numpy(), acc_f[sl].double().cpu().numpy()
         if name in ("cnt", "n_blue", "n_spectra"):
@@ -528,3 +529,29 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
         ok = ~np.isnan(ref)
         assert np.array_equal(np.isnan(ours), np.isnan(ref)), k
         assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
+
+
+@pytest.mark.parametrize("npix,nh,B", [(4000, 16, 20000), (2000, 8, 10000), (640, 32, 3000), (200, 12, 70)])
+def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B):
+    """QFA.deterministic = True (qfa_nll_grad_det_f32: per-block slab + fixed-order reducer instead of float32 atomics):
+    repeated runs on the same batch are BIT-identical, and agree with the default (atomic) mode to rounding."""
+    import torch
+    from qfa_amd import synthetic
+    from tools import parity_sections as PS
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=nh)
+    batch = synthetic.make_batch_torch(p, mu, wav, nb, B, 1234 + nh, dev, masks=True)
+    m = make_model(dev, p, mu)
+    ref = m.accumulate(*batch).clone()
+    m.deterministic = True
+    runs = [m.accumulate(*batch).clone() for _ in range(4)]
+    for r in runs[1:]:
+        assert torch.equal(runs[0], r)
+    for name, sl in PS.sections(m).items():
+        a, r = runs[0][sl].double().cpu().numpy(), ref[sl].double().cpu().numpy()
+        if name in ("cnt", "n_blue", "n_spectra"):
+            assert np.array_equal(a, r), name
+        elif a.size == 1:
+            assert abs(a[0] - r[0]) <= 2e-4 * abs(r[0]) + 1e-6, (name, a, r)
+        else:
+            assert rel_l2(a, r) < 5e-5, (name, rel_l2(a, r))

@@ -9,7 +9,7 @@ for set in "$@"; do
   i=$((i+1))
   d=$R/gpurun_out/pmc_${tag}_$i
   rm -rf $d
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -- python3 $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > $d.json 2> $d.err || { echo "pass $i failed"; tail -5 $d.err; }
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -- python3 $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-predict --sustain 0 > $d.json 2> $d.err || { echo "pass $i failed"; tail -5 $d.err; }
 done
 cd $R
 python3 tools/pmc_agg.py gpurun_out/pmc_${tag}_ > gpurun_out/pmc_${tag}_summary.txt
