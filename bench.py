@@ -124,7 +124,7 @@ def cpu_baseline(params, batch, n_sample, npix, config):
 
 def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
     """Throughput of QFA.predict (reference model.py:160-180, loop main.py:94-98) on the resident batch and the HBM
-    roofline of its writer k_predict_out: algorithmic bytes per spectrum = 4 (2 N_pix + k^2 + k + 1) out
+    roofline of its writer (k_predict_x at N_h <= 16, k_predict_out above): algorithmic bytes per spectrum = 4 (2 N_pix + k^2 + k + 1) out
     + 9 N_pix + 4 N_b in; the writer itself moves 8 N_pix bytes per spectrum (cont + unc)."""
     import numpy as np
     import torch
@@ -158,8 +158,8 @@ def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
     by_writer = 8 * npix
     w_ms = float(st[2])
     return {"value": B / dt, "unit": "spectra/s", "ms_per_call": dt * 1e3, "spectra": B, "calls": n,
-            "stage_ms": {"images_and_pass1": float(st[0]), "solve": float(st[1]), "k_predict_out": w_ms},
-            "roofline": {"bound": "hbm", "kernel": "k_predict_out", "achieved": by_writer * B / (w_ms * 1e-3) / 1e9,
+            "stage_ms": {"images_and_pass1": float(st[0]), "solve": float(st[1]), "writer": w_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_predict_x" if nh <= 16 else "k_predict_out", "achieved": by_writer * B / (w_ms * 1e-3) / 1e9,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": by_writer * B / (w_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                          "alg_bytes_per_spectrum_writer": by_writer},

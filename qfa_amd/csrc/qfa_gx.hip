@@ -1,6 +1,7 @@
 // qfa_gx.hip -- pass 2 on the XDL pipe (qfa_grads_x.h) in its own translation unit: the kernel is large and
 // is iterated on separately from the rest of the library.
 #include "qfa_grads_x.h"
+#include "qfa_predict_x.h"
 
 #include "qfa_host.h"
 
@@ -14,6 +15,21 @@ void qfa_gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t 
         k_grads_x<true><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS);
     else
         k_grads_x<false><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS);
+}
+
+size_t qfa_px_image_bytes(int KP, int ntiles32) {
+    return (size_t)ntiles32 * (KP == 8 ? PX<8>::TILE_B : PX<16>::TILE_B);
+}
+
+void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int Nh, int ntiles32, const WorkPlan &wp,
+                   unsigned char *PXI, const float *SOL, float *cont, float *unc, hipStream_t st) {
+    if (KP == 8) {
+        k_prep_px<8><<<ntiles32, 256, 0, st>>>(F, Npix, Nh, PXI);
+        k_predict_x<8><<<wp.items(), 256, 0, st>>>(mu, B, Npix, ntiles32, wp, PXI, SOL, cont, unc);
+    } else {
+        k_prep_px<16><<<ntiles32, 256, 0, st>>>(F, Npix, Nh, PXI);
+        k_predict_x<16><<<wp.items(), 256, 0, st>>>(mu, B, Npix, ntiles32, wp, PXI, SOL, cont, unc);
+    }
 }
 
 #ifdef QFA_GX_STAMPS

@@ -14,6 +14,11 @@ void qfa_gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t 
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
                    double *slabS, hipStream_t st);
 
+// posterior writer for N_h <= 16 on the XDL pipe (qfa_predict_x.h, built in qfa_gx.hip)
+size_t qfa_px_image_bytes(int KP, int ntiles32);
+void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int Nh, int ntiles32, const WorkPlan &wp,
+                   unsigned char *PXI, const float *SOL, float *cont, float *unc, hipStream_t st);
+
 namespace {
 
 inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
@@ -56,7 +61,8 @@ struct Layout {
     int ntiles32;                                      // pass 1 on the XDL pipe walks 32-pixel tiles (N_h <= 16)
     WorkPlan wp1, wp2;                                 // work items of pass 1 / pass 2
     WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
-    size_t oPF, oPFT, oPFX, oPGX, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
+    WorkPlan wpp;                                      // posterior writer on the XDL pipe (k_predict_x, N_h <= 16)
+    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
 };
 
 template <int KP>
@@ -81,6 +87,12 @@ Layout make_layout_t(int B, int Npix) {
     if constexpr (KP == 16) {
         L.oPGX = take(qfa_gx_image_bytes(L.ntiles32) / 4);
         L.wp2x = plan_work(B, L.ntiles32, 3, 256);
+    }
+    L.oPXI = 0;
+    L.wpp = WorkPlan{0, 0, 1, 0};
+    if constexpr (KP <= 16) {
+        L.oPXI = take(qfa_px_image_bytes(KP, L.ntiles32) / 4);
+        L.wpp = plan_work(B, L.ntiles32, 1);
     }
     // moment records: segment 0 for every row, segments 1.. for the rows of the segmented blocks only
     L.oMOM = take(((size_t)L.Bpad + (size_t)(L.wp1.nseg - 1) * (L.Bpad - 64 * (size_t)L.wp1.full)) * C::NMOM);
@@ -233,7 +245,16 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     constexpr int G = 64 / KP;
     k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, ll, nullptr, B, Nh, hmean, hcov);
     mark(2);
-    k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);
+    bool writer_xdl = false;
+    if constexpr (KP <= 16) {
+        const char *e = std::getenv("QFA_PREDICT_F32");          // =1: the float32-MFMA writer (A/B timing, cross-check)
+        writer_xdl = !(e && e[0] == '1');
+    }
+    if (writer_xdl)
+        qfa_px_launch(KP, p.F, mu, B, Npix, Nh, L.ntiles32, L.wpp, reinterpret_cast<unsigned char *>(ws + L.oPXI), SOL, cont,
+                      unc, st);
+    else
+        k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);
     mark(3);
     return hip_status();
 }

@@ -1,0 +1,200 @@
+// qfa_predict_x.h -- posterior writer for N_h <= 16 on the XDL pipe: cont = F hmean + mu, unc = sqrt(f^T hcov f)
+// for ALL pixels of every spectrum (reference QFA/model.py:177-180).
+//
+// k_predict_out (qfa_step_kernels.h) issues [f^T hmean | f^T hcov f] as 38 v_mfma_f32_16x16x4_f32 per 16 x 16 outputs:
+// 1 216 cycles of the SIMD's float32 datapath per 2 KiB written, i.e. compute-bound at 17-22 % of the HBM write rate
+// (bench.py `predict`).  Here the same contraction is the six-term split-bf16 product of qfa_grads_x.h's stage 1
+// (v_mfma_f32_16x16x32_bf16, both operands static: [hmean | hcov'] of 16 spectra in 72 / 36 VGPRs, the tile image
+// [F^T | pair products] staged by LDS-DMA): 36 / 18 MFMAs of 16 cycles per 16 x 16 outputs.
+//   lane (lo = lane & 15, g = lane >> 4) owns pixels 32 t + 2 lo + h (h = 0, 1) of the spectra s0 + 4 g + r: one 8-byte
+//   store per spectrum row and array, 128 contiguous bytes per row and wave instruction.
+#pragma once
+#include "qfa_common.h"
+#include "qfa_xdl_kernels.h"
+
+template <int KP>
+struct PX {
+    static constexpr int KK2 = KP * (KP + 1) / 2;
+    static constexpr int NKS = 1 + (KK2 + 31) / 32;          // K-steps: [hmean, 0 | pair products]; 3 at KP = 8, 6 at 16
+    static constexpr int S1_HALF = NKS * 3 * 1024;           // bytes of one 16-pixel half: [K-step][piece][lane][8 k] bf16
+    static constexpr int TILE_B = 2 * S1_HALF;               // per 32-pixel tile
+    static constexpr int NCHUNK = TILE_B / 1024;
+};
+
+// image of one 32-pixel tile per block: B[k = 32 ks + 8 g + j][px = 2 lo + h] as three bf16 pieces
+template <int KP>
+__global__ __launch_bounds__(256) void k_prep_px(const float *__restrict__ F, int Npix, int Nh,
+                                                 unsigned char *__restrict__ PXI) {
+    using X = PX<KP>;
+    unsigned char *tile = PXI + (size_t)blockIdx.x * X::TILE_B;
+    const int p0 = 32 * blockIdx.x;
+    __shared__ float f[32][KP + 1];
+    for (int i = threadIdx.x; i < 32 * KP; i += 256) {
+        const int px = i / KP, a = i % KP;
+        f[px][a] = (p0 + px < Npix && a < Nh) ? F[(size_t)(p0 + px) * Nh + a] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * X::NKS * 64; i += 256) {
+        const int lane = i & 63, ks = (i >> 6) % X::NKS, h = i / (64 * X::NKS);
+        const int lo = lane & 15, g = lane >> 4, px = 2 * lo + h;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 8 * g + j;
+            float x = 0.f;
+            if (ks == 0) {
+                if (kk < KP) x = f[px][kk];
+            } else {
+                const int q = 32 * (ks - 1) + kk;
+                if (q < X::KK2) {
+                    int a = 0;
+                    while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
+                    const int b = a + (q - pair_index(a, a, KP));
+                    x = f[px][a] * f[px][b];
+                }
+            }
+            v[j] = x;
+        }
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b, c;
+            split2(v[2 * q], v[2 * q + 1], a, b, c);
+            ph[q] = a; pm[q] = b; pl[q] = c;
+        }
+        unsigned char *dst = tile + h * X::S1_HALF + ks * 3072 + lane * 16;
+        *reinterpret_cast<u32x4 *>(dst) = ph;
+        *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+        *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+    }
+}
+
+struct __attribute__((packed, aligned(4))) pxf2 { float v[2]; };       // 4-byte aligned 8-byte store
+
+// One work item = (block of 64 spectra, range of 32-pixel tiles); SOL as k_solve<KP, true> leaves it
+// ([hmean | hcov' with doubled off-diagonals]).
+template <int KP>
+__global__ __launch_bounds__(256, 2) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
+                                                      WorkPlan wp, const unsigned char *__restrict__ PXI,
+                                                      const float *__restrict__ SOL, float *__restrict__ cont,
+                                                      float *__restrict__ unc) {
+    using C = Cfg<KP>;
+    using X = PX<KP>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X::TILE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = wave_uniform(tid >> 6);
+    int blk, seg, t0, t1;
+    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
+    const int n = t1 - t0;
+    const int s0 = (blk * 4 + wv) * 16;
+    const bool active = s0 < B;
+    const int lo = lane & 15, g = lane >> 4;
+    // A operand: spectrum s0 + lo, k = 32 ks + 8 g + j
+    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::NKS];
+    {
+        const bool v = active && (s0 + lo) < B;
+        const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+#pragma unroll
+        for (int ks = 0; ks < X::NKS; ++ks) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = 8 * g + j;
+                float val = 0.f;
+                if (ks == 0) {
+                    if (v && kk < KP) val = sol[kk];
+                } else {
+                    const int q = 32 * (ks - 1) + kk;
+                    if (v && q < X::KK2) val = sol[C::SOL_CI + q];
+                }
+                x[j] = val;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned a, b, c;
+                split2(x[2 * q], x[2 * q + 1], a, b, c);
+                S1h[ks][q] = a; S1m[ks][q] = b; S1l[ks][q] = c;
+            }
+        }
+    }
+    const bool full_wave = active && s0 + 16 <= B;
+    auto get_tile = [&](int c) {
+        const unsigned char *src = PXI + (size_t)(t0 + c) * X::TILE_B;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(src);
+        const unsigned char *sbase = reinterpret_cast<const unsigned char *>(
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
+#pragma unroll
+        for (int i = 0; i < (X::NCHUNK + 3) / 4; ++i) {
+            const int ch = wv + 4 * i;
+            if (ch < X::NCHUNK)
+                glds16a(sbase + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(lds + (c & 1) * X::TILE_B + ch * 1024)));
+        }
+    };
+    if (n > 0) get_tile(0);
+    dma_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int c = 0; c < n; ++c) {
+        if (c + 1 < n) get_tile(c + 1);
+        bool counted = false;
+        if (active) {
+            const int tg = t0 + c;
+            const unsigned char *img = lds + (c & 1) * X::TILE_B;
+            float co[2][4], un[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned char *bp = img + h * X::S1_HALF + lane * 16;
+                f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+                u32x4 bq[2][3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
+#pragma unroll
+                for (int ks = 0; ks < X::NKS; ++ks) {
+                    if (ks + 1 < X::NKS) {
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
+                    }
+                    const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
+                    if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
+                    else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
+                }
+                const float m = mu[min(32 * tg + 2 * lo + h, Npix - 1)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    co[h][r] = afy[r] + m;
+                    un[h][r] = __builtin_amdgcn_sqrtf(aq[r]);
+                }
+            }
+            const int px = 32 * tg + 2 * lo;
+            if (full_wave && 32 * tg + 31 < Npix) {          // wave-uniform: exactly eight store instructions
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = (size_t)(s0 + 4 * g + r) * Npix + px;
+                    *reinterpret_cast<pxf2 *>(cont + o) = pxf2{{co[0][r], co[1][r]}};
+                    *reinterpret_cast<pxf2 *>(unc + o) = pxf2{{un[0][r], un[1][r]}};
+                }
+                counted = true;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = s0 + 4 * g + r;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (s < B && px + h < Npix) {
+                            cont[(size_t)s * Npix + px + h] = co[h][r];
+                            unc[(size_t)s * Npix + px + h] = un[h][r];
+                        }
+                    }
+                }
+            }
+        }
+        // the image pieces of tile c + 1 were issued before this step's stores: all but the eight stores must be done
+        if (counted) dma_wait<8>();
+        else dma_wait<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}

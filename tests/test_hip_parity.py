@@ -555,3 +555,28 @@ def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B):
             assert abs(a[0] - r[0]) <= 2e-4 * abs(r[0]) + 1e-6, (name, a, r)
         else:
             assert rel_l2(a, r) < 5e-5, (name, rel_l2(a, r))
+
+
+@pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 7, 33), (1000, 12, 130), (1913, 8, 50), (33, 3, 17)])
+def test_predict_writer_xdl_matches_f32_writer(dev, npix, nh, B, monkeypatch):
+    """cont / unc of N_h <= 16 come from k_predict_x (split-bf16 products on the XDL pipe); QFA_PREDICT_F32=1 selects
+    the float32-MFMA writer k_predict_out: same values to float32 rounding on ragged shapes, both against the oracle."""
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=npix + nh)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=5 * npix + nh)
+    m = make_model(dev, p, mu)
+    bt = batch_t(b, dev, "flux")
+    monkeypatch.delenv("QFA_PREDICT_F32", raising=False)
+    ll, hm, hc, cont, unc = [x.cpu().numpy() for x in m.predict(*bt)]
+    monkeypatch.setenv("QFA_PREDICT_F32", "1")
+    ll2, hm2, hc2, cont2, unc2 = [x.cpu().numpy() for x in m.predict(*bt)]
+    monkeypatch.delenv("QFA_PREDICT_F32", raising=False)
+    assert np.array_equal(ll, ll2) and np.array_equal(hm, hm2)
+    assert np.max(np.abs(cont - cont2)) <= 2e-6 * np.max(np.abs(cont2))
+    assert np.max(np.abs(unc - unc2)) <= 5e-6 * np.max(np.abs(unc2))
+    for s in (0, B // 2, B - 1):
+        o = O.predict_single(p, mu, b["flux"][s], b["error"][s], b["zabs"][s], b["mask"][s])
+        assert np.max(np.abs(cont[s] - o[3])) / np.max(np.abs(o[3])) < 1e-4
+        assert rel_l2(unc[s], o[4]) < 1e-4
