@@ -15,12 +15,17 @@ from tools import parity_sections as PS
 
 pytestmark = pytest.mark.gpu
 
-# one big launch vs float64 sum of 512-spectrum launches
-TOL_SECTION = {"accF": 2e-5, "sumA": 5e-6, "gPsi": 5e-6, "gOmega": 5e-6, "g_tau0": 5e-5, "g_c0": 5e-5,
-               "g_beta": 5e-5, "sum_nll": 2e-6, "nll_per_spectrum_max_rel": 3e-6}
-# sampled sub-batch vs float64 oracle
-TOL_ORACLE = {"loss": 2e-6, "nll_per_spectrum_max_rel": 1e-5, "F": 1e-4, "Psi": 2e-5, "omega": 2e-5, "tau0": 5e-5,
-              "c0": 5e-5, "beta": 5e-5}
+# one big launch vs float64 sum of 512-spectrum launches (achieved, profiles/r2_accuracy.txt: accF 1.3e-5 at N_h = 32,
+# 4e-6 at c3; per-pixel sums <= 3e-6; scalar gradients <= 1e-5; per-spectrum NLL: 1e-6 in L2, the worst single spectrum
+# of 100 000 at 1.9e-5 -- a spectrum's NLL is a difference of terms ten times its size and the two launches sum the
+# pixel axis in different segmentations)
+TOL_SECTION = {"accF": 3e-5, "sumA": 3e-6, "gPsi": 1e-5, "gOmega": 1e-5, "g_tau0": 3e-5, "g_c0": 3e-5,
+               "g_beta": 3e-5, "sum_nll": 1e-6, "nll_per_spectrum_rel_l2": 3e-6, "nll_per_spectrum_max_rel": 5e-5}
+# sampled sub-batch vs float64 oracle (achieved: loss 2e-7, per-spectrum NLL <= 2.6e-6, F <= 3.4e-5, Psi/omega <= 4.4e-6).
+# The three scalar gradients of data drawn from the model itself are sums of cancelling terms (the expected gradient is
+# zero): their error is bounded against what the float32 numpy oracle achieves on the same sub-batch.
+TOL_ORACLE = {"loss": 2e-6, "nll_per_spectrum_max_rel": 5e-6, "F": 1e-4, "Psi": 2e-5, "omega": 2e-5}
+SCALAR_VS_NP32 = 6.0
 
 
 @pytest.fixture(scope="module")
@@ -54,6 +59,8 @@ def run_config(dev, npix, nh, B, masks, seed, n_oracle, tol_oracle=None):
         assert oe["nan_pattern_" + k], k
     for name, tol in tol_oracle.items():
         assert oe[name] < tol, (name, oe[name], tol)
+    for k in ("tau0", "c0", "beta"):
+        assert oe[k] < max(5e-5, SCALAR_VS_NP32 * oe[k + "_np32"]), (k, oe[k], oe[k + "_np32"])
     del batch
     torch.cuda.empty_cache()
 

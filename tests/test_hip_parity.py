@@ -1,9 +1,14 @@
 """GPU parity: the HIP path, called through the C-ABI behind the reference's Python surface,
 against the golden fixtures of the imported reference and against the CPU oracle on the same
-seeded inputs.  Tolerances (float32 HIP vs float64 oracle / float32 reference):
-  NLL / loss 1e-5 rel (north_star), posterior continuum 1e-4 rel (north_star),
-  gradients 2e-4 rel-L2 (F), 5e-5 (Psi, omega), 2e-4 (tau0/c0/beta: sums of sign-alternating
-  per-pixel terms, the float32 reference itself sits 1e-5 off float64), hmean/hcov 1e-4.
+seeded inputs.  Tolerances (float32 HIP vs float64 oracle / float32 reference), with the achieved maxima of the
+shipped build in profiles/r2_accuracy.txt:
+  NLL per spectrum and batch loss 5e-6 rel (north_star asks 1e-5; achieved <= 2.6e-6),
+  posterior continuum 1e-4 rel (north_star; achieved 4e-7),
+  gradients 1e-4 rel-L2 (F; achieved <= 3.6e-5 up to N_pix = 8000, N_h = 32), 2e-5 (Psi, omega; achieved <= 6e-6),
+  2e-4 (tau0 / c0 / beta: sums of cancelling per-pixel terms -- 1.3e-5 on generic batches, 1.8e-4 on the 8-spectrum
+  golden batch with a red-only spectrum; a build with libm-grade exp/log/division gives the same numbers
+  (profiles/r2_accuracy_precise_math.txt), so the float32 summation order is the responsible term, not the hardware
+  transcendentals), hmean/hcov 1e-4.
 Continuum error is measured as max|err| / max|cont| (the mock continua cross zero)."""
 import numpy as np
 import pytest
@@ -13,8 +18,8 @@ from conftest import golden, rel_l2
 pytestmark = pytest.mark.gpu
 
 KEYS = ("F", "Psi", "omega", "tau0", "c0", "beta")
-TOL_NLL = 1e-5
-TOL_G = {"F": 2e-4, "Psi": 5e-5, "omega": 5e-5, "tau0": 2e-4, "c0": 2e-4, "beta": 2e-4}
+TOL_NLL = 5e-6
+TOL_G = {"F": 1e-4, "Psi": 2e-5, "omega": 2e-5, "tau0": 2e-4, "c0": 2e-4, "beta": 2e-4}
 
 
 @pytest.fixture(scope="module")
@@ -270,7 +275,11 @@ def test_blue_red_boundary_layouts(dev, npix, nb, nh, B):
     loss, gr = m._finalize(acc, True)
     oloss, ogr = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
     per = np.array([O.nll_and_grads_single(p, b["delta"][s], b["error"][s], b["zabs"][s], b["mask"][s])[0] for s in range(B)])
-    assert np.all(np.abs(nll.cpu().numpy() - per) <= TOL_NLL * np.abs(per))      # (a fully masked spectrum: exactly 0)
+    # (a fully masked spectrum: exactly 0.)  An NLL is a sum of terms of order one per unmasked pixel that can cancel
+    # to almost nothing on these 30-pixel spectra (one here is -0.096): the tolerance is relative to the larger of
+    # |NLL| and the pixel count
+    scale = np.maximum(np.abs(per), 0.5 * b["mask"].sum(axis=1))
+    assert np.all(np.abs(nll.cpu().numpy() - per) <= TOL_NLL * scale)
     assert abs(loss.item() - oloss) / abs(oloss) < TOL_NLL
     for k in KEYS:
         ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
@@ -428,7 +437,7 @@ def test_full_size_properties_config3_shape(dev):
     for k in KEYS:
         ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
         ok = ~np.isnan(ref)
-        assert rel_l2(ours[ok], ref[ok]) < (5e-4 if k == "F" else TOL_G[k]), k
+        assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
 
 
 @pytest.mark.parametrize("nh,B", [(16, 33280 + 37), (8, 65536 + 64 * 5 + 3), (20, 512 * 64 + 1)])
@@ -484,7 +493,7 @@ def test_tolerance_sweep_float64_oracle_vs_float32_hip(dev, npix, nh):
         ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
         ok = ~np.isnan(ref)
         assert np.array_equal(np.isnan(ours), np.isnan(ref)), k
-        assert rel_l2(ours[ok], ref[ok]) < (5e-4 if k == "F" else TOL_G[k]), k
+        assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
     ll, hm, hc, cont, unc = [x.cpu().numpy() for x in m.predict(*batch_t(b, dev, "flux"))]
     for s in (0, B - 1):
         o = O.predict_single(p, mu, b["flux"][s], b["error"][s], b["zabs"][s], b["mask"][s])

@@ -60,7 +60,8 @@ def full(npix, nh, B, masks, seed, n_oracle):
     idx = torch.tensor(np.sort(rng.choice(B, size=n_oracle, replace=False)), device=dev)
     oe = PS.oracle_subbatch_errors(m, p, batch, idx)
     print(f"   oracle (float64) on {n_oracle} sampled spectra as their own launch: " +
-          "  ".join(f"{k} {v:.1e}" for k, v in oe.items() if isinstance(v, float)), flush=True)
+          "  ".join(f"{k} {v:.1e}" for k, v in oe.items() if isinstance(v, float) and not k.endswith("_np32")))
+    print("      (float32 numpy oracle vs float64, same sub-batch: " + "  ".join(f"{k[:-5]} {v:.1e}" for k, v in oe.items() if k.endswith("_np32")) + ")", flush=True)
     del batch
     torch.cuda.empty_cache()
 

@@ -68,13 +68,16 @@ def section_errors(model, batch, chunk=512):
         else:
             out[name] = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
     n1, n2 = nll.cpu().numpy().astype(np.float64), nll_c.cpu().numpy().astype(np.float64)
-    out["nll_per_spectrum_max_rel"] = float(np.max(np.abs(n1 - n2) / np.abs(n2)))
+    out["nll_per_spectrum_max_rel"] = float(np.max(np.abs(n1 - n2) / np.abs(n2)))      # worst of B spectra
+    out["nll_per_spectrum_rel_l2"] = float(np.linalg.norm(n1 - n2) / np.linalg.norm(n2))
     out["finite"] = bool(np.isfinite(big).all())
     return out
 
 
 def oracle_subbatch_errors(model, p, batch, idx):
-    """normalised gradients + loss + per-spectrum NLL of the sub-batch `idx` (its own launch) vs the float64 oracle"""
+    """normalised gradients + loss + per-spectrum NLL of the sub-batch `idx` (its own launch) vs the float64 oracle.
+    Keys "<k>_np32": the same error for the oracle evaluated in float32 numpy -- the yardstick for gradients that are
+    sums of strongly cancelling terms (the three scalar gradients on data drawn from the model itself)."""
     from oracle import qfa_oracle as O
     d, e, z, mk = (x[idx] for x in batch)
     n = d.shape[0]
@@ -83,15 +86,18 @@ def oracle_subbatch_errors(model, p, batch, idx):
     loss, gr = model._finalize(acc, True)
     dn, en, zn, mn = (x.cpu().numpy() for x in (d, e, z, mk))
     per = np.empty(n)
-    sums = counts = None
+    sums = counts = sums32 = None
     for s in range(n):
         per[s], g = O.nll_and_grads_single(p, dn[s], en[s], zn[s], mn[s])
+        _, g32 = O.nll_and_grads_single(p, dn[s], en[s], zn[s], mn[s], dtype=np.float32)
         if sums is None:
             sums = {k: np.zeros_like(v) for k, v in g.items()}
             counts = {k: np.zeros_like(v) for k, v in g.items()}
+            sums32 = {k: np.zeros_like(v) for k, v in g32.items()}
         for k in g:
             sums[k] += g[k]
             counts[k] += (g[k] != 0.0)
+            sums32[k] += g32[k]
     out = {"loss": float(abs(loss.item() - per.mean()) / abs(per.mean())),
            "nll_per_spectrum_max_rel": float(np.max(np.abs(nll.cpu().numpy() - per) / np.abs(per)))}
     with np.errstate(invalid="ignore", divide="ignore"):
@@ -101,4 +107,6 @@ def oracle_subbatch_errors(model, p, batch, idx):
             ok = ~np.isnan(ref)
             out["nan_pattern_" + k] = bool(np.array_equal(np.isnan(ours), np.isnan(ref)))
             out[k] = float(np.linalg.norm(ours[ok] - ref[ok]) / max(np.linalg.norm(ref[ok]), 1e-300))
+            r32 = (sums32[k] / counts[k]).astype(np.float64)
+            out[k + "_np32"] = float(np.linalg.norm(r32[ok] - ref[ok]) / max(np.linalg.norm(ref[ok]), 1e-300))
     return out
