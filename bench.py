@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain", type=float, default=3.0, help="seconds of extra steps after the timed region (0 = skip)")
     ap.add_argument("--no-predict", action="store_true")
+    ap.add_argument("--deterministic", action="store_true", help="fixed-order accumulation (model.deterministic)")
     args = ap.parse_args()
 
     import numpy as np
@@ -216,6 +217,7 @@ def main():
     torch.cuda.empty_cache()
 
     model = QFA(nb, nr, nh, dev, model_params=params)
+    model.deterministic = bool(args.deterministic)
     model.mu = torch.tensor(mu, device=dev)
     if use_dist:
         model.enable_data_parallel()

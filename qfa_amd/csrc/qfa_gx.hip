@@ -32,8 +32,8 @@ void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int
     }
 }
 
-#ifdef QFA_GX_STAMPS
+#if QFA_GX_STAMPS
 extern "C" int qfa_gx_debug_stamps(unsigned long long *out) {      // diagnostic build only
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qfa_gx_stamps), 32 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qfa_gx_stamps), 64 * sizeof(unsigned long long));
 }
 #endif

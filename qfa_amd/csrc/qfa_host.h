@@ -30,9 +30,9 @@ inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
 // tiles per item while the chip stays at most half full (the step of a small batch is latency-bound).
 constexpr int kMaxSeg = 32;
 
-inline WorkPlan plan_work(int B, int ntiles, int pro, int slots = 256 * 2) {
-    // slots = CUs x resident workgroups per CU (2 for the 256-thread kernels, 1 for the 512-thread k_grads_x)
-    const int nblk = (B + 63) / 64;
+inline WorkPlan plan_work(int B, int ntiles, int pro, int slots = 256 * 2, int spb = 64) {
+    // slots = CUs x resident workgroups per CU; spb = spectra per block (64; 32 for k_grads_x)
+    const int nblk = (B + spb - 1) / spb;
     WorkPlan best{0, nblk, 1, ntiles};
     double best_cost = 1e300;
     for (int full = (nblk / slots) * slots; full >= 0; full -= slots) {       // whole rounds kept unsegmented
@@ -86,7 +86,7 @@ Layout make_layout_t(int B, int Npix) {
     L.wp2x = WorkPlan{0, 0, 1, 0};
     if constexpr (KP == 16) {
         L.oPGX = take(qfa_gx_image_bytes(L.ntiles32) / 4);
-        L.wp2x = plan_work(B, L.ntiles32, 3, 256);
+        L.wp2x = plan_work(B, L.ntiles32, 3, 256, 64);
     }
     L.oPXI = 0;
     L.wpp = WorkPlan{0, 0, 1, 0};
@@ -174,11 +174,12 @@ void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t
 
 // deterministic mode: slab = [nblk rows of NF floats | scalar sums: (max items) x 4 waves x 3 doubles]
 inline size_t det_rows_floats(int Npix, int Nb, int Nh) { return (size_t)Npix * Nh + 3 * (size_t)Npix + Nb; }
+// rows: one per block of 64 spectra (both pass-2 forms)
+inline size_t det_rows(int B, int Nh) { (void)Nh; return (size_t)((B + 63) / 64); }
 inline size_t det_slab_bytes(int B, int Npix, int Nb, int Nh) {
     const Layout L = make_layout(B, Npix, Nh);
-    const size_t nblk = (size_t)(B + 63) / 64;
     const size_t items = (size_t)(L.wp2.items() > L.wp2x.items() ? L.wp2.items() : L.wp2x.items());
-    return (nblk * det_rows_floats(Npix, Nb, Nh) * sizeof(float) + 15) / 16 * 16 + items * 4 * 3 * sizeof(double);
+    return (det_rows(B, Nh) * det_rows_floats(Npix, Nb, Nh) * sizeof(float) + 15) / 16 * 16 + items * 4 * 3 * sizeof(double);
 }
 
 template <int KP>
@@ -188,7 +189,8 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     const size_t NF = det_rows_floats(Npix, Nb, Nh);
     const int nblk = (B + 63) / 64;
     float *slab = reinterpret_cast<float *>(slabv);
-    double *slabS = slab ? reinterpret_cast<double *>(reinterpret_cast<char *>(slab) + ((size_t)nblk * NF * sizeof(float) + 15) / 16 * 16)
+    double *slabS = slab ? reinterpret_cast<double *>(reinterpret_cast<char *>(slab) +
+                                                      (det_rows(B, Nh) * NF * sizeof(float) + 15) / 16 * 16)
                          : nullptr;
     float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL, *NBL = ws + L.oNBL;
     float *nllbuf = nll ? nll : ws + L.oNLL;
@@ -212,7 +214,8 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         qfa_gx_launch(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
                       accum, slab, slabS, st);
         if (slab)
-            k_reduce_slab<<<(unsigned)((NF + 255) / 256), 256, 0, st>>>(slab, slabS, nblk, L.wp2x.items() * 4, NF, accum);
+            k_reduce_slab<<<(unsigned)((NF + 255) / 256), 256, 0, st>>>(slab, slabS, (B + 63) / 64, L.wp2x.items() * 4, NF,
+                                                                        accum);
         mark(4);
         return hip_status();
     }
