@@ -98,11 +98,16 @@ __device__ __forceinline__ f32x16 xdl32(const u32x4 &a, const u32x4 &b, f32x16 c
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
                                                    0);
 }
+#ifndef QFA_GX_S3_TERMS
+#define QFA_GX_S3_TERMS 4      // bf16 piece products per stage-3 contraction: 6 (|error| ~ 2^-24) or 4 (~ 2^-17, see header)
+#endif
 __device__ __forceinline__ f32x16 xdl32_6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
                                           const u32x4 &bm, const u32x4 &bl, f32x16 c) {
-    c = xdl32(al, bh, c);
-    c = xdl32(ah, bl, c);
-    c = xdl32(am, bm, c);
+    if (QFA_GX_S3_TERMS == 6) {
+        c = xdl32(al, bh, c);
+        c = xdl32(ah, bl, c);
+    }
+    if (QFA_GX_S3_TERMS >= 4) c = xdl32(am, bm, c);
     c = xdl32(am, bh, c);
     c = xdl32(ah, bm, c);
     return xdl32(ah, bh, c);
@@ -217,7 +222,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                                                     int Nh, int ntiles, WorkPlan wp,
                                                     const unsigned char *__restrict__ PGX,
                                                     const float *__restrict__ SOL, float *__restrict__ accum,
-                                                    float *__restrict__ slab, double *__restrict__ slabS) {
+                                                    float *__restrict__ slab, double *__restrict__ slabS,
+                                                    int slab_stride) {
     using C = Cfg<16>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GX::L_TOTAL];
     const int tid = threadIdx.x;
@@ -240,13 +246,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     const bool det = slab != nullptr;
-    float *accF = det ? slab + (size_t)blk * ((size_t)Npix * Nh + 3 * (size_t)Npix + Nb) : accum;
+    float *accF = det ? slab + (size_t)blk * (size_t)slab_stride : accum;
     float *accA = accF + (size_t)Npix * Nh;                // sumA | gPsi | gOmega | cnt (contiguous)
     float *accS = accum + (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
-    auto add_to = [&](float *q, float v) {
-        if (det) *q = v;                                   // every (block, tile) element is written exactly once
-        else atomicAdd(q, v);
-    };
 
     // zero the slots that inactive groups never write
     for (int i = tid; i < (GX::L_SCAL - GX::L_BETA) / 4; i += 512) reinterpret_cast<float *>(lds + GX::L_BETA)[i] = 0.f;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 
 #ifndef QFA_GX_ABL
 #define QFA_GX_ABL 0       // timing-only ablations (wrong results): 1 no spectra staging, 2 no flush, 4 no image DMA,
-#endif                     // 8 the staging re-reads the first tile (cache hits)
+#endif                     // 8 the staging re-reads the first tile (cache hits), 16 zabs staged from the delta rows (16-byte aligned)
 #ifndef QFA_GX_STAGE_MID
 #define QFA_GX_STAGE_MID 1
 #endif
@@ -340,8 +342,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             if (QFA_GX_ABL & 8) tg = t0;
             const bool zblue = tg < nbt;                                                      // wave-uniform
             const bool fastp = 32 * tg + 31 < Npix, fastz = !zblue || 32 * tg + 31 < Nb;
-            const float *zb = zblue ? zbase : dbase;
-            const int zlen = zblue ? Nb : Npix;
+            const float *zb = (zblue && !(QFA_GX_ABL & 16)) ? zbase : dbase;
+            const int zlen = (zblue && !(QFA_GX_ABL & 16)) ? Nb : Npix;
             const unsigned dst = wave_uniform(lds_addr(stg + par * GX::STG_B));
             if (fastp) {
 #pragma unroll
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 else if (c + 1 < n && cnt_other == 8) dma_wait<8>();
                 else if (c + 1 < n && cnt_other == 14) dma_wait<14>();
                 else dma_wait<0>();
+                if (tg < nbt) { GXS(5) } else { GXS(21) }
                 take_tile(c & 1, cur);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging buffer read: it may be overwritten now
                 __builtin_amdgcn_sched_barrier(0);
@@ -635,41 +638,56 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                             wave_uniform(lds_addr(fp + (ch - GX::NCH_HALF) * 1024)));
             }
         };
-        // Every lane of a flushing wave issues its request (a lane outside the arrays adds 0 to an element inside them,
-        // a different one for each lane -- 195 000 tile-steps adding to ONE spare address took 50 ms): the number of
-        // requests per wave is then a constant, which the counted wait below needs.
-        auto flush_to = [&](float *q, float v, bool ok) {
-            if (det) {
-                if (ok) *q = v;            // (deterministic mode waits for everything: no counted wait there)
-            } else atomicAdd(q, v);
-        };
-        // tile tg leaves the workgroup: role B's 256 threads sum the four groups' partials (fixed order) and add them to
-        // the packed buffer, two outputs each: a wave's 64 lanes cover 4 pixel rows = 256 contiguous bytes at N_h = 16
+        // Every lane of a flushing wave issues its request: the number of requests per wave is then a constant, which
+        // the counted wait below needs.  Default mode (float atomics): a lane outside the arrays adds 0 to an element
+        // inside them, a different one for each lane (195 000 tile-steps adding to ONE spare address took 50 ms).
+        // Deterministic mode (plain stores into the block's slab row, every element written exactly once): such a lane
+        // stores into the 64 spare floats at the end of the row.
+        float *sink = accF + (slab_stride - 64) + lane;
+        // tile tg leaves the workgroup: role B sums the four groups' partials (fixed order) and adds them to the packed
+        // buffer.  Default: 256 threads, two outputs each (a wave's 64 lanes cover 4 pixel rows = 256 contiguous bytes
+        // at N_h = 16).  Deterministic with N_h a multiple of 4: waves 0 and 1, one 16-byte store per thread.
+        const bool wide = det && (Nh & 3) == 0;
         auto flush_F = [&](int tg, int par) {
             if (QFA_GX_ABL & 2) return;
             const float *pp = reinterpret_cast<const float *>(lds + GX::L_PART + par * GX::NG * 2048);
+            if (wide) {
+                if (tidB >= 128) return;                                              // wave-uniform
+                const int px = 32 * tg + (tidB >> 2), b4 = 4 * (tidB & 3);
+                const float4 *q4 = reinterpret_cast<const float4 *>(pp + (tidB >> 2) * 16 + b4);
+                const float4 v0 = q4[0], v1 = q4[128], v2 = q4[256], v3 = q4[384];
+                const float4 v = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
+                                  (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w)};
+                const bool ok = (b4 < Nh) & (px < Npix);
+                if (ok) *reinterpret_cast<float4 *>(accF + (size_t)px * Nh + b4) = v;
+                else *sink = v.x;
+                return;
+            }
 #pragma unroll
             for (int k4 = 0; k4 < 2; ++k4) {
                 const int o = tidB + 256 * k4;
                 const float v = (pp[o] + pp[512 + o]) + (pp[1024 + o] + pp[1536 + o]);
                 const int px = 32 * tg + (o >> 4), bb = o & 15;
                 const bool ok = (bb < Nh) & (px < Npix);
-                flush_to(accF + (size_t)min(px, Npix - 1) * Nh + (bb < Nh ? bb : bb - Nh), ok ? v : 0.f, ok);
+                if (det) *(ok ? accF + (size_t)px * Nh + bb : sink) = v;
+                else atomicAdd(accF + (size_t)min(px, Npix - 1) * Nh + (bb < Nh ? bb : bb - Nh), ok ? v : 0.f);
             }
         };
-        // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = tidB >> 5, pxl = tidB & 31)
+        // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = t >> 5, pxl = t & 31) of 128 -- waves
+        // 0 and 1, or waves 2 and 3 when the F sums go out as 16-byte stores (one request per wave and tile then)
         auto flush_P = [&](int tg, int par) {
             if (QFA_GX_ABL & 2) return;
-            if (tidB >= 128) return;
-            const int which = tidB >> 5, pxl = tidB & 31;
+            if (wide ? tidB < 128 : tidB >= 128) return;                              // wave-uniform
+            const int which = (tidB >> 5) & 3, pxl = tidB & 31;
             const float *q = reinterpret_cast<const float *>(lds + GX::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
             const float v = (q[0] + q[128]) + (q[256] + q[384]);
             const int px = 32 * tg + pxl;
             const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
-            // (a red pixel's lane of the gOmega group adds 0 to the pixel's count instead)
+            // (default mode: a red pixel's lane of the gOmega group adds 0 to the pixel's count instead)
             const int pxc = min(px, Npix - 1);
             const int offc = (which == 2 && pxc >= Nb) ? 2 * Npix + Nb + pxc : which * Npix - (which == 3 ? Npix - Nb : 0) + pxc;
-            flush_to(accA + offc, ok ? v : 0.f, ok);
+            if (det) *(ok ? accA + offc : sink) = v;
+            else atomicAdd(accA + offc, ok ? v : 0.f);
         };
         // stage 3 of tile c, in two parts (the two half-steps of tile c + 1; balanced, so that neither half-step waits for
         // this role): part 0 = the gamma term and the spectrum pairs 0..3, part 1 = pairs 4..7, added to part 0's sums
@@ -736,7 +754,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 // The image DMA first, the flushes behind it, and a wait that leaves exactly the flushes in flight: they
                 // are device-scope atomics with a long round trip, and have until the end of the NEXT half-step.
                 if (t + 1 < 2 * n) get_half(t + 1);
-                const bool fp_ = h == 0 && c >= 1 && c <= n && tidB < 128, ff_ = h == 0 && c >= 2;   // wave-uniform
+                // requests of this wave's flushes (wave-uniform): F 2 (one as a 16-byte store, waves 0 and 1), P 1
+                const bool wP = wide ? tidB >= 128 : tidB < 128, wF = !wide || tidB < 128;
+                const int nreq = (h == 0 && c >= 1 && c <= n && wP ? 1 : 0) + (h == 0 && c >= 2 && wF ? (wide ? 1 : 2) : 0);
                 if (h == 0) {
                     if (c >= 1 && c <= n) flush_P(tile_of(c - 1), (c - 1) & 1);
                     if (c >= 2) flush_F(tile_of(c - 2), c & 1);
@@ -747,10 +767,10 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     else tileB(c - 1, std::integral_constant<int, 1>{});
                 }
                 GXS(8 * h + 1)
-                if (det) dma_wait<0>();
-                else if (fp_ && ff_) dma_wait<3>();
-                else if (ff_) dma_wait<2>();
-                else if (fp_) dma_wait<1>();
+                if (QFA_GX_ABL & 2) dma_wait<0>();
+                else if (nreq == 3) dma_wait<3>();
+                else if (nreq == 2) dma_wait<2>();
+                else if (nreq == 1) dma_wait<1>();
                 else dma_wait<0>();
                 GXS(8 * h + 2)
                 step_barrier();

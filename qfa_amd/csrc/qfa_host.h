@@ -12,7 +12,7 @@
 size_t qfa_gx_image_bytes(int ntiles32);
 void qfa_gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
-                   double *slabS, hipStream_t st);
+                   double *slabS, int slab_stride, hipStream_t st);
 
 // posterior writer for N_h <= 16 on the XDL pipe (qfa_predict_x.h, built in qfa_gx.hip)
 size_t qfa_px_image_bytes(int KP, int ntiles32);
@@ -117,15 +117,15 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
     return 0;
 }
 
-// Which form of pass 2 runs at N_h = 9..16: 0 = the float32-MFMA form with stage 3 on the XDL pipe (k_grads), 1 = the
-// all-XDL two-role form (k_grads_x).  Default (measured at c3 on MI355X, profiles/r2_ablation_k_grads_x.txt): k_grads is
-// faster there (3.25 vs 3.5 ms), k_grads_x is the one that is bit-reproducible under the deterministic slab mode, so
-// it serves that mode.  QFA_PASS2_XDL=1 / QFA_PASS2_XDL=0 in the environment force one form (A/B timing, and the
-// cross-check of the two forms in tests/); read at every call, nothing is cached.
-inline bool pass2_use_xdl(bool deterministic) {
+// Which form of pass 2 runs at N_h = 9..16: 1 = the all-XDL two-role form (k_grads_x, the default: 2.4-2.6 ms at c3
+// against 3.2 for the other, and no slower at any batch size down to 64 spectra -- profiles/r2_ablation_k_grads_x.txt),
+// 0 = the float32-MFMA form with stage 3 on the XDL pipe (k_grads, the form N_h <= 8 and N_h = 17..32 still use).
+// QFA_PASS2_XDL=0 / 1 in the environment forces one form (A/B timing and the cross-check of the two forms in tests/);
+// read at every call, nothing is cached.
+inline bool pass2_use_xdl() {
     const char *e = std::getenv("QFA_PASS2_XDL");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    return deterministic;
+    return true;
 }
 
 inline int hip_status() {
@@ -172,26 +172,51 @@ void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t
     }
 }
 
-// deterministic mode: slab = [nblk rows of NF floats | scalar sums: (max items) x 4 waves x 3 doubles]
+// deterministic mode: slab = [nblk rows of det_row_stride floats | scalar sums: (max items) x 4 waves x 3 doubles |
+//                             float64 partial sums of the reducer: det_chunks x NF]
+// A row holds the NF = Npix Nh + 3 Npix + Nb sums of one block of 64 spectra, padded to a multiple of 4 floats (16-byte
+// stores), plus 64 floats that lanes outside the arrays write to (every lane of a flushing wave stores: the counted
+// wait in k_grads_x needs a constant number of requests per wave).
 inline size_t det_rows_floats(int Npix, int Nb, int Nh) { return (size_t)Npix * Nh + 3 * (size_t)Npix + Nb; }
-// rows: one per block of 64 spectra (both pass-2 forms)
-inline size_t det_rows(int B, int Nh) { (void)Nh; return (size_t)((B + 63) / 64); }
-inline size_t det_slab_bytes(int B, int Npix, int Nb, int Nh) {
+inline size_t det_row_stride(int Npix, int Nb, int Nh) { return (det_rows_floats(Npix, Nb, Nh) + 3) / 4 * 4 + 64; }
+inline size_t det_rows(int B) { return (size_t)((B + 63) / 64); }
+constexpr int DET_CHUNK_ROWS = QFA_DET_CHUNK_ROWS;   // rows summed by one thread of the reducer's first stage
+inline size_t det_chunks(int B) { return (det_rows(B) + DET_CHUNK_ROWS - 1) / DET_CHUNK_ROWS; }
+struct DetLayout {
+    size_t NF, stride, oS, oPart, bytes;      // offsets in bytes
+};
+inline DetLayout det_layout(int B, int Npix, int Nb, int Nh) {
     const Layout L = make_layout(B, Npix, Nh);
     const size_t items = (size_t)(L.wp2.items() > L.wp2x.items() ? L.wp2.items() : L.wp2x.items());
-    return (det_rows(B, Nh) * det_rows_floats(Npix, Nb, Nh) * sizeof(float) + 15) / 16 * 16 + items * 4 * 3 * sizeof(double);
+    DetLayout D;
+    D.NF = det_rows_floats(Npix, Nb, Nh);
+    D.stride = det_row_stride(Npix, Nb, Nh);
+    D.oS = (det_rows(B) * D.stride * sizeof(float) + 15) / 16 * 16;
+    D.oPart = D.oS + (items * 4 * 3 * sizeof(double) + 15) / 16 * 16;
+    D.bytes = D.oPart + det_chunks(B) * D.NF * sizeof(double);
+    return D;
+}
+inline size_t det_slab_bytes(int B, int Npix, int Nb, int Nh) { return det_layout(B, Npix, Nb, Nh).bytes; }
+
+// the fixed-order reduction of the slab into the packed buffer: rows in chunks of DET_CHUNK_ROWS (float64 partials,
+// rows in order), then the chunks in order
+inline void launch_reduce_slab(const float *slab, const DetLayout &D, int B, int nitemwaves, float *accum, hipStream_t st) {
+    const double *slabS = reinterpret_cast<const double *>(reinterpret_cast<const char *>(slab) + D.oS);
+    double *part = reinterpret_cast<double *>(const_cast<char *>(reinterpret_cast<const char *>(slab)) + D.oPart);
+    const int nblk = (int)det_rows(B), nch = (int)det_chunks(B);
+    const unsigned gx = (unsigned)((D.NF + 255) / 256);
+    k_reduce_slab_rows<<<dim3(gx, (unsigned)nch), 256, 0, st>>>(slab, nblk, D.NF, D.stride, part);
+    k_reduce_slab_fin<<<gx, 256, 0, st>>>(part, slabS, nch, nitemwaves, D.NF, accum);
 }
 
 template <int KP>
 int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                  float *nll, float *accum, float *ws, hipStream_t st, void *const *events, void *slabv = nullptr) {
     const Layout L = make_layout_t<KP>(B, Npix);
-    const size_t NF = det_rows_floats(Npix, Nb, Nh);
-    const int nblk = (B + 63) / 64;
     float *slab = reinterpret_cast<float *>(slabv);
-    double *slabS = slab ? reinterpret_cast<double *>(reinterpret_cast<char *>(slab) +
-                                                      (det_rows(B, Nh) * NF * sizeof(float) + 15) / 16 * 16)
-                         : nullptr;
+    DetLayout D{};
+    if (slab) D = det_layout(B, Npix, Nb, Nh);
+    double *slabS = slab ? reinterpret_cast<double *>(reinterpret_cast<char *>(slab) + D.oS) : nullptr;
     float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL, *NBL = ws + L.oNBL;
     float *nllbuf = nll ? nll : ws + L.oNLL;
     const size_t accS = (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
@@ -209,24 +234,22 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
     mark(3);
     bool pass2_xdl = false;
-    if constexpr (KP == 16) pass2_xdl = pass2_use_xdl(slab != nullptr);
+    if constexpr (KP == 16) pass2_xdl = pass2_use_xdl();
     if (pass2_xdl) {
         qfa_gx_launch(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
-                      accum, slab, slabS, st);
-        if (slab)
-            k_reduce_slab<<<(unsigned)((NF + 255) / 256), 256, 0, st>>>(slab, slabS, (B + 63) / 64, L.wp2x.items() * 4, NF,
-                                                                        accum);
+                      accum, slab, slabS, (int)D.stride, st);
+        if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
         return hip_status();
     }
     for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
         if (16 * bh >= Nh) break;
         if (b.A_blue)
-            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS);
+            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride);
         else
-            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS);
+            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride);
     }
-    if (slab) k_reduce_slab<<<(unsigned)((NF + 255) / 256), 256, 0, st>>>(slab, slabS, nblk, L.wp2.items() * 4, NF, accum);
+    if (slab) launch_reduce_slab(slab, D, B, L.wp2.items() * 4, accum, st);
     mark(4);
     return hip_status();
 }

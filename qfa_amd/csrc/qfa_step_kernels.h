@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
                                                               int bhalf, const float *__restrict__ PFT,
                                                               const float *__restrict__ SOL,
                                                               float *__restrict__ accum, float *__restrict__ slab,
-                                                              double *__restrict__ slabS) {
+                                                              double *__restrict__ slabS, int slab_stride) {
     // slab != NULL: deterministic mode -- the block's tile partials go to row blk of the slab (plain stores), its
     // scalar sums to slabS[item][wave][3]; k_reduce_slab adds the rows to accum in block order.
     // bhalf: which 16 columns of the F gradient this launch produces (N_h > 16 runs the kernel once per
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     const int lo = lane & 15, g = lane >> 4;
 
     const bool det = slab != nullptr;
-    float *accF = det ? slab + (size_t)blk * ((size_t)Npix * Nh + 3 * (size_t)Npix + Nb) : accum;
+    float *accF = det ? slab + (size_t)blk * (size_t)slab_stride : accum;
     float *accA = accF + (size_t)Npix * Nh;
     float *accS = accum + (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
     auto add_to = [&](float *q, float v) {
@@ -1090,21 +1090,59 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_reduce_slab (deterministic mode): accum[j] += sum over blocks of slab[blk][j] in block order (float64 partial),
-// and the three scalar gradients from slabS[item][wave] in item order.
+// Deterministic mode, the fixed-order reduction of the slab (rows of `stride` floats, one per block of 64 spectra):
+//   k_reduce_slab_rows : part[chunk][j] = sum of rows [32 chunk, 32 chunk + 32) of column j, rows in order, float64;
+//   k_reduce_slab_fin  : accum[j] += sum of the chunks in order; the three scalar gradients from slabS[item][wave]
+//                        in item order.
+// The summation order depends on the batch size only -- never on timing.
 // ------------------------------------------------------------------------------------------------
-static __global__ void k_reduce_slab(const float *__restrict__ slab, const double *__restrict__ slabS, int nblk,
-                                     int nitemwaves, size_t NF, float *__restrict__ accum) {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#ifndef QFA_DET_CHUNK_ROWS
+#define QFA_DET_CHUNK_ROWS 32
+#endif
+static __global__ __launch_bounds__(256) void k_reduce_slab_rows(const float *__restrict__ slab, int nblk, size_t NF,
+                                                                 size_t stride, double *__restrict__ part) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= NF) return;
+    const int r0 = blockIdx.y * QFA_DET_CHUNK_ROWS, r1 = min(nblk, r0 + QFA_DET_CHUNK_ROWS);
+    const float *q = slab + (size_t)r0 * stride + j;
+    double a = 0.0;
+    int r = r0;
+    for (; r + 8 <= r1; r += 8, q += 8 * stride) {               // eight loads in flight, added in row order
+        const float v0 = q[0], v1 = q[stride], v2 = q[2 * stride], v3 = q[3 * stride], v4 = q[4 * stride],
+                    v5 = q[5 * stride], v6 = q[6 * stride], v7 = q[7 * stride];
+        a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+        a += (double)v4; a += (double)v5; a += (double)v6; a += (double)v7;
+    }
+    for (; r < r1; ++r, q += stride) a += (double)q[0];
+    part[(size_t)blockIdx.y * NF + j] = a;
+}
+static __global__ __launch_bounds__(256) void k_reduce_slab_fin(const double *__restrict__ part,
+                                                                const double *__restrict__ slabS, int nch,
+                                                                int nitemwaves, size_t NF, float *__restrict__ accum) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j < NF) {
         double a = 0.0;
-        for (int bq = 0; bq < nblk; ++bq) a += (double)slab[(size_t)bq * NF + j];
+        for (int c = 0; c < nch; ++c) a += part[(size_t)c * NF + j];
         accum[j] += (float)a;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 3) {
-        double a = 0.0;
-        for (int q = 0; q < nitemwaves; ++q) a += slabS[(size_t)q * 3 + threadIdx.x];
-        accum[NF + threadIdx.x] += (float)a;
+    // the three scalar gradients: thread t sums its contiguous share of the records in order, thread k < 3 then the 256
+    // shares in order
+    __shared__ double sh[3][256];
+    if (blockIdx.x == 0) {
+        const int per = (nitemwaves + 255) / 256, q0 = threadIdx.x * per, q1 = min(nitemwaves, q0 + per);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int q = q0; q < q1; ++q) {
+            a0 += slabS[(size_t)q * 3 + 0];
+            a1 += slabS[(size_t)q * 3 + 1];
+            a2 += slabS[(size_t)q * 3 + 2];
+        }
+        sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = a2;
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double a = 0.0;
+            for (int t = 0; t < 256; ++t) a += sh[threadIdx.x][t];
+            accum[NF + threadIdx.x] += (float)a;
+        }
     }
 }
 

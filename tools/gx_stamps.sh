@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 QFA_PASS2_XDL=1 QFA_HIP_LIB=$PWD/qfa_amd/libqfa_$1.so python - <<'PY'
 import ctypes, sys, os, runpy
-sys.argv = ["bench.py", "--config", "c3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-predict", "--sustain", "0"]
+sys.argv = ["bench.py", "--config", "c3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-predict", "--sustain", "0"] + os.environ.get("STAMP_BENCH_ARGS", "").split()
 try:
     runpy.run_path("bench.py", run_name="__main__")
 except SystemExit:
@@ -17,8 +17,8 @@ n = a[30]
 print("role A, tiles", n, " idle steps", a[31])
 for tag, off, cnt in (("blue", 0, None), ("red", 16, None)):
     for hh in range(2):
-        v = a[off + 8 * hh: off + 8 * hh + 5]
-        print(f"  {tag} h{hh}: wait+take {v[0]}  stage1 {v[1]}  stage2 {v[2]}  reduce+store {v[3]}  barrier {v[4]}   (total cycles over all tiles)")
+        v = a[off + 8 * hh: off + 8 * hh + 6]
+        print(f"  {tag} h{hh}: vmcnt wait {v[5]}  take {v[0]}  stage1 {v[1]}  stage2 {v[2]}  reduce+store {v[3]}  barrier {v[4]}   (total cycles over all tiles)")
 print("  sum", sum(a[:30]), "per tile", sum(a[:30]) / max(n, 1))
 print("role B")
 for hh in range(2):
