@@ -51,7 +51,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // 4 bytes per lane into LDS (any source alignment: tools/ubench/glds_align.hip); see glds16a for M0
 __device__ __forceinline__ void glds4a(const void *sbase, unsigned voff, unsigned lds_dst) {
+#if QFA_TRACKED_LOADS
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(sbase) + voff),
+        (__attribute__((address_space(3))) void *)(size_t)__builtin_amdgcn_readfirstlane((int)lds_dst), 4, 0, 0);
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#endif
 }
 // a pointer the compiler can see is wave-uniform (an "s" asm operand needs that; values derived from blockIdx through
 // divisions are not always proven uniform)
@@ -64,7 +70,7 @@ __device__ __forceinline__ const T *uniform_ptr(const T *p) {
 }
 __device__ __forceinline__ void step_barrier() {        // LDS writes of this step done, then the workgroup barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    wg_barrier();
     asm volatile("" ::: "memory");
 }
 
@@ -312,7 +318,6 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             asm volatile("" : "+v"(q));                                // keep the product out of the loop-invariant set
             return (unsigned)min(q + r, last_row);
         };
-        auto offN_of = [&](int r) { return row_of(r) * (unsigned)Npix; };
         auto offB_of = [&](int r) { return row_of(r) * (unsigned)Nb; };
         const float *dbase = uniform_ptr(bt.delta + (size_t)(active ? s0 : 0) * Npix);
         const float *ebase = uniform_ptr(bt.error + (size_t)(active ? s0 : 0) * Npix);
@@ -345,6 +350,25 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             const float *zb = (zblue && !(QFA_GX_ABL & 16)) ? zbase : dbase;
             const int zlen = (zblue && !(QFA_GX_ABL & 16)) ? Nb : Npix;
             const unsigned dst = wave_uniform(lds_addr(stg + par * GX::STG_B));
+#if QFA_TRACKED_LOADS
+            {   // test build: ordinary loads and LDS stores for all four arrays (two rows per pass), no counted wait
+                float *sf = reinterpret_cast<float *>(stg + par * GX::STG_B);
+                unsigned char *mb = stg + par * GX::STG_B + GX::STG_MASK;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = 2 * i + (lane >> 5), pxl = lane & 31;
+                    const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+                    const int px = 32 * tg + pxl;
+                    const unsigned o = row * (unsigned)Npix + (unsigned)min(px, Npix - 1);
+                    sf[0 * (GX::STG_ARR / 4) + q * 32 + pxl] = dbase[o];
+                    sf[1 * (GX::STG_ARR / 4) + q * 32 + pxl] = ebase[o];
+                    sf[2 * (GX::STG_ARR / 4) + q * 32 + pxl] = zb[row * (unsigned)zlen + (unsigned)min(px, zlen - 1)];
+                    mb[q * 32 + pxl] = px < Npix ? mbase[o] : (unsigned char)0;
+                }
+                (void)dst; (void)fastz;
+                return 0;
+            }
+#endif
             if (fastp) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void k_predict_x(const float *__restrict__ 
     };
     if (n > 0) get_tile(0);
     dma_wait<0>();
-    __builtin_amdgcn_s_barrier();
+    wg_barrier();
     asm volatile("" ::: "memory");
     for (int c = 0; c < n; ++c) {
         if (c + 1 < n) get_tile(c + 1);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_predict_x(const float *__restrict__ 
         if (counted) dma_wait<8>();
         else dma_wait<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        wg_barrier();
         asm volatile("" ::: "memory");
     }
 }

@@ -37,14 +37,39 @@ struct XCfg {
 // M0 (the LDS destination) is written and not restored: a restore behind the DMA waits until the texture path has
 // accepted the request (measured: ~150 cycles per piece, 1 250-2 500 per tile); nothing else in this kernel
 // depends on M0.
+// QFA_TRACKED_LOADS=1 (test build, `make tracked` -> libqfa_tracked.so): every load, LDS-DMA and wait of the XDL
+// kernels in the form hipcc keeps the books for -- builtin LDS-DMA, ordinary loads, vmcnt(0) and a full
+// __syncthreads() at every hand-over.  Slow, but free of hand-counted waits: tests/test_tracked_loads.py requires
+// its results to be bit-identical to the shipped build's, which is what shows the counted waits to be sufficient.
+#ifndef QFA_TRACKED_LOADS
+#define QFA_TRACKED_LOADS 0
+#endif
 __device__ __forceinline__ void glds16a(const void *sbase, unsigned voff, unsigned lds_dst) {
+#if QFA_TRACKED_LOADS
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(sbase) + voff),
+        (__attribute__((address_space(3))) void *)(size_t)__builtin_amdgcn_readfirstlane((int)lds_dst), 16, 0, 0);
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void dma_wait() {
+#if QFA_TRACKED_LOADS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
 }
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }   // LDS aperture: low 32 bits
+// workgroup barrier behind explicit waits (the caller has waited for what the hand-over needs)
+__device__ __forceinline__ void wg_barrier() {
+#if QFA_TRACKED_LOADS
+    __syncthreads();
+#else
+    __builtin_amdgcn_s_barrier();
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 template <int KP>
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
         // returns true when the loads were issued as (untracked) asm loads
         auto load_spec = [&](int tg, SpecRegsX &r) {
             const int pb = 32 * tg + 8 * g;
-            if (pb + 7 < Npix) {
+            if (!QFA_TRACKED_LOADS && pb + 7 < Npix) {
                 aload16<0>(r.d0, dbase + 32 * tg, voffN);
                 aload16<16>(r.d1, dbase + 32 * tg, voffN);
                 aload16<0>(r.s0, ebase + 32 * tg, voffN);
@@ -211,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
                 asm volatile("" : "+v"(r.d0), "+v"(r.d1), "+v"(r.s0), "+v"(r.s1));
             }
             if (BLUE) {
-                if (pb + 7 < Nb) {
+                if (!QFA_TRACKED_LOADS && pb + 7 < Nb) {
                     aload16<0>(r.z0, zbase + 32 * tg, voffB);
                     aload16<16>(r.z1, zbase + 32 * tg, voffB);
                 } else {
@@ -340,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
             // 1 mask) / 7 (blue: + 2 zabs) spectra loads of this step (the ragged-end path issues more, smaller ones)
             if (reload) dma_wait<BLUE ? 7 : 5>();
             else dma_wait<0>();
-            __builtin_amdgcn_s_barrier();
+            wg_barrier();
             asm volatile("" ::: "memory");
         };
 
