@@ -74,32 +74,34 @@ __device__ __forceinline__ void step_barrier() {        // LDS writes of this st
     asm volatile("" ::: "memory");
 }
 
-struct GX {                                              // KP = 16
-    static constexpr int KP = 16, KK2 = 136;
-    static constexpr int NKS = 6;                        // K-steps of stage 1: [y, 0 | 5 x 32 pair products (136 used)]
+template <int KP_>
+struct GXT {                                             // KP = 16 (N_h = 9..16) or 8 (N_h <= 8)
+    static constexpr int KP = KP_, KK2 = KP * (KP + 1) / 2;
+    static constexpr int NKS = 1 + (KK2 + 31) / 32;      // K-steps of stage 1: [y, 0 | pair products, 32 per step]: 6 / 3
     static constexpr int S1_HALF = NKS * 3 * 1024;       // bytes of the stage-1 image of one 16-pixel half
-    static constexpr int HALF_B = S1_HALF + 1024;        // ring slot: + float32 Psi[16], omega[16] of its pixels (19 KiB)
+    static constexpr int HALF_B = S1_HALF + 1024;        // ring slot: + float32 Psi[16], omega[16] of its pixels (19 / 10 KiB)
     static constexpr int OFF_FP = 2 * HALF_B;            // F as bf16 pieces, A operand of stage 3: [piece][lane][8 a]
-    static constexpr int TILE_B = OFF_FP + 3 * 1024;     // 41 KiB per 32-pixel tile in global memory
-    static constexpr int NCH_HALF = HALF_B / 1024;       // 19 one-KiB DMA pieces per half (+ 3 for the F pieces with h = 1)
+    static constexpr int TILE_B = OFF_FP + 3 * 1024;     // 41 / 23 KiB per 32-pixel tile in global memory
+    static constexpr int NCH_HALF = HALF_B / 1024;       // one-KiB DMA pieces per half (+ 3 for the F pieces with h = 1)
     static constexpr int GROW = 16;                      // floats per row of the transposed gamma slot
     static constexpr int NG = 4;                         // groups of 16 spectra per workgroup
     static constexpr int SPB = 16 * NG;                  // spectra per workgroup
     static constexpr int STG_ARR = 16 * 128;             // staging: one array of one tile, [16 rows][32 px] float
     static constexpr int STG_MASK = 3 * STG_ARR;         // mask bytes [16 rows][32 px]
     static constexpr int STG_B = 3 * STG_ARR + 512;      // delta | sigma | zabs | mask (6.5 KiB per wave and tile)
+    static constexpr int PARTF = 32 * KP;                // floats of one group's stage-3 sums of a tile: [32 px][KP b]
     // LDS (bytes), per workgroup
     static constexpr int L_IMG = 0;                                  // [2 halves][HALF_B]
     static constexpr int L_FP = L_IMG + 2 * HALF_B;                  // [2 tile parity][3 KiB]
     static constexpr int L_BETA = L_FP + 2 * 3072;                   // [2 tile parity][NG][16 s][32 px] float
     static constexpr int L_GAM = L_BETA + 2 * NG * 2048;             // [2][NG][32 rows][GROW] float
-    static constexpr int L_PART = L_GAM + 2 * NG * 32 * GROW * 4;    // [2][NG][32 px][16 b] float
-    static constexpr int L_PSUM = L_PART + 2 * NG * 2048;            // [2][NG][4 sums][32 px] float (summed over the wave)
+    static constexpr int L_PART = L_GAM + 2 * NG * 32 * GROW * 4;    // [2][NG][32 px][KP b] float
+    static constexpr int L_PSUM = L_PART + 2 * NG * PARTF * 4;       // [2][NG][4 sums][32 px] float (summed over the wave)
     static constexpr int L_SCAL = L_PSUM + 2 * NG * 512;             // [NG waves][3 sums][64 lanes] double (role A)
     static constexpr int L_STG = L_SCAL + NG * 3 * 64 * 8;           // [NG waves][2 tile parity][STG_B]
     static constexpr int L_TOTAL = L_STG + NG * 2 * STG_B;
 };
-static_assert(GX::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
+static_assert(GXT<16>::L_TOTAL <= 160 * 1024 && GXT<8>::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
 __device__ __forceinline__ f32x16 xdl32(const u32x4 &a, const u32x4 &b, f32x16 c) {     // 32x32x16
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
                                                    0);
@@ -131,13 +133,15 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 &h, u32x4 &m, 
 // ------------------------------------------------------------------------------------------------
 // k_prep_pgx : F, Psi, omega -> the pass-2 image, one block per 32-pixel tile.
 //   half h (h = 0, 1)  [K-step ks][piece][lane (g, lo)][8 k] bf16: B[k = 32 ks + 8 g + j][px = 2 lo + h]
-//                      ks = 0: k < 16 -> F[px][k]; ks >= 1: pair q = 32 (ks - 1) + 8 g + j -> F[px][a_q] F[px][b_q]
+//                      ks = 0: k < KP -> F[px][k]; ks >= 1: pair q = 32 (ks - 1) + 8 g + j -> F[px][a_q] F[px][b_q]
 //                      then float32 Psi[lo], omega[lo] of the pixels 2 lo + h
 //   stage-3 part       [piece][lane (r, h2)][8 a] bf16: A[px = r][a = 8 h2 + j]
 // ------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, const float *__restrict__ Psi,
-                                                         const float *__restrict__ omega, int Npix, int Nb, int Nh,
-                                                         unsigned char *__restrict__ PGX) {
+template <int KP>
+__global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, const float *__restrict__ Psi,
+                                                  const float *__restrict__ omega, int Npix, int Nb, int Nh,
+                                                  unsigned char *__restrict__ PGX) {
+    using GX = GXT<KP>;
     unsigned char *tile = PGX + (size_t)blockIdx.x * GX::TILE_B;
     const int p0 = 32 * blockIdx.x;
     __shared__ float f[32][17];
@@ -155,13 +159,13 @@ static __global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict
             const int kk = 8 * g + j;
             float x = 0.f;
             if (ks == 0) {
-                if (kk < 16) x = f[px][kk];
+                if (kk < KP) x = f[px][kk];
             } else {
                 const int q = 32 * (ks - 1) + kk;
                 if (q < GX::KK2) {
                     int a = 0;
-                    while (a + 1 < 16 && pair_index(a + 1, a + 1, 16) <= q) ++a;
-                    const int b = a + (q - pair_index(a, a, 16));
+                    while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
+                    const int b = a + (q - pair_index(a, a, KP));
                     x = f[px][a] * f[px][b];
                 }
             }
@@ -223,14 +227,15 @@ __device__ unsigned long long qfa_gx_stamps[2 * 32];
 #else
 #define GXS(i) {}
 #endif
-template <bool HASA>
+template <int KP, bool HASA>
 __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix, int Nb,
                                                     int Nh, int ntiles, WorkPlan wp,
                                                     const unsigned char *__restrict__ PGX,
                                                     const float *__restrict__ SOL, float *__restrict__ accum,
                                                     float *__restrict__ slab, double *__restrict__ slabS,
                                                     int slab_stride) {
-    using C = Cfg<16>;
+    using C = Cfg<KP>;
+    using GX = GXT<KP>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GX::L_TOTAL];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -274,9 +279,6 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #ifndef QFA_GX_STAGE_MID
 #define QFA_GX_STAGE_MID 1
 #endif
-#ifndef QFA_GX_FLUSH_LATE
-#define QFA_GX_FLUSH_LATE 1
-#endif
 #ifndef QFA_GX_ROLE
 #define QFA_GX_ROLE 0      // register-pressure experiments: 1 = role A only, 2 = role B only
 #endif
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     const int kk = 8 * g + j;
                     float val = 0.f;
                     if (ks == 0) {
-                        if (v && kk < 16) val = sol[kk];
+                        if (v && kk < KP) val = sol[kk];
                     } else {
                         const int q = 32 * (ks - 1) + kk;
                         if (v && q < GX::KK2) val = sol[C::SOL_CI + q];
@@ -619,27 +621,30 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         }
     } else if (QFA_GX_ROLE != 1) {
         // ================================================================ role B: image DMA, flushes, stage 3
-        const int col = lane & 31, h2 = lane >> 5, b = lane & 15, sp = (lane >> 4) & 1;
+        // One stage-3 MFMA (32 px x 32 columns x K = 16) covers the columns of 32 / KP spectra: a pair at KP = 16, four
+        // spectra at KP = 8 (where only k < 8 carries data).  Column col = (spectrum sc = col / KP, b = col % KP).
+        constexpr int SPM = 32 / KP, NMG = 16 / SPM;       // spectra per MFMA, MFMA groups per wave (8 pairs / 4 fours)
+        const int col = lane & 31, h2 = lane >> 5, b = lane & (KP - 1), sc = col / KP, sp = (lane >> 4) & 1;
         const int tidB = tid & 255;                        // 0..255 over the four role-B waves
-        // B operands: Z of the pair (2p, 2p + 1): B[k = a = 8 h2 + j][col = (sp, b)] = Z_{2p + sp}[a][b]
-        u32x4 Zh[8], Zm[8], Zl[8], Ph, Pm, Pl;
+        // B operands: Z of group m: B[k = a = 8 h2 + j][col = (sc, b)] = Z_{SPM m + sc}[a][b]
+        u32x4 Zh[NMG], Zm[NMG], Zl[NMG], Ph, Pm, Pl;
         {
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) {
-                const int s = s0 + 2 * pr + sp;
+            for (int m = 0; m < NMG; ++m) {
+                const int s = s0 + SPM * m + sc;
                 const bool v = active && s < B && b < Nh;
                 const float *sol = SOL + (size_t)(v ? s : 0) * C::NSOL + C::SOL_Z + b;
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = v ? sol[(8 * h2 + j) * 16] : 0.f;
-                split8(x, Zh[pr], Zm[pr], Zl[pr]);
+                for (int j = 0; j < 8; ++j) x[j] = (v && 8 * h2 + j < KP) ? sol[(8 * h2 + j) * KP] : 0.f;
+                split8(x, Zh[m], Zm[m], Zl[m]);
             }
-            // gamma term: B[k = s = 8 h2 + j][col] = p_s[b] for col < 16, 0 otherwise
+            // gamma term: B[k = s = 8 h2 + j][col] = p_s[b] for col < KP, 0 otherwise
             float x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int s = s0 + 8 * h2 + j;
-                const bool v = active && s < B && col < 16 && b < Nh;
+                const bool v = active && s < B && col < KP && b < Nh;
                 x[j] = v ? SOL[(size_t)s * C::NSOL + C::SOL_P + b] : 0.f;
             }
             split8(x, Ph, Pm, Pl);
@@ -669,17 +674,19 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         // stores into the 64 spare floats at the end of the row.
         float *sink = accF + (slab_stride - 64) + lane;
         // tile tg leaves the workgroup: role B sums the four groups' partials (fixed order) and adds them to the packed
-        // buffer.  Default: 256 threads, two outputs each (a wave's 64 lanes cover 4 pixel rows = 256 contiguous bytes
-        // at N_h = 16).  Deterministic with N_h a multiple of 4: waves 0 and 1, one 16-byte store per thread.
+        // buffer.  Default: 256 threads, 32 KP / 256 outputs each (a wave's 64 lanes cover 256 contiguous bytes at
+        // N_h = KP).  Deterministic with N_h a multiple of 4: the first 8 KP threads, one 16-byte store each.
         const bool wide = det && (Nh & 3) == 0;
+        constexpr int NWIDE = 8 * KP;                      // threads of the 16-byte form: 128 (waves 0, 1) / 64 (wave 0)
         auto flush_F = [&](int tg, int par) {
             if (QFA_GX_ABL & 2) return;
-            const float *pp = reinterpret_cast<const float *>(lds + GX::L_PART + par * GX::NG * 2048);
+            const float *pp = reinterpret_cast<const float *>(lds + GX::L_PART + par * GX::NG * GX::PARTF * 4);
             if (wide) {
-                if (tidB >= 128) return;                                              // wave-uniform
-                const int px = 32 * tg + (tidB >> 2), b4 = 4 * (tidB & 3);
-                const float4 *q4 = reinterpret_cast<const float4 *>(pp + (tidB >> 2) * 16 + b4);
-                const float4 v0 = q4[0], v1 = q4[128], v2 = q4[256], v3 = q4[384];
+                if (tidB >= NWIDE) return;                                            // wave-uniform
+                const int pxl = tidB / (KP / 4), b4 = 4 * (tidB % (KP / 4));
+                const int px = 32 * tg + pxl;
+                const float4 *q4 = reinterpret_cast<const float4 *>(pp + pxl * KP + b4);
+                const float4 v0 = q4[0], v1 = q4[GX::PARTF / 4], v2 = q4[2 * GX::PARTF / 4], v3 = q4[3 * GX::PARTF / 4];
                 const float4 v = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
                                   (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w)};
                 const bool ok = (b4 < Nh) & (px < Npix);
@@ -688,20 +695,20 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 return;
             }
 #pragma unroll
-            for (int k4 = 0; k4 < 2; ++k4) {
+            for (int k4 = 0; k4 < GX::PARTF / 256; ++k4) {
                 const int o = tidB + 256 * k4;
-                const float v = (pp[o] + pp[512 + o]) + (pp[1024 + o] + pp[1536 + o]);
-                const int px = 32 * tg + (o >> 4), bb = o & 15;
+                const float v = (pp[o] + pp[GX::PARTF + o]) + (pp[2 * GX::PARTF + o] + pp[3 * GX::PARTF + o]);
+                const int px = 32 * tg + o / KP, bb = o % KP;
                 const bool ok = (bb < Nh) & (px < Npix);
                 if (det) *(ok ? accF + (size_t)px * Nh + bb : sink) = v;
-                else atomicAdd(accF + (size_t)min(px, Npix - 1) * Nh + (bb < Nh ? bb : bb - Nh), ok ? v : 0.f);
+                else atomicAdd(accF + (size_t)min(px, Npix - 1) * Nh + bb % Nh, ok ? v : 0.f);
             }
         };
         // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = t >> 5, pxl = t & 31) of 128 -- waves
         // 0 and 1, or waves 2 and 3 when the F sums go out as 16-byte stores (one request per wave and tile then)
         auto flush_P = [&](int tg, int par) {
             if (QFA_GX_ABL & 2) return;
-            if (wide ? tidB < 128 : tidB >= 128) return;                              // wave-uniform
+            if (wide ? tidB < 128 : tidB >= 128) return;                              // wave-uniform (waves 2, 3 / 0, 1)
             const int which = (tidB >> 5) & 3, pxl = tidB & 31;
             const float *q = reinterpret_cast<const float *>(lds + GX::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
             const float v = (q[0] + q[128]) + (q[256] + q[384]);
@@ -714,15 +721,15 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             else atomicAdd(accA + offc, ok ? v : 0.f);
         };
         // stage 3 of tile c, in two parts (the two half-steps of tile c + 1; balanced, so that neither half-step waits for
-        // this role): part 0 = the gamma term and the spectrum pairs 0..3, part 1 = pairs 4..7, added to part 0's sums
-        // in LDS (the accumulator does not live across the barrier: this role is at the register limit as well)
+        // this role): part 0 = the gamma term and the first half of the MFMA groups, part 1 = the second half, added to
+        // part 0's sums in LDS (the accumulator does not live across the barrier: this role is at the register limit)
         auto tileB = [&](int c, auto part_tag) {
             constexpr int PART = decltype(part_tag)::value;
             const int par = c & 1;
             const unsigned char *fp = lds + GX::L_FP + (c & 1) * 3072 + lane * 16;
             const float *bslot = reinterpret_cast<const float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
             const float *gslot = reinterpret_cast<const float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
-            float *part = reinterpret_cast<float *>(lds + GX::L_PART + (par * GX::NG + w) * 2048);
+            float *part = reinterpret_cast<float *>(lds + GX::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
             const u32x4 Fh = *reinterpret_cast<const u32x4 *>(fp), Fm = *reinterpret_cast<const u32x4 *>(fp + 1024),
                         Fl = *reinterpret_cast<const u32x4 *>(fp + 2048);
             f32x16 zero;
@@ -739,9 +746,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 acc = xdl32_6(Gh, Gm, Gl, Ph, Pm, Pl, zero);
             }
 #pragma unroll
-            for (int pr = 4 * PART; pr < 4 * PART + 4; ++pr) {
-                const f32x16 G = xdl32_6(Fh, Fm, Fl, Zh[pr], Zm[pr], Zl[pr], zero);
-                const float *brow = bslot + (2 * pr + sp) * 32 + 4 * h2;       // pixels 8 q + 4 h2 + (0..3)
+            for (int m = (NMG / 2) * PART; m < (NMG / 2) * (PART + 1); ++m) {
+                const f32x16 G = xdl32_6(Fh, Fm, Fl, Zh[m], Zm[m], Zl[m], zero);
+                const float *brow = bslot + (SPM * m + sc) * 32 + 4 * h2;       // pixels 8 q + 4 h2 + (0..3)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 bq = *reinterpret_cast<const float4 *>(brow + 8 * q);
@@ -751,18 +758,23 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     acc[4 * q + 3] = fmaf(bq.w, G[4 * q + 3], acc[4 * q + 3]);
                 }
             }
-            // sum the two spectra of the pairs (lanes l and l ^ 16): v_permlane16_swap exchanges the odd 16-lane rows of
-            // acc[i] with the even rows of acc[8 + i], so one add leaves the sums of acc[i] in the sp = 0 lanes and those
-            // of acc[8 + i] in the sp = 1 lanes; each half of the lanes then stores half the rows:
+            // Sum the spectra of the groups (the lanes that share b).  Lanes l and l ^ 16: v_permlane16_swap exchanges
+            // the odd 16-lane rows of acc[i] with the even rows of acc[8 + i], so one add leaves the sums of acc[i] in
+            // the even rows (sp = 0) and those of acc[8 + i] in the odd rows.  KP = 8: also lanes l and l ^ 8 (a rotation
+            // by 8 inside the row, DPP).  Each half of the lanes then stores half the pixel rows:
             // part[pxl][b], pxl = (ii & 3) + 8 (ii >> 2) + 4 h2 with ii = i + 8 sp
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i]), __float_as_uint(acc[8 + i]), false, false);
-                const float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                if (KP == 8)
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
                 const int pxl0 = (i & 3) + 8 * (i >> 2) + 4 * h2;                 // ii = i; ii = 8 + i adds 16 pixels
-                float *q = part + (pxl0 + 16 * sp) * 16 + b;
-                if (PART == 0) *q = v;
-                else *q += v;                 // (read-add-write: ds_add_f32 cost 2 500 cycles more per tile)
+                float *q = part + (pxl0 + 16 * sp) * KP + b;
+                if (KP == 16 || (lane & 8) == 0) {
+                    if (PART == 0) *q = v;
+                    else *q += v;             // (read-add-write: ds_add_f32 cost 2 500 cycles more per tile)
+                }
             }
         };
         if (n > 0) get_half(0);
@@ -772,15 +784,13 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int t = 2 * c + h;
-                // the flushes first: their stores / atomics are the oldest requests of the step and have the whole of
-                // this half's stage 3 to drain before the vmcnt(0) in front of the barrier
-#if QFA_GX_FLUSH_LATE
                 // The image DMA first, the flushes behind it, and a wait that leaves exactly the flushes in flight: they
                 // are device-scope atomics with a long round trip, and have until the end of the NEXT half-step.
                 if (t + 1 < 2 * n) get_half(t + 1);
                 // requests of this wave's flushes (wave-uniform): F 2 (one as a 16-byte store, waves 0 and 1), P 1
-                const bool wP = wide ? tidB >= 128 : tidB < 128, wF = !wide || tidB < 128;
-                const int nreq = (h == 0 && c >= 1 && c <= n && wP ? 1 : 0) + (h == 0 && c >= 2 && wF ? (wide ? 1 : 2) : 0);
+                const bool wP = wide ? tidB >= 128 : tidB < 128, wF = !wide || tidB < NWIDE;
+                const int nreq = (h == 0 && c >= 1 && c <= n && wP ? 1 : 0) +
+                                 (h == 0 && c >= 2 && wF ? (wide ? 1 : GX::PARTF / 256) : 0);
                 if (h == 0) {
                     if (c >= 1 && c <= n) flush_P(tile_of(c - 1), (c - 1) & 1);
                     if (c >= 2) flush_F(tile_of(c - 2), c & 1);
@@ -799,19 +809,6 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 GXS(8 * h + 2)
                 step_barrier();
                 GXS(8 * h + 3)
-#else
-                if (h == 0) {
-                    if (c >= 1 && c <= n) flush_P(tile_of(c - 1), (c - 1) & 1);
-                    if (c >= 2) flush_F(tile_of(c - 2), c & 1);
-                }
-                if (t + 1 < 2 * n) get_half(t + 1);
-                if (c >= 1 && c <= n && active) {
-                    if (h == 0) tileB(c - 1, std::integral_constant<int, 0>{});
-                    else tileB(c - 1, std::integral_constant<int, 1>{});
-                }
-                dma_wait<0>();
-                step_barrier();
-#endif
             }
         }
 #if QFA_GX_STAMPS

@@ -5,16 +5,23 @@
 
 #include "qfa_host.h"
 
-size_t qfa_gx_image_bytes(int ntiles32) { return (size_t)ntiles32 * GX::TILE_B; }
+size_t qfa_gx_image_bytes(int KP, int ntiles32) { return (size_t)ntiles32 * (KP == 8 ? GXT<8>::TILE_B : GXT<16>::TILE_B); }
 
-void qfa_gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab, double *slabS, int slab_stride,
-                   hipStream_t st) {
-    k_prep_pgx<<<ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, PGX);
+template <int KP>
+static void gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                      int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
+                      double *slabS, int slab_stride, hipStream_t st) {
+    k_prep_pgx<KP><<<ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, PGX);
     if (b.A_blue)
-        k_grads_x<true><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride);
+        k_grads_x<KP, true><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride);
     else
-        k_grads_x<false><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride);
+        k_grads_x<KP, false><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride);
+}
+void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
+                   double *slabS, int slab_stride, hipStream_t st) {
+    if (KP == 8) gx_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, st);
+    else gx_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, st);
 }
 
 size_t qfa_px_image_bytes(int KP, int ntiles32) {

@@ -8,9 +8,9 @@
 #include "qfa_step_kernels.h"
 #include "qfa_xdl_kernels.h"
 
-// pass 2 for N_h in 9..16 with every contraction on the XDL pipe (qfa_grads_x.h, built in qfa_gx.hip)
-size_t qfa_gx_image_bytes(int ntiles32);
-void qfa_gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+// pass 2 for N_h <= 16 with every contraction on the XDL pipe (qfa_grads_x.h: KP = 8 or 16, built in qfa_gx.hip)
+size_t qfa_gx_image_bytes(int KP, int ntiles32);
+void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
                    double *slabS, int slab_stride, hipStream_t st);
 
@@ -84,8 +84,8 @@ Layout make_layout_t(int B, int Npix) {
     if constexpr (KP <= 16) L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4));
     L.oPGX = 0;
     L.wp2x = WorkPlan{0, 0, 1, 0};
-    if constexpr (KP == 16) {
-        L.oPGX = take(qfa_gx_image_bytes(L.ntiles32) / 4);
+    if constexpr (KP == 8 || KP == 16) {
+        L.oPGX = take(qfa_gx_image_bytes(KP, L.ntiles32) / 4);
         L.wp2x = plan_work(B, L.ntiles32, 3, 256, 64);
     }
     L.oPXI = 0;
@@ -117,15 +117,18 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
     return 0;
 }
 
-// Which form of pass 2 runs at N_h = 9..16: 1 = the all-XDL two-role form (k_grads_x, the default: 2.4-2.6 ms at c3
-// against 3.2 for the other, and no slower at any batch size down to 64 spectra -- profiles/r2_ablation_k_grads_x.txt),
-// 0 = the float32-MFMA form with stage 3 on the XDL pipe (k_grads, the form N_h <= 8 and N_h = 17..32 still use).
+// Which form of pass 2 runs at N_h <= 16 (KP = 8 or 16): the all-XDL two-role form (k_grads_x) or the float32-MFMA
+// form (k_grads, the only one for N_h = 17..32).  Default, from measurements on MI355X (profiles/r2_ablation_k_grads_x.txt):
+//   KP = 16: k_grads_x -- 2.4-2.6 ms at c3 against 3.2, and no slower at any batch size down to 64 spectra;
+//   KP = 8 : k_grads   -- k_grads_x<8> is correct (same tests) but slower there (0.22 against 0.17 ms at c2, 2.3 against
+//            1.8 ms at 160 000 x 2000): its tile step is bound by the VALU work of stage 2 and the hand-overs, which
+//            do not shrink with N_h, while k_grads runs two workgroups per CU.
 // QFA_PASS2_XDL=0 / 1 in the environment forces one form (A/B timing and the cross-check of the two forms in tests/);
 // read at every call, nothing is cached.
-inline bool pass2_use_xdl() {
+inline bool pass2_use_xdl(int KP) {
     const char *e = std::getenv("QFA_PASS2_XDL");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    return true;
+    return KP == 16;
 }
 
 inline int hip_status() {
@@ -234,9 +237,9 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
     mark(3);
     bool pass2_xdl = false;
-    if constexpr (KP == 16) pass2_xdl = pass2_use_xdl();
+    if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP);
     if (pass2_xdl) {
-        qfa_gx_launch(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
+        qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
                       accum, slab, slabS, (int)D.stride, st);
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);

@@ -502,11 +502,12 @@ def test_tolerance_sweep_float64_oracle_vs_float32_hip(dev, npix, nh):
         assert rel_l2(unc[s], o[4]) < 1e-4
 
 
-@pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 9, 33), (1000, 12, 130), (64, 16, 1), (33, 13, 17)])
+@pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 9, 33), (1000, 12, 130), (64, 16, 1), (33, 13, 17),
+                                       (1913, 8, 130), (200, 8, 70), (97, 5, 33), (64, 3, 9), (450, 1, 65)])
 def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatch):
-    """N_h = 9..16 has two forms of pass 2: k_grads (float32-MFMA stage 1) and k_grads_x (qfa_grads_x.h: everything on
-    the XDL pipe, two roles per SIMD, 32-pixel tiles; the engine of the deterministic mode); QFA_PASS2_XDL=1 / 0 in
-    the environment selects one.  Ragged shapes (pixel axis not a multiple of 32, blue/red boundary inside a tile,
+    """N_h <= 16 has two forms of pass 2: k_grads (float32-MFMA stage 1) and k_grads_x (qfa_grads_x.h, KP = 8 or 16:
+    everything on the XDL pipe, two roles per SIMD, 32-pixel tiles; the default); QFA_PASS2_XDL=1 / 0 in the
+    environment selects one.  Ragged shapes (pixel axis not a multiple of 32, blue/red boundary inside a tile,
     spectra not a multiple of 16/64): both forms against each other section by section and against the oracle."""
     import torch
     from oracle import qfa_oracle as O
