@@ -293,7 +293,12 @@ def main():
     # the n k^2 (matrix-pipe) part of dom_flops and the bf16 products issued for it: pass 1 4 n k^2 x 6; pass 2
     # n k^2 (stage 1, diag Sigma^-1) x 6 + 2 n k^2 (stage 3, M Z) x 6, or x 4 in k_grads_x
     nk2 = npix * nh * nh
-    xdl_flops = (6 * 1 + (4 if dominant == "k_grads_x" else 6) * 2) * nk2 if dominant == p2_name else 6 * 4 * nk2
+    if dominant == "k_grads_x":
+        xdl_flops = (6 * 1 + 4 * 2) * nk2
+    elif dominant == "k_moments" and nh <= 16:
+        xdl_flops = 6 * 4 * nk2
+    else:
+        xdl_flops = None          # k_grads (N_h <= 8, 17..32): stage 1 on the float32 MFMA, no XDL roof to price against
     ach = dom_flops * B / (dom_ms * 1e-3) / 1e12
     traffic = None
     tfile = os.path.join(REPO, "profiles", f"traffic_{args.config}.json")
@@ -323,8 +328,8 @@ def main():
                      "kernel_ms": dom_ms, "alg_flops_per_spectrum": dom_flops,
                      # the roof the kernel is built against: contraction flops issued six-fold on the bf16 XDL pipe
                      "peak_xdl": PEAK_BF16_TFLOPS,
-                     "achieved_xdl": xdl_flops * B / (dom_ms * 1e-3) / 1e12,
-                     "frac_xdl": xdl_flops * B / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                     "achieved_xdl": xdl_flops * B / (dom_ms * 1e-3) / 1e12 if xdl_flops else None,
+                     "frac_xdl": xdl_flops * B / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if xdl_flops else None,
                      "xdl_flops_per_spectrum": xdl_flops,
                      "built_against": "xdl (bf16 MFMA: six piece products per float32 product, four in stage 3 of "
                                       "k_grads_x); frac = the survey's float32 roof"},

@@ -275,7 +275,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 
 #ifndef QFA_GX_ABL
 #define QFA_GX_ABL 0       // timing-only ablations (wrong results): 1 no spectra staging, 2 no flush, 4 no image DMA,
-#endif                     // 8 the staging re-reads the first tile (cache hits), 16 zabs staged from the delta rows (16-byte aligned)
+#endif                     // 8 the staging re-reads the first tile (cache hits), 16 zabs staged from the delta rows (16-byte aligned),
+                           // 32 flush without its atomics, 64 flush without its LDS reads
 #ifndef QFA_GX_STAGE_MID
 #define QFA_GX_STAGE_MID 1
 #endif
@@ -697,9 +698,10 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #pragma unroll
             for (int k4 = 0; k4 < GX::PARTF / 256; ++k4) {
                 const int o = tidB + 256 * k4;
-                const float v = (pp[o] + pp[GX::PARTF + o]) + (pp[2 * GX::PARTF + o] + pp[3 * GX::PARTF + o]);
+                float v = (QFA_GX_ABL & 64) ? 1.f : (pp[o] + pp[GX::PARTF + o]) + (pp[2 * GX::PARTF + o] + pp[3 * GX::PARTF + o]);
                 const int px = 32 * tg + o / KP, bb = o % KP;
                 const bool ok = (bb < Nh) & (px < Npix);
+                if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); continue; }
                 if (det) *(ok ? accF + (size_t)px * Nh + bb : sink) = v;
                 else atomicAdd(accF + (size_t)min(px, Npix - 1) * Nh + bb % Nh, ok ? v : 0.f);
             }
@@ -711,7 +713,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             if (wide ? tidB < 128 : tidB >= 128) return;                              // wave-uniform (waves 2, 3 / 0, 1)
             const int which = (tidB >> 5) & 3, pxl = tidB & 31;
             const float *q = reinterpret_cast<const float *>(lds + GX::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
-            const float v = (q[0] + q[128]) + (q[256] + q[384]);
+            float v = (QFA_GX_ABL & 64) ? 1.f : (q[0] + q[128]) + (q[256] + q[384]);
+            if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); return; }
             const int px = 32 * tg + pxl;
             const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
             // (default mode: a red pixel's lane of the gOmega group adds 0 to the pixel's count instead)

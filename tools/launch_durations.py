@@ -5,11 +5,15 @@ f = sorted(glob.glob(os.path.join(d, "*", "*kernel_trace.csv")), key=os.path.get
 b = json.load(open(benchjson))
 w = b["warmup"]
 print(f"# {os.path.basename(f)}; bench: steps {b['steps']}, warmup {w}; stage_ms (HIP events, timed steps only): {b['stage_ms']}")
-for key in ("k_moments_x", "k_moments<", "k_solve", "k_grads"):
+for key in ("k_moments_x<16, false", "k_moments_x<8, false", "k_moments<", "k_solve<16, false", "k_solve<8, false", "k_solve<32, false", "k_grads_x", "k_grads<"):
     rows = [r for r in csv.DictReader(open(f)) if key in r["Kernel_Name"]]
     if not rows:
         continue
     ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
-    per = len(ms) // (b["steps"] + w)
-    timed = ms[w * per:]
-    print(f"{key:12s} launches {[round(x, 3) for x in ms]}  mean of the timed ones {sum(timed) / len(timed) * per:.3f} ms per step")
+    # launch order: warmup, the timed steps, then the sustained leg (same step, seconds of it)
+    per = 2 if key == "k_grads<" and b["config"]["n_h"] > 16 else 1       # N_h = 17..32: one launch per 16 columns of F
+    timed = ms[w * per:(w + b["steps"]) * per]
+    rest = ms[(w + b["steps"]) * per:]
+    print(f"{key:22s} warmup+timed launches {[round(x, 3) for x in ms[:(w + b['steps']) * per]]}  mean of the timed ones "
+          f"{sum(timed) / max(1, len(timed)):.3f} ms; {len(rest)} later launches (sustained leg) mean "
+          f"{(sum(rest) / len(rest)) if rest else float('nan'):.3f} ms")

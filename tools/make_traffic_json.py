@@ -13,7 +13,7 @@ for line in open(summary):
         if m: vals[cur][m.group(1)] = float(m.group(2))
 res = {"config": cfg, "B": B, "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ*); "
        "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; check: TCC_EA0_RDREQ_128B*128"}
-for k in ("k_grads", "k_moments", "k_solve"):
+for k in ("k_grads", "k_grads_x", "k_moments", "k_solve"):
     v = vals.get(k, {})
     if k == "k_moments" and "k_moments_x" in vals:      # pass 1 on the XDL pipe (N_h <= 16)
         v = vals["k_moments_x"]
