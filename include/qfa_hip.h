@@ -83,7 +83,10 @@ size_t qfa_accum_floats(int Npix, int Nb, int Nh);
  * MatrixLogDet (QFA/utils.py:12-54) for a whole batch.
  *   nll   (B,)  per-spectrum negative log-likelihood (out, may be NULL)
  *   accum qfa_accum_floats() floats, ADDED to (caller zeroes it once per step).
- * The per-spectrum sums are raw (not normalised): see qfa_finalize_grads_f32. */
+ * The per-spectrum sums are raw (not normalised): see qfa_finalize_grads_f32.
+ * Limit: the counts in `accum` (cnt per pixel, n_spectra, n_spectra_with_blue) are float32 sums of ones, exact up to
+ * 2^24: B > 16 777 216 returns QFA_E_SIZE, and a caller that adds several launches (or ranks) into one buffer must
+ * finalise before the total number of spectra passes 2^24. */
 int qfa_nll_grad_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau,
                      int B, int Npix, int Nb, int Nh,
                      float *nll, float *accum, void *workspace, size_t workspace_bytes,

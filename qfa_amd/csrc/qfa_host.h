@@ -114,6 +114,10 @@ Layout make_layout(int B, int Npix, int Nh) {
 inline int check_shape(int B, int Npix, int Nb, int Nh) {
     if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || Nh < 1 || Nh > 32) return QFA_E_SIZE;
     if ((long long)64 * Npix >= (1LL << 31)) return QFA_E_SIZE;      // 32-bit byte offsets inside a wave's 16 rows
+    // the per-pixel counts and the spectrum counts of the packed buffer are float32 sums of ones: exact up to 2^24
+    // contributions, so one accumulation (launch, or all-reduced job of launches into one buffer) takes at most
+    // 16 777 216 spectra; beyond that the caller finalises more often (the host code here never comes near it)
+    if (B > (1 << 24)) return QFA_E_SIZE;
     return 0;
 }
 

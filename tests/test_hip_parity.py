@@ -371,6 +371,18 @@ def test_loud_failures(dev):
         m.forward(x, x, z[:, :5], torch.ones(2, 20, dtype=torch.bool, device=dev))
     with pytest.raises(QFAHipError):
         m.forward(x.cpu(), x, z, torch.ones(2, 20, dtype=torch.bool, device=dev))
+    # more than 2^24 spectra in one accumulation: the float32 counts would stop being exact (include/qfa_hip.h);
+    # the argument check refuses before anything is launched or read
+    import ctypes as C
+    from qfa_amd import _lib
+    ps = m._params_struct()
+    bs, keep = m._batch_struct(x, x, z, torch.ones(2, 20, dtype=torch.bool, device=dev))
+    big = (1 << 24) + 1
+    rc = _lib.lib().qfa_nll_grad_f32(C.byref(ps), C.byref(bs), C.byref(m._tau_model), big, 20, 10, 4, None,
+                                     C.c_void_p(m._accum().data_ptr()), C.c_void_p(x.data_ptr()), C.c_size_t(1 << 62),
+                                     _lib.current_stream(dev))
+    assert rc == -2                                                   # QFA_E_SIZE
+    del keep
 
 
 def test_full_size_properties_config2(dev):
