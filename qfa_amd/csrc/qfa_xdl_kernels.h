@@ -153,6 +153,17 @@ __device__ __forceinline__ void land(SpecRegsX &r) {
     if (BLUE) asm volatile("" : "+v"(r.z0), "+v"(r.z1));
 }
 
+#ifndef QFA_P1_CT_TERMS
+#define QFA_P1_CT_TERMS 6      // experiment: 4 = C and T from the two leading pieces of both operands
+#endif
+__device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
+                                        const u32x4 &bm, const u32x4 &bl, f32x4 c) {
+    if (QFA_P1_CT_TERMS == 6) return xdl6(ah, am, al, bh, bm, bl, c);
+    c = xdl(am, bm, c);
+    c = xdl(am, bh, c);
+    c = xdl(ah, bm, c);
+    return xdl(ah, bh, c);
+}
 template <int KP, bool PREDICT, int NW>
 __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                       const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
@@ -341,8 +352,8 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 const u32x4 bh = rdB(0, C::NFT + t), bm = rdB(1, C::NFT + t), bl = rdB(2, C::NFT + t);
-                accC[t] = xdl6(w.w1h, w.w1m, w.w1l, bh, bm, bl, accC[t]);
-                if (BLUE) accT[t] = xdl6(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
+                accC[t] = xdl_ct(w.w1h, w.w1m, w.w1l, bh, bm, bl, accC[t]);
+                if (BLUE) accT[t] = xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
             }
         };
 

@@ -356,6 +356,26 @@ def test_custom_tau_callable_goes_through_A_blue(dev, shipped, grid):
     assert abs(l3.item() - ol3) / abs(ol3) < TOL_NLL
 
 
+@pytest.mark.parametrize("npix,nh,B", [(200, 12, 70), (1000, 16, 40), (97, 8, 33)])
+def test_custom_tau_on_the_xdl_pass2(dev, npix, nh, B, monkeypatch):
+    """The A_blue input (a user tau callable) through k_grads_x (HASA instantiation; N_h = 8 forced onto it): same
+    gradients as the built-in becker tau when the callable IS becker, ragged shapes."""
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=npix)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=npix + 1)
+    monkeypatch.setenv("QFA_PASS2_XDL", "1")
+    m1 = make_model(dev, p, mu)
+    m2 = make_model(dev, p, mu, tau=lambda z: 0.751 * ((1 + z) / 4.5) ** 2.90 - 0.132)
+    l1, g1 = m1.forward(*batch_t(b, dev))
+    l2, g2 = m2.forward(*batch_t(b, dev))
+    assert abs(l1.item() - l2.item()) / abs(l1.item()) < 1e-5
+    for k in KEYS:
+        a, r = g2[k].cpu().numpy(), g1[k].cpu().numpy()
+        ok = ~np.isnan(r)
+        assert rel_l2(a[ok], r[ok]) < 2e-4, k
+
+
 def test_loud_failures(dev):
     import torch
     from qfa_amd import QFA

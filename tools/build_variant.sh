@@ -7,4 +7,5 @@ B="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-math-errno"
 if [ ! -f /tmp/qfa_k32_variant.o ] || [ $R/qfa_amd/csrc/qfa_step_kernels.h -nt /tmp/qfa_k32_variant.o ]; then
   /opt/rocm/bin/hipcc $B -c $R/qfa_amd/csrc/qfa_k32.hip -o /tmp/qfa_k32_variant.o || exit 1
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $out.capi.o /tmp/qfa_k32_variant.o -o $out
+# the XDL pass 2 / writer translation unit is taken from the tree's last build (tools/build_gx_variant.sh varies that one)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $out.capi.o /tmp/qfa_k32_variant.o $R/qfa_amd/csrc/qfa_gx.o -o $out
