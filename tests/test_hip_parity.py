@@ -373,7 +373,9 @@ def test_custom_tau_on_the_xdl_pass2(dev, npix, nh, B, monkeypatch):
     for k in KEYS:
         a, r = g2[k].cpu().numpy(), g1[k].cpu().numpy()
         ok = ~np.isnan(r)
-        assert rel_l2(a[ok], r[ok]) < 2e-4, k
+        # the callable's exp(-tau) comes from torch (pow, exp), the built-in from the kernel's exp2 / log2: the three
+        # scalar gradients (sums of cancelling terms) see that difference amplified
+        assert rel_l2(a[ok], r[ok]) < (5e-4 if k in ("tau0", "c0", "beta") else 2e-4), k
 
 
 def test_loud_failures(dev):
