@@ -42,12 +42,16 @@ struct Cfg {
     // pair products, then Psi, omega, zero padding to a multiple of 4 rows.
     static constexpr int PFT_PSI = KP + KK2;
     static constexpr int NR = (KP + KK2 + 2 + 3) / 4 * 4;
-    // N_h = 16: stage 3 of pass 2 runs on the XDL pipe; its A operand (F of the tile as three bf16 pieces in the
-    // lane order of v_mfma_f32_16x16x16_bf16: [piece][g][px][a = 4g + j], 3 x 512 bytes) is appended to the tile,
-    // and both parts are padded to whole KiB so that the tile moves as 1-KiB LDS-DMA pieces
-    static constexpr bool XS3 = KP == 16;
+    // N_h > 8: stage 3 of k_grads runs on the XDL pipe; its A operand (F of the tile as three bf16 pieces in the lane
+    // order of the MFMA: KP = 16 v_mfma_f32_16x16x16_bf16 [piece][g][px][a = 4g + j], 3 x 512 bytes; KP = 32
+    // v_mfma_f32_16x16x32_bf16 [piece][g][px][a = 8g + j], 3 x 1 KiB) is appended to the tile, and both parts are
+    // padded to whole KiB so that the tile moves as 1-KiB LDS-DMA pieces
+#ifndef QFA_XS3_32
+#define QFA_XS3_32 1
+#endif
+    static constexpr bool XS3 = KP == 16 || (KP == 32 && QFA_XS3_32);
     static constexpr int PFT_MAIN = XS3 ? (NR * 16 + 255) / 256 * 256 : NR * 16;   // floats of the float32 part
-    static constexpr int PFT_FP = XS3 ? 512 : 0;        // floats
+    static constexpr int PFT_FP = XS3 ? (KP == 32 ? 768 : 512) : 0;                // floats
     static constexpr int TILE_PFT = PFT_MAIN + PFT_FP;
     // per-spectrum moment record: [C PW][T PW][b FW][b2 FW][qd, ld, n, nblue]
     static constexpr int NMOM = 2 * PW + 2 * FW + 4;

@@ -277,6 +277,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #define QFA_GX_ABL 0       // timing-only ablations (wrong results): 1 no spectra staging, 2 no flush, 4 no image DMA,
 #endif                     // 8 the staging re-reads the first tile (cache hits), 16 zabs staged from the delta rows (16-byte aligned),
                            // 32 flush without its atomics, 64 flush without its LDS reads
+#ifndef QFA_GX_BPRIO
+#define QFA_GX_BPRIO 1        // priority of the role-B waves (0..3; 4 = 1 on red tiles only): 1 or 2 measured -0.05..-0.1 ms at c3
+#endif
 #ifndef QFA_GX_STAGE_MID
 #define QFA_GX_STAGE_MID 1
 #endif
@@ -780,10 +783,18 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 }
             }
         };
+#if QFA_GX_BPRIO && QFA_GX_BPRIO < 4
+        __builtin_amdgcn_s_setprio(QFA_GX_BPRIO);
+#endif
         if (n > 0) get_half(0);
         dma_wait<0>();
         step_barrier();
         for (int c = 0; c < n + 2; ++c) {
+#if QFA_GX_BPRIO == 4
+            // this role is the slower one while role A works on a red tile, and the faster one on a blue tile
+            if (c < n && tile_of(c) < nbt) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int t = 2 * c + h;

@@ -57,7 +57,23 @@ __global__ void k_prep_pf(const float *__restrict__ F, const float *__restrict__
     }
     // zero padding rows of the PFT tile
     for (int r = C::PFT_PSI + 2 + threadIdx.x; r < C::NR; r += blockDim.x) pft[r * 16] = 0.f;
-    if constexpr (C::XS3) {
+    if constexpr (C::XS3 && KP == 32) {
+        // F of this pixel as bf16 pieces, A operand of stage 3 (K = a = 32): [piece][g][px][a = 8g + j], 16 bytes per (g, px)
+        if (threadIdx.x < 4) {
+            const int g = threadIdx.x;
+            unsigned *fp = reinterpret_cast<unsigned *>(PFT + (size_t)(i >> 4) * C::TILE_PFT + C::PFT_MAIN) +
+                           (g * 16 + (i & 15)) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int a = 8 * g + 2 * q;
+                const float v0 = (live && a < Nh) ? F[(size_t)i * Nh + a] : 0.f;
+                const float v1 = (live && a + 1 < Nh) ? F[(size_t)i * Nh + a + 1] : 0.f;
+                unsigned h, m, l;
+                split2(v0, v1, h, m, l);
+                fp[q] = h; fp[256 + q] = m; fp[512 + q] = l;
+            }
+        }
+    } else if constexpr (C::XS3) {
         // F of this pixel as bf16 pieces, A operand of stage 3: [piece][g][px][a = 4g + j], 8 bytes per (g, px)
         if (threadIdx.x < 4) {
             const int g = threadIdx.x;
@@ -547,11 +563,16 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     constexpr bool XS3 = C::XS3;
     // ring of 3 parameter tiles; with stage 3 on the XDL pipe only the F pieces of a tile are read in its own step
     // (the float32 part is consumed one step earlier by stage 1), so the float32 part needs two slots only
-    constexpr int NM4 = C::PFT_MAIN / 4, NP4 = XS3 ? C::PFT_FP / 4 : 1, RING_M = XS3 ? 2 : 3;
+    // KP = 32: stage 3 on the XDL pipe as well, but the float32 part of the tile keeps travelling through the staging
+    // registers into a ring of 3 (XDMA = false) and every lane reads its two 16-byte F pieces of the tile straight
+    // from the image in global memory (L2) at the start of the step.  (Through LDS -- by LDS-DMA into a ring, or
+    // staged with the rest of the tile -- they arrived wrong at this size; not understood, the parity tests caught it.)
+    constexpr bool XDMA = XS3 && KP == 16;
+    constexpr int NM4 = C::PFT_MAIN / 4, NP4 = XDMA ? C::PFT_FP / 4 : 1, RING_M = XDMA ? 2 : 3;
     constexpr int NCH_MAIN = C::PFT_MAIN / 256, NCH = C::TILE_PFT / 256;   // 1-KiB LDS-DMA pieces (XDL form)
     __shared__ float4 lds4[RING_M][XS3 ? NM4 : NF4];
-    __shared__ float4 ldsfp[XS3 ? 3 : 1][NP4];                   // F as bf16 pieces (stage-3 A operand)
-    __shared__ unsigned ldszl[XS3 ? 4 : 1][XS3 ? 16 * 64 * 2 : 1];   // third bf16 piece of Z, per wave [spectrum][lane][2]
+    __shared__ float4 ldsfp[XDMA ? 3 : 1][NP4];                  // F as bf16 pieces (stage-3 A operand, KP = 16)
+    __shared__ unsigned ldszl[XDMA ? 4 : 1][XDMA ? 16 * 64 * 2 : 1];   // third bf16 piece of Z (KP = 16), per wave [spectrum][lane][2]
     __shared__ float ldspart[2][4][NPART];
 #if QFA_ABL == 6                                                  // occupancy experiment: one workgroup per CU
     __shared__ float ldspad[22000];
@@ -595,7 +616,12 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     //   ALL 16 spectra as bf16 pieces h, m (registers) and l (LDS); beta is applied to G_s on the VALU.
     constexpr int NZR = XS3 ? 1 : 4, NZA = XS3 ? 1 : KP, NZS = XS3 ? 16 : 1;
     float Zr[NZR][NZA], pr[4];
-    u32x2 Zh[NZS], Zm[NZS], ph = {0u, 0u}, pm = {0u, 0u}, pl = {0u, 0u};
+    // (KP = 32: K = a = 32 per MFMA, 8 values per lane and piece, the two leading pieces only -- four products of
+    // 2^-17 each, as in k_grads_x: the third piece would take 16 KB of LDS per wave)
+    using ZV = std::conditional_t<KP == 32, u32x4, u32x2>;
+    constexpr int NZJ = KP == 32 ? 8 : 4;              // values of Z per lane and spectrum
+    ZV Zh[NZS], Zm[NZS];
+    u32x2 ph = {0u, 0u}, pm = {0u, 0u}, pl = {0u, 0u};
     bool sv[4];
     int offN[4], offB[4];
 #pragma unroll
@@ -615,27 +641,38 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
         offB[r] = sc * Nb;
     }
     if constexpr (XS3) {
-        unsigned *zl = ldszl[wv];
+        unsigned *zl = ldszl[KP == 16 ? wv : 0];
         // all 64 loads first (the LDS stores below otherwise serialise them: load 4, wait, split, store, ...)
-        float zraw[16][4];
+        float zraw[16][NZJ];
+        const int zcol = 16 * bhalf + lo;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const bool v = active && (s0 + s) < B && lo < KP;
-            const float *sol = SOL + (size_t)(v ? s0 + s : 0) * C::NSOL + C::SOL_Z + lo;
+            const bool v = active && (s0 + s) < B && zcol < KP;
+            const float *sol = SOL + (size_t)(v ? s0 + s : 0) * C::NSOL + C::SOL_Z + zcol;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) zraw[s][j] = (v && 4 * g + j < KP) ? sol[(4 * g + j) * KP] : 0.f;
+            for (int j = 0; j < NZJ; ++j) zraw[s][j] = (v && NZJ * g + j < KP) ? sol[(NZJ * g + j) * KP] : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float *z = zraw[s];
-            unsigned h0, m0, l0, h1, m1, l1;
-            split2(z[0], z[1], h0, m0, l0);
-            split2(z[2], z[3], h1, m1, l1);
-            Zh[s] = u32x2{h0, h1};
-            Zm[s] = u32x2{m0, m1};
-            zl[(s * 64 + lane) * 2] = l0;
-            zl[(s * 64 + lane) * 2 + 1] = l1;
+            if constexpr (KP == 32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned h, m, l;
+                    split2(z[2 * q], z[2 * q + 1], h, m, l);
+                    Zh[s][q] = h;
+                    Zm[s][q] = m;
+                }
+            } else {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split2(z[0], z[1], h0, m0, l0);
+                split2(z[2], z[3], h1, m1, l1);
+                Zh[s] = u32x2{h0, h1};
+                Zm[s] = u32x2{m0, m1};
+                zl[(s * 64 + lane) * 2] = l0;
+                zl[(s * 64 + lane) * 2 + 1] = l1;
+            }
         }
         // p of the spectra 4g+j as the B operand of the gamma term (K = spectrum)
         unsigned h0, m0, l0, h1, m1, l1;
@@ -649,7 +686,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
     const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
     const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
     const float4 *PFT4 = reinterpret_cast<const float4 *>(PFT);
-    using TC = TileCopy<NF4>;
+    using TC = TileCopy<XS3 ? NM4 : NF4>;       // (XDL stage 3: the F pieces at the end of the tile are not staged)
     float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f}, tvx[TC::NX];
     double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;   // float32 per tile, float64 across tiles
     int ntile_done = 0;                               // picks the flushing wave, round robin
@@ -905,22 +942,31 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
         // static operands), then accF[px][b] += beta_{s,px} G_s[px][b] on the VALU; beta reaches the lane that
         // holds rows px = 4g..4g+3 of G through the wave's LDS slot.  The gamma term sum_s gamma_{s,px} p_s[b] is
         // one more product with K = spectrum (gamma split in the loop: 4 values per lane).
-        auto stage3x = [&](const float4 *fpt, const float (&betaR)[4], const float (&gamR)[4], float *part) {
+        auto stage3x = [&](const float4 *fpt, const ZV &Fgh, const ZV &Fgm, const float (&betaR)[4], const float (&gamR)[4],
+                           float *part) {
             if constexpr (XS3) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) part[(4 * g + r) * 16 + lo] = betaR[r];
-                const u32x2 *fp = reinterpret_cast<const u32x2 *>(fpt) + lane;
-                const u32x2 Fh = fp[0], Fm = fp[64], Fl = fp[128];
+                const ZV *fp = reinterpret_cast<const ZV *>(fpt) + lane;
+                const ZV Fh = XDMA ? fp[0] : Fgh, Fm = XDMA ? fp[64] : Fgm;
                 unsigned h0, m0, l0, h1, m1, l1;
                 split2(gamR[0], gamR[1], h0, m0, l0);
                 split2(gamR[2], gamR[3], h1, m1, l1);
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 f32x4 acc = xdl16_6(u32x2{h0, h1}, u32x2{m0, m1}, u32x2{l0, l1}, ph, pm, pl, zero);
-                const u32x2 *zl = reinterpret_cast<const u32x2 *>(ldszl[wv]) + lane;
+                const u32x2 *zl = reinterpret_cast<const u32x2 *>(ldszl[KP == 16 ? wv : 0]) + lane;
                 const float4 *brow = reinterpret_cast<const float4 *>(part) + g;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const f32x4 G = xdl16_6(Fh, Fm, Fl, Zh[s], Zm[s], zl[s * 64], zero);
+                    f32x4 G;
+                    if constexpr (KP == 32) {
+                        G = xdl(Fm, Zm[s], zero);
+                        G = xdl(Fm, Zh[s], G);
+                        G = xdl(Fh, Zm[s], G);
+                        G = xdl(Fh, Zh[s], G);
+                    } else {
+                        G = xdl16_6(Fh, Fm, fp[128], Zh[s], Zm[s], zl[s * 64], zero);
+                    }
                     const float4 bq = brow[s * 4];
                     acc[0] = fmaf(bq.x, G[0], acc[0]);
                     acc[1] = fmaf(bq.y, G[1], acc[1]);
@@ -962,7 +1008,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
         // parameter tile c -> LDS.  XDL form: LDS-DMA, wave w moves the 1-KiB pieces w, w+4, ... (no staging
         // registers; the tile barrier retires them).  f32 form: through the staging registers (get / put).
         auto get_tile = [&](int c) {
-            if constexpr (XS3) {
+            if constexpr (XDMA) {
                 const unsigned char *src = reinterpret_cast<const unsigned char *>(PFT4 + (size_t)tile_of(c) * NF4) + lane * 16;
 #pragma unroll
                 for (int i = 0; i < (NCH + 3) / 4; ++i) {
@@ -975,7 +1021,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
             }
         };
         auto put_tile = [&](int c) {
-            if constexpr (!XS3) TC::store(lds4[c % RING_M], tid, tv0, tv1, tv2, tvx);
+            if constexpr (!XDMA) TC::store(lds4[c % RING_M], tid, tv0, tv1, tv2, tvx);
         };
 
         // Software pipeline over tiles (one barrier per tile, ring of 3 parameter tiles):
@@ -995,6 +1041,14 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
             f32x4 afyN = {0.f, 0.f, 0.f, 0.f}, aqN = {0.f, 0.f, 0.f, 0.f};
             float PsiN = 0.f, omN = 0.f;
             float betaR[4] = {0.f, 0.f, 0.f, 0.f}, gamR[4] = {0.f, 0.f, 0.f, 0.f};
+            ZV Fgh = {}, Fgm = {};
+            if constexpr (XS3 && !XDMA) {      // KP = 32: the lane's F pieces of this tile straight from the tile image (L2)
+                if (active) {
+                    const ZV *fg = reinterpret_cast<const ZV *>(PFT + (size_t)tg * C::TILE_PFT + C::PFT_MAIN) + lane;
+                    Fgh = fg[0];
+                    Fgm = fg[64];
+                }
+            }
             if (active) {
                 const int cn1 = more ? c + 1 : c;                 // last tile: harmless recomputation
 #if QFA_ABL != 2
@@ -1012,7 +1066,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, 
             if (c + 2 < n) get_tile(c + 2);
             if (active) {
 #if QFA_ABL != 5
-                if constexpr (XS3) stage3x(ldsfp[c % 3], betaR, gamR, ldspart[pbuf][wv]);
+                if constexpr (XS3) stage3x(ldsfp[XDMA ? c % 3 : 0], Fgh, Fgm, betaR, gamR, ldspart[pbuf][wv]);
                 else stage3(tilebuf(c), betaR, gamR, ldspart[pbuf][wv]);
 #else
                 asm volatile("" ::"v"(betaR[0]), "v"(betaR[1]), "v"(betaR[2]), "v"(betaR[3]), "v"(gamR[0]), "v"(gamR[1]),
