@@ -62,7 +62,8 @@ struct Layout {
     WorkPlan wp1, wp2;                                 // work items of pass 1 / pass 2
     WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
     WorkPlan wpp;                                      // posterior writer on the XDL pipe (k_predict_x, N_h <= 16)
-    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, total;   // float offsets
+    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oBG, total;   // float offsets
+    int bg_stride;                                     // beta / gamma hand-over of pass 2 at N_h = 17..32 ([2][Bpad][NpixPad])
 };
 
 template <int KP>
@@ -99,6 +100,9 @@ Layout make_layout_t(int B, int Npix) {
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
     L.oNLL = take((size_t)L.Bpad);
     L.oNBL = take((size_t)L.Bpad);
+    L.oBG = 0;
+    L.bg_stride = L.NpixPad;
+    if constexpr (KP == 32) L.oBG = take(2 * (size_t)round_up(B, 64) * L.NpixPad);
     L.total = o;
     return L;
 }
@@ -249,12 +253,23 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         mark(4);
         return hip_status();
     }
+    if constexpr (KP == 32) {
+        // columns 0..15 by k_grads, which also stores beta and gamma; columns 16..31 by the stage-3-only kernel
+        float *BG = Nh > 16 ? ws + L.oBG : nullptr, *GG = Nh > 16 ? BG + (size_t)round_up(B, 64) * L.NpixPad : nullptr;
+        if (b.A_blue)
+            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, 0, PFT, SOL, accum, slab, slabS, (int)D.stride, BG, GG, L.bg_stride);
+        else
+            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, 0, PFT, SOL, accum, slab, slabS, (int)D.stride, BG, GG, L.bg_stride);
+        if (Nh > 16)
+            k_grads_s3<KP><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, 1, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
+    } else {
     for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
         if (16 * bh >= Nh) break;
         if (b.A_blue)
             k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride);
         else
             k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride);
+    }
     }
     if (slab) launch_reduce_slab(slab, D, B, L.wp2.items() * 4, accum, st);
     mark(4);
