@@ -75,7 +75,7 @@ Layout make_layout_t(int B, int Npix) {
     L.ntiles = L.NpixPad / 16;
     L.Bpad = round_up(B, 16);
     L.ntiles32 = (Npix + 31) / 32;
-    L.wp2 = plan_work(B, L.ntiles, 4);
+    L.wp2 = plan_work(B, L.ntiles, 4, 256 * (KP == 8 ? QFA_G8_OCC : (KP > 16 ? 1 : 2)));
     L.wp1 = KP <= 16 ? plan_work(B, L.ntiles32, 1) : plan_work(B, L.ntiles, 2);
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };

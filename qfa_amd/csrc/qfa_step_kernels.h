@@ -545,8 +545,11 @@ struct SpecRegs2 {
     unsigned m[4];
 };
 
+#ifndef QFA_G8_OCC
+#define QFA_G8_OCC 2      // workgroups per CU the N_h <= 8 instantiation is compiled for
+#endif
 template <int KP, bool HASA>
-__global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_grads(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B,
+__global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void k_grads(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B,
                                                               int Npix, int Nb, int Nh, int ntiles, WorkPlan wp,
                                                               int bhalf, const float *__restrict__ PFT,
                                                               const float *__restrict__ SOL,
