@@ -171,7 +171,7 @@ void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t
     float *MOM = ws + L.oMOM;
     if constexpr (KP <= 16) {
         unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
-        k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, PFX);
+        k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, Npix, Nb, Nh, PFX);
 #ifndef QFA_XNW
 #define QFA_XNW 4
 #endif

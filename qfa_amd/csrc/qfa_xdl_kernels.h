@@ -23,8 +23,8 @@ struct XCfg {
     using C = Cfg<KP>;
     static constexpr int NCOL = C::FW + C::PW;               // f columns first, then the pair columns
     static constexpr int PSTR = NCOL * 64;                    // bytes of one piece: 32 px x bf16 per column
-    static constexpr int OFF_PSI = 3 * PSTR;                  // float32 Psi[32], omega[32]
-    static constexpr int TILE_B = (3 * PSTR + 256 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
+    static constexpr int OFF_PSI = 3 * PSTR;                  // float32 Psi[32], omega[32], mu[32] (prediction)
+    static constexpr int TILE_B = (3 * PSTR + 384 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
     static constexpr int NCHUNK = TILE_B / 1024;
 };
 
@@ -74,7 +74,8 @@ __device__ __forceinline__ void wg_barrier() {
 // ------------------------------------------------------------------------------------------------
 template <int KP>
 __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, const float *__restrict__ Psi,
-                                                  const float *__restrict__ omega, int Npix, int Nb, int Nh,
+                                                  const float *__restrict__ omega, const float *__restrict__ mu,
+                                                  int Npix, int Nb, int Nh,
                                                   unsigned char *__restrict__ PFX) {
     using C = Cfg<KP>;
     using X = XCfg<KP>;
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, c
         float v = 0.f;
         if (idx < 32) v = i < Npix ? Psi[i] : 0.f;
         else if (idx < 64) v = i < Nb ? omega[i] : 0.f;
+        else if (idx < 96) v = (mu && i < Npix) ? mu[i] : 0.f;      // mean continuum (prediction: delta = flux - mu A)
         po[idx] = v;
     }
 }
@@ -265,7 +267,12 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
         // ---- phase 1 of a tile: per-element weights on the VALU (QFA/model.py:125-131), split into bf16 pieces
         auto weights = [&](int tg, const SpecRegsX &cur, const unsigned char *tile, Pieces &w) {
             const float *pp = reinterpret_cast<const float *>(tile + X::OFF_PSI) + 8 * g;
-            float psi[8], om[8];
+            float psi[8], om[8], muv[8];
+            if (PREDICT) {          // from the tile image: a global load here would sit in the counted vmcnt queue
+                const float4 a = *reinterpret_cast<const float4 *>(pp + 64), b = *reinterpret_cast<const float4 *>(pp + 68);
+                muv[0] = a.x; muv[1] = a.y; muv[2] = a.z; muv[3] = a.w;
+                muv[4] = b.x; muv[5] = b.y; muv[6] = b.z; muv[7] = b.w;
+            }
             {
                 const float4 a = *reinterpret_cast<const float4 *>(pp), b = *reinterpret_cast<const float4 *>(pp + 4);
                 psi[0] = a.x; psi[1] = a.y; psi[2] = a.z; psi[3] = a.w;
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
                         const float A = blue ? Ab : 1.f;
                         const float zdom = blue ? t.zd * om[e] : 0.f;
                         D = A * A * psi[e] + zdom + sg * sg;
-                        if (PREDICT) d = d - mu[min(px, Npix - 1)] * A;      // QFA/model.py:166
+                        if (PREDICT) d = d - muv[e] * A;                     // QFA/model.py:166
                         wD = wv_ ? fast_rcp(D) : 0.f;
                         d = wv_ ? d : 0.f;
                         const float wDA = wD * A;
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
                         cblue += (wv_ & blue) ? 1.f : 0.f;
                     } else {                                                 // red side: A = 1, no omega term
                         D = psi[e] + sg * sg;
-                        if (PREDICT) d = d - mu[min(px, Npix - 1)];
+                        if (PREDICT) d = d - muv[e];
                         wD = wv_ ? fast_rcp(D) : 0.f;
                         d = wv_ ? d : 0.f;
                         c2[h2] = wD;
