@@ -62,7 +62,7 @@ struct Layout {
     WorkPlan wp1, wp2;                                 // work items of pass 1 / pass 2
     WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
     WorkPlan wpp;                                      // posterior writer on the XDL pipe (k_predict_x, N_h <= 16)
-    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oBG, total;   // float offsets
+    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, total;   // float offsets
     int bg_stride;                                     // beta / gamma hand-over of pass 2 at N_h = 17..32 ([2][Bpad][NpixPad])
 };
 
@@ -100,6 +100,7 @@ Layout make_layout_t(int B, int Npix) {
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
     L.oNLL = take((size_t)L.Bpad);
     L.oNBL = take((size_t)L.Bpad);
+    L.oRED = take(2 * 2 * NRED + 2);                    // k_reduce_nll: 2 x NRED doubles + the ticket counter
     L.oBG = 0;
     L.bg_stride = L.NpixPad;
     if constexpr (KP == 32) L.oBG = take(2 * (size_t)round_up(B, 64) * L.NpixPad);
@@ -234,18 +235,22 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     auto mark = [&](int i) {
         if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
     };
+    bool pass2_xdl = false;
+    if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP);
     mark(0);
-    launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
+    // the float32 images PF / PFT serve k_moments (N_h > 16) and k_grads: not needed when both passes run on the XDL pipe
+    if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
     mark(1);
     launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, ws, st);
     mark(2);
     sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
-    k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr);
-    k_reduce_nll<<<1, 1024, 0, st>>>(nllbuf, NBL, B, accum + accS);
+    double *red = reinterpret_cast<double *>(ws + L.oRED);
+    unsigned *ticket = reinterpret_cast<unsigned *>(red + 2 * NRED);
+    k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr, ticket);
+    const int nred = B <= 2048 ? 1 : (B >= 2048 * NRED ? NRED : (B + 2047) / 2048);     // small batches: one block, no hand-over
+    k_reduce_nll<<<nred, 256, 0, st>>>(nllbuf, NBL, B, accum + accS, red, ticket);
     mark(3);
-    bool pass2_xdl = false;
-    if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP);
     if (pass2_xdl) {
         qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
                       accum, slab, slabS, (int)D.stride, st);
@@ -285,19 +290,19 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     auto mark = [&](int i) {
         if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
     };
+    bool writer_xdl = false;
+    if constexpr (KP <= 16) {
+        const char *e = std::getenv("QFA_PREDICT_F32");          // =1: the float32-MFMA writer (A/B timing, cross-check)
+        writer_xdl = !(e && e[0] == '1');
+    }
     mark(0);
-    launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
+    if (!writer_xdl) launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);      // (PF / PFT: k_moments and k_predict_out only)
     launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, ws, st);
     mark(1);
     sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
     k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, ll, nullptr, B, Nh, hmean, hcov);
     mark(2);
-    bool writer_xdl = false;
-    if constexpr (KP <= 16) {
-        const char *e = std::getenv("QFA_PREDICT_F32");          // =1: the float32-MFMA writer (A/B timing, cross-check)
-        writer_xdl = !(e && e[0] == '1');
-    }
     if (writer_xdl)
         qfa_px_launch(KP, p.F, mu, B, Npix, Nh, L.ntiles32, L.wpp, reinterpret_cast<unsigned char *>(ws + L.oPXI), SOL, cont,
                       unc, st);

@@ -385,9 +385,11 @@ static __global__ void k_sum_segments(float4 *__restrict__ mom, const float4 *__
 template <int KP, bool PREDICT>
 __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
                                                float *__restrict__ nll_out, float *__restrict__ nblue_out, int B,
-                                               int Nh, float *__restrict__ hmean, float *__restrict__ hcov) {
+                                               int Nh, float *__restrict__ hmean, float *__restrict__ hcov,
+                                               unsigned *__restrict__ ticket = nullptr) {
     using C = Cfg<KP>;
     constexpr int G = 64 / KP;
+    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;     // arrival counter of k_reduce_nll (next launch)
     const int lane = threadIdx.x & 63;
     const int c = lane % KP;
     const int s = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + lane / KP;
@@ -495,14 +497,20 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_reduce_nll : accum scalars += {#spectra with an unmasked blue pixel, sum NLL, B}.  One block,
-// fp64 partial sums, fixed order (deterministic).
+// k_reduce_nll : accum scalars += {#spectra with an unmasked blue pixel, sum NLL, B}.  NRED blocks sum one contiguous
+// share of the spectra each (float64, fixed order inside a block); the block that arrives last (ticket counter, zeroed by
+// k_solve) adds the NRED partial sums in block order: deterministic, and 100 000 spectra no longer pass through one
+// block's 1 024 serial load-add chains (39 us).
 // ------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(1024) void k_reduce_nll(const float *__restrict__ nll, const float *__restrict__ nblue,
-                                                     int B, float *__restrict__ scal) {
-    __shared__ double sh[2][16];
+constexpr int NRED = 32;
+static __global__ __launch_bounds__(256) void k_reduce_nll(const float *__restrict__ nll, const float *__restrict__ nblue,
+                                                           int B, float *__restrict__ scal, double *__restrict__ part,
+                                                           unsigned *__restrict__ ticket) {
+    __shared__ double sh[2][4];
+    __shared__ bool last;
+    const int per = (B + (int)gridDim.x - 1) / (int)gridDim.x, s0 = blockIdx.x * per, s1 = min(B, s0 + per);
     double a = 0.0, nb = 0.0;
-    for (int s = threadIdx.x; s < B; s += blockDim.x) {
+    for (int s = s0 + threadIdx.x; s < s1; s += 256) {
         a += (double)nll[s];
         nb += nblue[s] > 0.f ? 1.0 : 0.0;
     }
@@ -515,10 +523,22 @@ static __global__ __launch_bounds__(1024) void k_reduce_nll(const float *__restr
     __syncthreads();
     if (threadIdx.x == 0) {
         double ta = 0.0, tb = 0.0;
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { ta += sh[0][i]; tb += sh[1][i]; }
-        scal[3] += (float)tb;
-        scal[4] += (float)ta;
-        scal[5] += (float)B;
+        for (int i = 0; i < 4; ++i) { ta += sh[0][i]; tb += sh[1][i]; }
+        part[blockIdx.x] = ta;
+        part[NRED + blockIdx.x] = tb;
+        __threadfence();                                          // release: the partial sums before the ticket
+        last = atomicAdd(ticket, 1u) == (unsigned)gridDim.x - 1u;
+        if (last) {
+            __threadfence();                                      // acquire: the other blocks' partial sums
+            ta = 0.0; tb = 0.0;
+            for (int i = 0; i < (int)gridDim.x; ++i) {
+                ta += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tb += __hip_atomic_load(part + NRED + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            scal[3] += (float)tb;
+            scal[4] += (float)ta;
+            scal[5] += (float)B;
+        }
     }
 }
 
