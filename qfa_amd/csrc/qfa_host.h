@@ -21,6 +21,10 @@ void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int
 
 namespace {
 
+#ifndef QFA_P1_XDL32
+#define QFA_P1_XDL32 1      // pass 1 at N_h > 16: 1 = k_moments_x (XDL pipe, two column sweeps per tile), 0 = k_moments (f32 MFMA)
+#endif
+
 inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
 
 // Work plan of a pass (WorkPlan, qfa_common.h): the blocks of 64 spectra that fill whole rounds of the 512
@@ -76,13 +80,14 @@ Layout make_layout_t(int B, int Npix) {
     L.Bpad = round_up(B, 16);
     L.ntiles32 = (Npix + 31) / 32;
     L.wp2 = plan_work(B, L.ntiles, 4, 256 * (KP == 8 ? QFA_G8_OCC : (KP > 16 ? 1 : 2)));
-    L.wp1 = KP <= 16 ? plan_work(B, L.ntiles32, 1) : plan_work(B, L.ntiles, 2);
+    // pass 1 runs on the XDL pipe at every N_h (32-pixel tiles; one workgroup per CU at N_h > 16)
+    L.wp1 = KP <= 16 ? plan_work(B, L.ntiles32, 1) : (QFA_P1_XDL32 ? plan_work(B, L.ntiles32, 1, 256) : plan_work(B, L.ntiles, 2));
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
     L.oPF = take((size_t)L.ntiles * C::TILE_PF);
     L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
     L.oPFX = 0;
-    if constexpr (KP <= 16) L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4));
+    L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4));
     L.oPGX = 0;
     L.wp2x = WorkPlan{0, 0, 1, 0};
     if constexpr (KP == 8 || KP == 16) {
@@ -170,7 +175,7 @@ template <int KP, bool PREDICT>
 void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, const float *mu, int B, int Npix,
                    int Nb, int Nh, const Layout &L, float *ws, hipStream_t st) {
     float *MOM = ws + L.oMOM;
-    if constexpr (KP <= 16) {
+    if constexpr (KP <= 16 || QFA_P1_XDL32) {
         unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
         k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, Npix, Nb, Nh, PFX);
 #ifndef QFA_XNW

@@ -22,10 +22,22 @@ template <int KP>
 struct XCfg {
     using C = Cfg<KP>;
     static constexpr int NCOL = C::FW + C::PW;               // f columns first, then the pair columns
-    static constexpr int PSTR = NCOL * 64;                    // bytes of one piece: 32 px x bf16 per column
-    static constexpr int OFF_PSI = 3 * PSTR;                  // float32 Psi[32], omega[32], mu[32] (prediction)
-    static constexpr int TILE_B = (3 * PSTR + 384 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
-    static constexpr int NCHUNK = TILE_B / 1024;
+    static constexpr int NCT = NCOL / 16;                     // 16-column tiles: 4 / 10 / 35
+    // N_h > 16: the image of a 32-pixel tile (105 KiB) does not fit LDS twice -- it is cut into NSW = 2 sub-images of
+    // column tiles [0, CT1) and [CT1, NCT), which a tile step sweeps one after the other (ring slot 0 / slot 1)
+    static constexpr int NSW = KP > 16 ? 2 : 1;
+    static constexpr int CT1 = (NCT + NSW - 1) / NSW;
+    static constexpr int nct(int j) { return j == 0 ? CT1 : NCT - CT1; }
+    static constexpr int pstr(int j) { return nct(j) * 1024; }   // bytes of one piece of sub-image j: 32 px x bf16 per column
+    static constexpr int PSTR = pstr(0);
+    static constexpr int OFF_PSI = 3 * PSTR;                  // in sub-image 0: float32 Psi[32], omega[32], mu[32] (prediction)
+    static constexpr int SUB0_B = (3 * PSTR + 384 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
+    static constexpr int SUB1_B = NSW > 1 ? 3 * pstr(1) : 0;
+    static constexpr int sub_off(int j) { return j == 0 ? 0 : SUB0_B; }
+    static constexpr int sub_bytes(int j) { return j == 0 ? SUB0_B : SUB1_B; }
+    static constexpr int TILE_B = SUB0_B + SUB1_B;            // bytes of a tile in global memory
+    static constexpr int SLOT_B = SUB0_B > SUB1_B ? SUB0_B : SUB1_B;       // LDS ring slot
+    static constexpr int NCHUNK = SUB0_B / 1024;
 };
 
 // LDS-DMA: the wave's 64 lanes move 64 x 16 B from per-lane global addresses to LDS byte address lds_dst + 16 * lane
@@ -106,13 +118,15 @@ __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, c
         unsigned h, m, l;
         split2(v[0], v[1], h, m, l);
         // lane-linear for the B-operand read: [16-column tile][8-pixel group][column][8 px]
-        unsigned *dst = reinterpret_cast<unsigned *>(tile + (c >> 4) * 1024 + (q >> 3) * 256 + (c & 15) * 16 + (q & 7) * 2);
+        const int ct = c >> 4, sw = ct >= X::CT1 ? 1 : 0, ctl = ct - (sw ? X::CT1 : 0), ps = sw ? X::pstr(1) : X::pstr(0);
+        unsigned *dst = reinterpret_cast<unsigned *>(tile + (sw ? X::SUB0_B : 0) + ctl * 1024 + (q >> 3) * 256 + (c & 15) * 16 +
+                                                     (q & 7) * 2);
         dst[0] = h;
-        dst[X::PSTR / 4] = m;
-        dst[2 * X::PSTR / 4] = l;
+        dst[ps / 4] = m;
+        dst[2 * ps / 4] = l;
     }
     float *po = reinterpret_cast<float *>(tile + X::OFF_PSI);
-    for (int idx = threadIdx.x; idx < (X::TILE_B - X::OFF_PSI) / 4; idx += 256) {
+    for (int idx = threadIdx.x; idx < (X::SUB0_B - X::OFF_PSI) / 4; idx += 256) {
         const int i = 32 * blockIdx.x + (idx & 31);
         float v = 0.f;
         if (idx < 32) v = i < Npix ? Psi[i] : 0.f;
@@ -167,13 +181,13 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
     return xdl(ah, bh, c);
 }
 template <int KP, bool PREDICT, int NW>
-__global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
+__global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                       const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
                                                       int ntiles, WorkPlan wp, const unsigned char *__restrict__ PFX,
                                                       float *__restrict__ MOM) {
     using C = Cfg<KP>;
     using X = XCfg<KP>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][X::TILE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][X::SLOT_B];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
@@ -205,16 +219,19 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
     float cn = 0.f, cblue = 0.f;
 
     // LDS-DMA of one image tile: wave w moves the 1-KiB pieces w, w+4, ...
-    constexpr int NPIECE = (X::NCHUNK + 3) / 4;                   // pieces per wave and tile
-    auto stage_piece = [&](int tg, int buf, int i) {
-        const int ch = wv + 4 * i;
-        if (ch < X::NCHUNK)
-            glds16a(PFX + (size_t)tg * X::TILE_B + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(&lds[buf][ch * 1024])));
-    };
-    auto stage = [&](int tg, int buf) {
+    // (sub-image j of tile tg into ring slot buf; NSW = 1: the whole tile)
+    auto stage_sub = [&](int tg, auto jtag, int buf) {
+        constexpr int J = decltype(jtag)::value;
+        constexpr int NCH = X::sub_bytes(J) / 1024;
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i) stage_piece(tg, buf, i);
+        for (int i = 0; i < (NCH + 3) / 4; ++i) {
+            const int ch = wv + 4 * i;
+            if (ch < NCH)
+                glds16a(PFX + (size_t)tg * X::TILE_B + X::sub_off(J) + ch * 1024, (unsigned)lane * 16u,
+                        wave_uniform(lds_addr(&lds[buf][ch * 1024])));
+        }
     };
+    auto stage = [&](int tg, int buf) { stage_sub(tg, std::integral_constant<int, 0>{}, buf); };
 
     auto run = [&](auto blue_tag, int ta, int tb) {
         constexpr bool BLUE = decltype(blue_tag)::value;
@@ -344,23 +361,30 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
             qd += (double)qd8;
             ld += (double)ld8;
         };
-        // ---- phase 3: per 16-column tile of the image three ds_read_b128, then 6 (red) or 12 (blue) XDL MFMAs
-        auto mfmas = [&](const unsigned char *tile, const Pieces &w) {
+        // ---- phase 3: per 16-column tile of the image three ds_read_b128, then 6 (red) or 12 (blue) XDL MFMAs.
+        // J: the sub-image in `tile` (N_h > 16: column tiles [0, CT1) or [CT1, NCT); else all of them)
+        auto mfmas = [&](const unsigned char *tile, const Pieces &w, auto jtag) {
+            constexpr int J = decltype(jtag)::value;
+            constexpr int CT0 = J == 0 ? 0 : X::CT1, CTE = J == 0 ? X::CT1 : X::NCT, PS = X::pstr(J);
             const unsigned char *bcol = tile + lane * 16;            // lane-linear: conflict-free ds_read_b128
             auto rdB = [&](int piece, int ct) {
-                return *reinterpret_cast<const u32x4 *>(bcol + piece * X::PSTR + ct * 1024);
+                return *reinterpret_cast<const u32x4 *>(bcol + piece * PS + (ct - CT0) * 1024);
             };
 #pragma unroll
             for (int t = 0; t < C::NFT; ++t) {
-                const u32x4 bh = rdB(0, t), bm = rdB(1, t), bl = rdB(2, t);
-                accb[t] = xdl6(w.w3h, w.w3m, w.w3l, bh, bm, bl, accb[t]);
-                if (BLUE) accb2[t] = xdl6(w.w4h, w.w4m, w.w4l, bh, bm, bl, accb2[t]);
+                if (t >= CT0 && t < CTE) {
+                    const u32x4 bh = rdB(0, t), bm = rdB(1, t), bl = rdB(2, t);
+                    accb[t] = xdl6(w.w3h, w.w3m, w.w3l, bh, bm, bl, accb[t]);
+                    if (BLUE) accb2[t] = xdl6(w.w4h, w.w4m, w.w4l, bh, bm, bl, accb2[t]);
+                }
             }
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
-                const u32x4 bh = rdB(0, C::NFT + t), bm = rdB(1, C::NFT + t), bl = rdB(2, C::NFT + t);
-                accC[t] = xdl_ct(w.w1h, w.w1m, w.w1l, bh, bm, bl, accC[t]);
-                if (BLUE) accT[t] = xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
+                if (C::NFT + t >= CT0 && C::NFT + t < CTE) {
+                    const u32x4 bh = rdB(0, C::NFT + t), bm = rdB(1, C::NFT + t), bl = rdB(2, C::NFT + t);
+                    accC[t] = xdl_ct(w.w1h, w.w1m, w.w1l, bh, bm, bl, accC[t]);
+                    if (BLUE) accT[t] = xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
+                }
             }
         };
 
@@ -378,11 +402,38 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
             const bool reload = active & (c + 2 < n);
             if (reload) load_spec(ta + c + 2, cur);
             __builtin_amdgcn_sched_barrier(0);
-            if (active) mfmas(lds[buf], w);
+            if (active) mfmas(lds[buf], w, std::integral_constant<int, 0>{});
             // retire everything up to and including the DMA: it was issued before the 5 (red: 2 delta, 2 sigma,
             // 1 mask) / 7 (blue: + 2 zabs) spectra loads of this step (the ragged-end path issues more, smaller ones)
             if (reload) dma_wait<BLUE ? 7 : 5>();
             else dma_wait<0>();
+            wg_barrier();
+            asm volatile("" ::: "memory");
+        };
+
+        // N_h > 16, one tile in two sweeps: sub-image 0 lives in ring slot 0, sub-image 1 in slot 1.  Sweep 0: weights,
+        // DMA of this tile's sub-image 1, the spectra of tile c + 2, the MFMAs of the first column tiles; sweep 1: DMA of
+        // the next tile's sub-image 0 (slot 0 is free behind the barrier), the remaining MFMAs.  The second wait is for
+        // everything: the spectra requested in sweep 0 have had a whole tile step (~3 us at N_h = 32) by then.
+        auto step2 = [&](int c, SpecRegsX &cur) {
+            Pieces w;
+            land<BLUE>(cur);
+            if (active) weights(ta + c, cur, lds[0], w);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_sub(ta + c, std::integral_constant<int, X::NSW - 1>{}, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool reload = active & (c + 2 < n);
+            if (reload) load_spec(ta + c + 2, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) mfmas(lds[0], w, std::integral_constant<int, 0>{});
+            if (reload) dma_wait<BLUE ? 7 : 5>();
+            else dma_wait<0>();
+            wg_barrier();
+            asm volatile("" ::: "memory");
+            if (c + 1 < n) stage(ta + c + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) mfmas(lds[1], w, std::integral_constant<int, X::NSW - 1>{});
+            dma_wait<0>();
             wg_barrier();
             asm volatile("" ::: "memory");
         };
@@ -396,8 +447,13 @@ __global__ __launch_bounds__(256, 2) void k_moments_x(qfa_params_t p, qfa_batch_
         dma_wait<0>();
         __syncthreads();
         for (int c = 0; c < n; c += 2) {
-            step(c, ra, 0);
-            if (c + 1 < n) step(c + 1, rb, 1);
+            if constexpr (X::NSW == 1) {
+                step(c, ra, 0);
+                if (c + 1 < n) step(c + 1, rb, 1);
+            } else {
+                step2(c, ra);
+                if (c + 1 < n) step2(c + 1, rb);
+            }
         }
         __syncthreads();
     };
