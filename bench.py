@@ -295,7 +295,7 @@ def main():
     nk2 = npix * nh * nh
     if dominant == "k_grads_x":
         xdl_flops = (6 * 1 + 4 * 2) * nk2
-    elif dominant == "k_moments" and nh <= 16:
+    elif dominant == "k_moments":
         xdl_flops = 6 * 4 * nk2
     else:
         xdl_flops = None          # k_grads (N_h <= 8, 17..32): stage 1 on the float32 MFMA, no XDL roof to price against
