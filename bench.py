@@ -117,6 +117,8 @@ def cpu_baseline(params, batch, n_sample, npix, config):
                   f"(host reports {os.cpu_count()} cpus, usable {usable_cores()})",
         "lowrank_oracle_spectra_per_s": 1.0 / dt_lr,
         "loss_finite": bool(np.isfinite(float(loss))),
+        "loss_note": "the float32 port (like the reference, SURVEY App. B Q7) overflows det() to inf at N_h >= 16; the HIP "
+                     "path takes log det from the pivots and stays finite; the timing is unaffected",
         "true_reference_8core_survey": REFERENCE_8CORE.get(config),
         "true_reference_note": "the imported reference's forward on the survey container's 8 cores at this shape "
                                "(SURVEY.md section 6); it cannot travel to the GPU box",
