@@ -193,13 +193,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    local %= max(1, torch.cuda.device_count())          # (fewer devices than ranks: a rehearsal on one GPU shares it)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("QFA_BENCH_FORCE_DIST") == "1"     # (the flag rehearses RCCL at N = 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL (backend "nccl" on ROCm); QFA_BENCH_BACKEND=gloo rehearses N > 1 with ranks that share one GPU (RCCL refuses
+        # two ranks on a device): the packed buffer then goes through host memory, timings are not a scaling measurement
+        backend = os.environ.get("QFA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     B, npix, nh, masks, n_cpu = CONFIGS[args.config]
     if args.batch:
