@@ -34,7 +34,8 @@ def run(lib, out, npix, nh, B):
 
 @pytest.mark.parametrize("npix,nh,B", [(4000, 16, 3000),      # k_moments_x<16>, k_grads_x, k_predict_x<16>; full tiles
                                        (1913, 8, 2500),       # k_moments_x<8>, k_predict_x<8>; ragged last tile
-                                       (1000, 12, 700)])      # N_h = 12 on the 16-wide XDL kernels
+                                       (1000, 12, 700),       # N_h = 12 on the 16-wide XDL kernels
+                                       (1100, 24, 300)])      # N_h = 24: k_moments_x<32> (two column sweeps per tile)
 def test_tracked_build_is_bit_identical(tmp_path, npix, nh, B):
     assert os.path.exists(TRACKED), "libqfa_tracked.so missing: __graft_entry__.build() / make -C qfa_amd/csrc tracked"
     a = run(None, str(tmp_path / "shipped.npz"), npix, nh, B)
