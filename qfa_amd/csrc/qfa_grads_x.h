@@ -49,31 +49,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// 4 bytes per lane into LDS (any source alignment: tools/ubench/glds_align.hip); see glds16a for M0
-__device__ __forceinline__ void glds4a(const void *sbase, unsigned voff, unsigned lds_dst) {
-#if QFA_TRACKED_LOADS
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(sbase) + voff),
-        (__attribute__((address_space(3))) void *)(size_t)__builtin_amdgcn_readfirstlane((int)lds_dst), 4, 0, 0);
-#else
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-#endif
-}
-// a pointer the compiler can see is wave-uniform (an "s" asm operand needs that; values derived from blockIdx through
-// divisions are not always proven uniform)
-template <typename T>
-__device__ __forceinline__ const T *uniform_ptr(const T *p) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
-                   hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-    return reinterpret_cast<const T *>(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ void step_barrier() {        // LDS writes of this step done, then the workgroup barrier
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wg_barrier();
-    asm volatile("" ::: "memory");
-}
-
 template <int KP_>
 struct GXT {                                             // KP = 16 (N_h = 9..16) or 8 (N_h <= 8)
     static constexpr int KP = KP_, KK2 = KP * (KP + 1) / 2;

@@ -7,6 +7,7 @@
 
 #include "qfa_step_kernels.h"
 #include "qfa_xdl_kernels.h"
+#include "qfa_s12_x.h"
 
 // pass 2 for N_h <= 16 with every contraction on the XDL pipe (qfa_grads_x.h: KP = 8 or 16, built in qfa_gx.hip)
 size_t qfa_gx_image_bytes(int KP, int ntiles32);
@@ -21,6 +22,9 @@ void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int
 
 namespace {
 
+#ifndef QFA_P2_S12
+#define QFA_P2_S12 1        // pass 2 at N_h > 16: 1 = k_s12_x + two k_grads_s3, 0 = k_grads (f32 stage 1) + one k_grads_s3
+#endif
 #ifndef QFA_P1_XDL32
 #define QFA_P1_XDL32 1      // pass 1 at N_h > 16: 1 = k_moments_x (XDL pipe, two column sweeps per tile), 0 = k_moments (f32 MFMA)
 #endif
@@ -93,6 +97,9 @@ Layout make_layout_t(int B, int Npix) {
     if constexpr (KP == 8 || KP == 16) {
         L.oPGX = take(qfa_gx_image_bytes(KP, L.ntiles32) / 4);
         L.wp2x = plan_work(B, L.ntiles32, 3, 256, 64);
+    } else if constexpr (QFA_P2_S12 != 0) {            // N_h = 17..32: stages 1 and 2 of pass 2 by k_s12_x (qfa_s12_x.h)
+        L.oPGX = take((size_t)L.ntiles32 * (S12<KP>::TILE_B / 4));
+        L.wp2x = plan_work(B, L.ntiles32, 3, 256, 64);
     }
     L.oPXI = 0;
     L.wpp = WorkPlan{0, 0, 1, 0};
@@ -107,8 +114,8 @@ Layout make_layout_t(int B, int Npix) {
     L.oNBL = take((size_t)L.Bpad);
     L.oRED = take(2 * 2 * NRED + 2);                    // k_reduce_nll: 2 x NRED doubles + the ticket counter
     L.oBG = 0;
-    L.bg_stride = L.NpixPad;
-    if constexpr (KP == 32) L.oBG = take(2 * (size_t)round_up(B, 64) * L.NpixPad);
+    L.bg_stride = round_up(Npix, 32);
+    if constexpr (KP == 32) L.oBG = take(2 * (size_t)round_up(B, 64) * L.bg_stride);
     L.total = o;
     return L;
 }
@@ -259,6 +266,21 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     if (pass2_xdl) {
         qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
                       accum, slab, slabS, (int)D.stride, st);
+        if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
+        mark(4);
+        return hip_status();
+    }
+    if constexpr (KP == 32 && QFA_P2_S12 != 0) {
+        // stages 1 and 2 for every (spectrum, pixel) on the XDL pipe, beta / gamma through HBM, then stage 3 per 16 columns
+        float *BG = ws + L.oBG, *GG = BG + (size_t)round_up(B, 64) * L.bg_stride;
+        unsigned char *IMG = reinterpret_cast<unsigned char *>(ws + L.oPGX);
+        k_prep_s12<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, IMG);
+        if (b.A_blue)
+            k_s12_x<KP, true><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride);
+        else
+            k_s12_x<KP, false><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride);
+        for (int bh = 0; 16 * bh < Nh; ++bh)
+            k_grads_s3<KP><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, bh, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
         return hip_status();

@@ -1,0 +1,479 @@
+// qfa_s12_x.h -- pass 2 for N_h = 17..32, stages 1 and 2 on the XDL pipe (k_s12_x).
+//
+// k_grads_x (qfa_grads_x.h) does not scale to KP = 32: its hand-over slots, staging buffers and a 110 KiB image ring
+// need 250 KiB of LDS, and stage 3 would need Z of 16 spectra for 32 columns in registers.  Pass 2 is therefore cut
+// differently there:
+//   k_s12_x      stage 1 ([f^T y | f^T C^-1' f], K = 32 + 528 as 18 K-steps of six v_mfma_f32_16x16x32_bf16) and stage 2
+//                (u, diag Sigma^-1, dG, the Psi / omega / tau0 / beta / c0 sums) for every (spectrum, pixel); the per-pixel
+//                sums are flushed, beta = wD A^2 and gamma = A u go to HBM ([Bpad64][NpixPad] each);
+//   k_grads_s3   (qfa_step_kernels.h) stage 3 from beta / gamma, once per 16 output columns.
+// Lane layout as role A of k_grads_x: a wave = 16 spectra, lane (lo = lane & 15, g = lane >> 4) owns spectra
+// s0 + 4 g + r (r = 0..3) at the pixels 32 t + 2 lo + h of half h of tile t; the A operand of stage 1 (y, C^-1' of the
+// wave's spectra as three bf16 pieces, 216 registers) is loaded once per work item -- one wave per SIMD, 512 registers,
+// built in the N_h > 16 translation unit.  Workgroup = 4 such waves = 64 spectra, no roles.
+//
+// The image of a 16-pixel half (18 K-steps x 3 pieces x 1 KiB = 54 KiB) moves through LDS in two QUARTERS of 9
+// K-steps (ring of 3 x 28 KiB: a quarter + the KiB with Psi / omega of the half): a tile step is four sub-steps
+// [issue the LDS-DMA of the quarter two ahead | the 54 MFMAs of this one (+ stage 2 of the half behind its second
+// quarter) | counted wait for the next quarter | barrier].  The spectra go the way of k_grads_x: every wave streams the
+// row segments of its 16 spectra (delta, sigma, zabs, mask) into its own LDS staging buffers by LDS-DMA TWO tiles ahead
+// and copies the tile it starts on into registers.  Every request of the hot path is an asm statement, so hipcc inserts
+// no vmcnt wait of its own (ordinary loads did: pass 2 at c5 5.2 ms against 4.2); the waits count the requests that
+// may stay in flight (dma_wait_n), the requests per sub-step being known numbers.
+#pragma once
+#include "qfa_common.h"
+#include "qfa_xdl_kernels.h"
+
+#ifndef QFA_S12_ABL
+#define QFA_S12_ABL 0        // timing-only ablations: 1 no beta / gamma stores, 2 no spectra loads, 4 no stage 2
+#endif
+typedef float s12_f32x2 __attribute__((ext_vector_type(2)));
+template <int KP>
+struct S12 {
+    static constexpr int KK2 = KP * (KP + 1) / 2;
+    static constexpr int NKS = 1 + (KK2 + 31) / 32;          // 18 at KP = 32
+    static_assert(NKS % 2 == 0, "two quarters of NKS / 2 K-steps");
+    static constexpr int NKQ = NKS / 2;                        // K-steps per quarter
+    static constexpr int Q_B = NKQ * 3 * 1024;                 // bytes of a quarter image (27 KiB)
+    static constexpr int SLOT_B = Q_B + 1024;                  // ring slot: + Psi[16], omega[16] of the half (float32, one KiB)
+    static constexpr int HALF_B = 2 * Q_B + 1024;              // global: [quarter 0 | Psi/omega KiB | quarter 1]
+    static constexpr int TILE_B = 2 * HALF_B;                  // 110 KiB per 32-pixel tile
+    static constexpr int STG_ARR = 16 * 128;                   // staging: one array of one tile, [16 rows][32 px] float
+    static constexpr int STG_MASK = 3 * STG_ARR;               // mask bytes [16 rows][32 px]
+    static constexpr int STG_B = 3 * STG_ARR + 512;            // delta | sigma | zabs | mask (6.5 KiB per wave and tile)
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_prep_s12 : F, Psi, omega -> the image above, one block per 32-pixel tile.
+//   half h, K-step ks, piece, lane (g, lo), 8 k:  B[k = 32 ks + 8 g + j][px = 2 lo + h];  ks = 0: F[px][k];
+//   ks >= 1: pair q = 32 (ks - 1) + 8 g + j -> F[px][a_q] F[px][b_q]
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void k_prep_s12(const float *__restrict__ F, const float *__restrict__ Psi,
+                                                  const float *__restrict__ omega, int Npix, int Nb, int Nh,
+                                                  unsigned char *__restrict__ IMG) {
+    using X = S12<KP>;
+    unsigned char *tile = IMG + (size_t)blockIdx.x * X::TILE_B;
+    const int p0 = 32 * blockIdx.x;
+    __shared__ float f[32][KP + 1];
+    for (int i = threadIdx.x; i < 32 * KP; i += 256) {
+        const int px = i / KP, a = i % KP;
+        f[px][a] = (p0 + px < Npix && a < Nh) ? F[(size_t)(p0 + px) * Nh + a] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * X::NKS * 64; i += 256) {
+        const int lane = i & 63, ks = (i >> 6) % X::NKS, h = i / (64 * X::NKS);
+        const int lo = lane & 15, g = lane >> 4, px = 2 * lo + h;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 8 * g + j;
+            float x = 0.f;
+            if (ks == 0) {
+                if (kk < KP) x = f[px][kk];
+            } else {
+                const int q = 32 * (ks - 1) + kk;
+                if (q < X::KK2) {
+                    int a = 0;
+                    while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
+                    const int b = a + (q - pair_index(a, a, KP));
+                    x = f[px][a] * f[px][b];
+                }
+            }
+            v[j] = x;
+        }
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b, c;
+            split2(v[2 * q], v[2 * q + 1], a, b, c);
+            ph[q] = a; pm[q] = b; pl[q] = c;
+        }
+        const int qt = ks / X::NKQ, kq = ks % X::NKQ;
+        unsigned char *dst = tile + h * X::HALF_B + qt * (X::Q_B + 1024) + kq * 3072 + lane * 16;
+        *reinterpret_cast<u32x4 *>(dst) = ph;
+        *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+        *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+    }
+    for (int i = threadIdx.x; i < 512; i += 256) {            // Psi, omega of each half's pixels (+ zero padding of the KiB)
+        const int h = i >> 8, j = i & 255;
+        float *po = reinterpret_cast<float *>(tile + h * X::HALF_B + X::Q_B);
+        const int px = p0 + 2 * (j & 15) + h;
+        float v = 0.f;
+        if (j < 16) v = px < Npix ? Psi[px] : 0.f;
+        else if (j < 32) v = px < Nb ? omega[px] : 0.f;
+        po[j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_s12_x.  One work item = (block of 64 spectra, range of 32-pixel tiles).  slab != NULL: deterministic mode (the
+// per-pixel sums go to row blk of the slab by plain stores, the scalar sums to slabS[item][wave][3]).
+// ------------------------------------------------------------------------------------------------
+template <int KP, bool HASA>
+__global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix, int Nb,
+                                                  int Nh, int ntiles, WorkPlan wp, const unsigned char *__restrict__ IMG,
+                                                  const float *__restrict__ SOL, float *__restrict__ BG,
+                                                  float *__restrict__ GG, int bg_stride, float *__restrict__ accum,
+                                                  float *__restrict__ slab, double *__restrict__ slabS, int slab_stride) {
+    using C = Cfg<KP>;
+    using X = S12<KP>;
+    constexpr int RING = 3;                                    // quarters in LDS: two of DMA distance (the image streams
+                                                               // from the Infinity Cache: 27.5 MB at c5 against 4 MB of L2)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RING][X::SLOT_B];
+    __shared__ __attribute__((aligned(16))) unsigned char lstg[4][2][X::STG_B];      // [wave][tile parity]
+    __shared__ float lpsum[2][4][4][32];                       // [tile parity][wave][sumA | gPsi | gOmega | cnt][32 px]
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_uniform(tid >> 6);
+    const int lo = lane & 15, g = lane >> 4;
+    int blk, seg, t0, t1;
+    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
+    const int s0 = blk * 64 + wv * 16;
+    const bool active = s0 < B;                                // wave-uniform
+    const int n = t1 - t0;
+    const int nbt = (Nb + 31) >> 5;
+    const DevConsts k = load_consts(p, tau);
+    const bool det = slab != nullptr;
+    float *accA = (det ? slab + (size_t)blk * (size_t)slab_stride : accum) + (size_t)Npix * Nh;   // sumA | gPsi | gOmega | cnt
+    float *accS = accum + (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
+    for (int i = tid; i < 2 * 4 * 4 * 32; i += 256) (&lpsum[0][0][0][0])[i] = 0.f;      // inactive waves' rows stay 0
+
+    // A operand of stage 1: spectrum s0 + lo, k = 32 ks + 8 g + j
+    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::NKS];
+    {
+        const bool v = active && (s0 + lo) < B;
+        const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+#pragma unroll
+        for (int ks = 0; ks < X::NKS; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kk = 8 * g + 2 * q + e;
+                    float val = 0.f;
+                    if (ks == 0) {
+                        if (v && kk < KP) val = sol[kk];
+                    } else {
+                        const int qq = 32 * (ks - 1) + kk;
+                        if (v && qq < X::KK2) val = sol[C::SOL_CI + qq];
+                    }
+                    x[e] = val;
+                }
+                unsigned a, b, c;
+                split2(x[0], x[1], a, b, c);
+                S1h[ks][q] = a; S1m[ks][q] = b; S1l[ks][q] = c;
+            }
+        }
+    }
+    bool sv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sv[r] = active && (s0 + 4 * g + r) < B;
+    // (a small window: the workgroups of an XCD then stream the same few tiles of the image through its L2)
+    const int rot = n > 0 ? (int)(((unsigned)blk * 2654435761u) % (unsigned)min(n, 4)) : 0;
+    auto tile_of = [&](int c) {
+        int x = c + rot;
+        if (x >= n) x -= n;
+        return t0 + x;
+    };
+
+    struct Spec {                      // one lane's 4 spectra x 2 pixels of a tile; sigma < 0: masked
+        float d[4][2], sg[4][2], z[4][2];
+    };
+    // Staging (qfa_grads_x.h): slot q of an array holds row q ^ ((q >> 2) & 1); 16-byte pieces, two instructions per
+    // float array, the mask as 4-byte pieces.  Returns the requests issued: 8 (all 32 pixels inside the row and, on a blue
+    // tile, inside the blue side), else 0 = "ragged: ordinary loads and LDS stores, wait for everything".
+    const int last_row = active ? min(15, B - 1 - s0) : 0;          // wave-uniform
+    const float *dbase = uniform_ptr(bt.delta + (size_t)(active ? s0 : 0) * Npix);
+    const float *ebase = uniform_ptr(bt.error + (size_t)(active ? s0 : 0) * Npix);
+    const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)(active ? s0 : 0) * Npix);
+    const float *zbase = uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
+    auto stage_tile = [&](int tg, int par) -> int {
+        if (QFA_S12_ABL & 2) return 8;
+        const bool zblue = tg < nbt;                                                      // wave-uniform
+        const bool fast = (32 * tg + 31 < Npix) && (!zblue || 32 * tg + 31 < Nb) && !QFA_TRACKED_LOADS;
+        const float *zb = zblue ? zbase : dbase;
+        const int zlen = zblue ? Nb : Npix;
+        unsigned char *buf = lstg[wv][par];
+        if (fast) {
+            const unsigned dst = wave_uniform(lds_addr(buf));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = 8 * i + (lane >> 3);
+                const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+                const unsigned pc = 4u * (unsigned)(lane & 7);                            // first pixel of the piece
+                const unsigned o = row * (unsigned)Npix + 32u * (unsigned)tg + pc;
+                glds16a(dbase, 4u * o, dst + 0 * X::STG_ARR + i * 1024);
+                glds16a(ebase, 4u * o, dst + 1 * X::STG_ARR + i * 1024);
+                glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * X::STG_ARR + i * 1024);
+                glds4a(mbase, o, dst + X::STG_MASK + i * 256);
+            }
+            return 8;
+        }
+        float *sf = reinterpret_cast<float *>(buf);
+        unsigned char *mb = buf + X::STG_MASK;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = 2 * i + (lane >> 5), pxl = lane & 31;
+            const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+            const int px = 32 * tg + pxl;
+            const unsigned o = row * (unsigned)Npix + (unsigned)min(px, Npix - 1);
+            sf[0 * (X::STG_ARR / 4) + q * 32 + pxl] = dbase[o];
+            sf[1 * (X::STG_ARR / 4) + q * 32 + pxl] = ebase[o];
+            sf[2 * (X::STG_ARR / 4) + q * 32 + pxl] = zb[row * (unsigned)zlen + (unsigned)min(px, zlen - 1)];
+            mb[q * 32 + pxl] = px < Npix ? mbase[o] : (unsigned char)0;
+        }
+        return 0;
+    };
+    auto take_tile = [&](int par, Spec &cur) {
+        const unsigned char *sb = lstg[wv][par] + 8 * lo;
+        const unsigned char *mb = lstg[wv][par] + X::STG_MASK + 2 * lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int slot = 4 * g + (r ^ (g & 1));
+            const s12_f32x2 d2 = *reinterpret_cast<const s12_f32x2 *>(sb + 0 * X::STG_ARR + slot * 128);
+            const s12_f32x2 e2 = *reinterpret_cast<const s12_f32x2 *>(sb + 1 * X::STG_ARR + slot * 128);
+            const s12_f32x2 z2 = *reinterpret_cast<const s12_f32x2 *>(sb + 2 * X::STG_ARR + slot * 128);
+            const unsigned mk = *reinterpret_cast<const unsigned short *>(mb + slot * 32);
+            cur.d[r][0] = d2[0]; cur.d[r][1] = d2[1];
+            cur.sg[r][0] = (mk & 0xffu) ? fabsf(e2[0]) : -1.f;        // (sign bit = masked; only sigma^2 is used)
+            cur.sg[r][1] = (mk & 0xff00u) ? fabsf(e2[1]) : -1.f;
+            cur.z[r][0] = z2[0]; cur.z[r][1] = z2[1];
+        }
+    };
+
+    // LDS-DMA of quarter u (u = 4 c + 2 h + j: tile c, half h, K-range j) into ring slot u % RING; wave w moves the 1-KiB
+    // pieces w, w + 4, ...; the quarter with j = 0 is followed by the half's Psi / omega KiB
+    auto get_quarter = [&](int u) {
+        const int c = u >> 2, h = (u >> 1) & 1, j = u & 1;
+        const unsigned char *src = uniform_ptr(IMG + (size_t)tile_of(c) * X::TILE_B + h * X::HALF_B + j * (X::Q_B + 1024));
+        unsigned char *dst = lds[u % RING];
+        constexpr int NCH = X::Q_B / 1024;
+#pragma unroll
+        for (int i = 0; i < (NCH + 1 + 3) / 4; ++i) {
+            const int ch = wv + 4 * i;
+            if (ch < NCH) glds16a(src + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(dst + ch * 1024)));
+            else if (ch == NCH && j == 0)
+                glds16a(src + X::Q_B, (unsigned)lane * 16u, wave_uniform(lds_addr(dst + X::Q_B)));
+        }
+    };
+
+    double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;
+    f32x4 afy, aq;
+    float PsiH = 0.f, omH = 0.f;
+
+    // the K-steps of quarter j of a half: B pieces of K-step ks + 1 are read while the six MFMAs of ks run
+    auto quarter = [&](auto jtag, const unsigned char *img) {
+        constexpr int j = decltype(jtag)::value;
+        const unsigned char *bp = img + lane * 16;
+        if (j == 0) {
+            afy = f32x4{0.f, 0.f, 0.f, 0.f};
+            aq = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *po = reinterpret_cast<const float *>(img + X::Q_B);
+            PsiH = po[lo];
+            omH = po[16 + lo];
+        }
+        u32x4 bq[2][3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
+#pragma unroll
+        for (int kq = 0; kq < X::NKQ; ++kq) {
+            if (kq + 1 < X::NKQ) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    bq[(kq + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (kq + 1) * 3072 + pc * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 &bh = bq[kq & 1][0], &bm = bq[kq & 1][1], &bl = bq[kq & 1][2];
+            // (ks = NKQ j + kq is a compile-time constant per (j, kq): j is passed as a literal below)
+            if (j == 0) {
+                if (kq == 0) afy = xdl6(S1h[0], S1m[0], S1l[0], bh, bm, bl, afy);
+                else aq = xdl6(S1h[kq], S1m[kq], S1l[kq], bh, bm, bl, aq);
+            } else {
+                aq = xdl6(S1h[X::NKQ + kq], S1m[X::NKQ + kq], S1l[X::NKQ + kq], bh, bm, bl, aq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // stage 2 of the lane's four elements of half h of tile tg (as role A of k_grads_x), beta / gamma to HBM, per-pixel
+    // sums of the wave to its LDS row
+    float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
+    auto stage2 = [&](auto blue_tag, int tg, int h, const Spec &cur, int par) {
+        constexpr bool BLUE = decltype(blue_tag)::value;
+        const int px = 32 * tg + 2 * lo + h;
+        const bool inb = px < Npix;
+        const bool blue = px < Nb;
+        const float Psi = PsiH, om = omH;
+        float gPsi = 0.f, gOm = 0.f, sA = 0.f, cnt = 0.f;
+        float betaR[4], gamR[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sg = cur.sg[r][h];
+            const bool wv_ = inb & sv[r] & (__float_as_int(sg) >= 0);
+            const float dd = wv_ ? cur.d[r][h] : 0.f;
+            if (BLUE) {
+                const float l2 = fast_log2(1.0f + cur.z[r][h]);
+                const float pw = fast_exp2(k.beta * l2);
+                const float tauv = k.t_amp * fast_exp2(k.t_expo * (l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
+                float Ab = fast_exp2(-tauv * QFA_LOG2E);                                          // QFA/model.py:125
+                if (HASA) Ab = bt.A_blue[(size_t)(active ? min(s0 + 4 * g + r, B - 1) : 0) * Nb + min(px, Nb - 1)];
+                const float re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);               // QFA/utils.py:91
+                const float Av = blue ? Ab : 1.f;
+                const float zd = blue ? re * re : 0.f;
+                const float A2 = Av * Av;
+                const float D = A2 * Psi + om * zd + sg * sg;
+                const float wD = wv_ ? fast_rcp(D) : 0.f;
+                const float wDA = wD * Av;
+                const float uu = wD * (dd - Av * afy[r]);                   // (Sigma^-1 delta)_i
+                const float dS = wD - wDA * wDA * aq[r];                    // diag(Sigma^-1)_i
+                const float dG = 0.5f * (dS - uu * uu);                     // QFA/model.py:136,138
+                gPsi += A2 * dG;                                            // :139
+                gOm += dG * zd;                                             // :140
+                const float root = 1.0f - k.tau0 * pw - k.c0;               // :141
+                const float e = dG * (om * zd) * zd * 2.0f * root;
+                t_tau0 -= e * pw;                                           // :142
+                t_beta -= e * (k.tau0 * pw * (l2 * QFA_LN2));               // :143
+                t_c0 -= e;                                                  // :144
+                cnt += wv_ ? 1.f : 0.f;
+                betaR[r] = wDA * Av;
+                sA += betaR[r] * Av;
+                gamR[r] = Av * uu;
+            } else {                                                        // red side: A = 1, zd = 0
+                const float D = Psi + sg * sg;
+                const float wD = wv_ ? fast_rcp(D) : 0.f;
+                const float uu = wD * (dd - afy[r]);
+                const float dS = wD - wD * wD * aq[r];
+                gPsi += 0.5f * (dS - uu * uu);
+                cnt += wv_ ? 1.f : 0.f;
+                betaR[r] = wD;
+                sA += wD;
+                gamR[r] = uu;
+            }
+        }
+        if (active && !(QFA_S12_ABL & 1)) {  // (bg_stride >= 32 ntiles: every pixel of the last tile has its own slot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = (size_t)(s0 + 4 * g + r) * bg_stride + px;
+                BG[o] = betaR[r];
+                GG[o] = gamR[r];
+            }
+        }
+        // per-pixel sums over the wave's 16 spectra: quantity q ends up in the 16-lane row q (qfa_grads_x.h)
+        {
+            const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sA), __float_as_uint(gPsi), false, false);
+            const auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(gOm), __float_as_uint(cnt), false, false);
+            const float u01 = __uint_as_float(s01[0]) + __uint_as_float(s01[1]);
+            const float u23 = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);
+            const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(u01), __float_as_uint(u23), false, false);
+            lpsum[par][wv][g][2 * lo + h] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        }
+        if (BLUE && h == 1) {
+            s_tau0 += (double)t_tau0;
+            s_c0 += (double)t_c0;
+            s_beta += (double)t_beta;
+            t_tau0 = 0.f; t_c0 = 0.f; t_beta = 0.f;
+        }
+    };
+    // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = tid >> 5, pxl = tid & 31) of the first 128.
+    // Every lane issues its request (the waits count it): a lane outside the arrays adds 0 to an element inside them, a
+    // different one per lane, or -- deterministic mode -- stores into the spare floats at the end of the slab row.
+    float *sink = (det ? slab + (size_t)blk * (size_t)slab_stride + (slab_stride - 64) : accum) + lane;
+    auto flush_P = [&](int tg, int par) {
+        if ((QFA_S12_ABL & 1) || tid >= 128) return;
+        const int which = tid >> 5, pxl = tid & 31;
+        const float v = (lpsum[par][0][which][pxl] + lpsum[par][1][which][pxl]) +
+                        (lpsum[par][2][which][pxl] + lpsum[par][3][which][pxl]);
+        const int px = 32 * tg + pxl;
+        const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
+        const int pxc = min(px, Npix - 1);
+        // (a red pixel's lane of the gOmega group adds 0 to the pixel's count instead)
+        const int offc = (which == 2 && pxc >= Nb) ? 2 * Npix + Nb + pxc : which * Npix - (which == 3 ? Npix - Nb : 0) + pxc;
+        if (det) *(ok ? accA + offc : sink) = v;
+        else atomicAdd(accA + offc, ok ? v : 0.f);
+    };
+
+    if (n > 0) {
+        // requests a sub-step puts into this wave's queue BEHIND its image DMA: the flush atomic of (h0, j0) (waves 0, 1),
+        // the staging of tile c + 2 issued there, the eight beta / gamma stores of a sub-step with stage 2
+        int stag_a = 0, stag_b = 0;                 // staging requests in flight for buffer 0 / 1 (0: not a counted issue)
+        bool drain = false;                         // a ragged staging is pending: wait for everything
+        if (active) {
+            stag_a = stage_tile(tile_of(0), 0);
+            if (n > 1) stag_b = stage_tile(tile_of(1), 1);
+        }
+        get_quarter(0);
+        if (4 * n > 1) get_quarter(1);
+        dma_wait<0>();
+        step_barrier();
+        auto cnt_q = [&](int u) { return wv == 3 ? 6 + ((u & 1) ? 0 : 1) : 7; };      // pieces of quarter u moved by this wave
+        int rest_prev = 0;                          // requests of the previous sub-step behind its image DMA
+        Spec cur;
+        auto tile_step = [&](int c, int &stag_cur) {
+            const int tg = tile_of(c);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int u = 4 * c + 2 * h + j;
+                    const bool more = u + 2 < 4 * n;
+                    if (more) get_quarter(u + 2);                 // (slot of quarter u - 1: free behind the barrier)
+                    int rest = 0;
+                    if (h == 0 && j == 0) {
+                        if (c >= 1) {
+                            flush_P(tile_of(c - 1), (c - 1) & 1);
+                            rest += (!(QFA_S12_ABL & 1) && tid < 128) ? 1 : 0;
+                        }
+                        if (active) {
+                            take_tile(c & 1, cur);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging buffer read: it may be overwritten
+                            stag_cur = 0;
+                            if (c + 2 < n) {
+                                stag_cur = stage_tile(tile_of(c + 2), c & 1);
+                                if (stag_cur == 0) drain = true;
+                                rest += stag_cur;
+                            }
+                        }
+                    }
+                    if (active) {
+                        if (j == 0) quarter(std::integral_constant<int, 0>{}, lds[u % RING]);
+                        else quarter(std::integral_constant<int, 1>{}, lds[u % RING]);
+                        if (j == 1 && !(QFA_S12_ABL & 4)) {
+                            if (tg < nbt) stage2(std::true_type{}, tg, h, cur, c & 1);
+                            else stage2(std::false_type{}, tg, h, cur, c & 1);
+                            rest += (QFA_S12_ABL & 1) ? 0 : 8;
+                        }
+                    }
+                    // the DMA of quarter u + 1 (issued at the start of the previous sub-step) must have landed; behind it in
+                    // the queue: the rest of the previous sub-step, this sub-step's DMA and its rest
+                    if (!more || drain) dma_wait<0>();
+                    else dma_wait_n(rest_prev + cnt_q(u + 2) + rest);
+                    if (drain && (h == 1 && j == 1)) drain = false;       // (everything has been waited for since)
+                    rest_prev = rest;
+                    step_barrier();
+                }
+            }
+        };
+        for (int c = 0; c < n; c += 2) {
+            tile_step(c, stag_a);
+            if (c + 1 < n) tile_step(c + 1, stag_b);
+        }
+        flush_P(tile_of(n - 1), (n - 1) & 1);
+    }
+    if (active) {
+        for (int o = 32; o >= 1; o >>= 1) {
+            s_tau0 += __shfl_xor(s_tau0, o);
+            s_c0 += __shfl_xor(s_c0, o);
+            s_beta += __shfl_xor(s_beta, o);
+        }
+    }
+    if (lane == 0) {
+        if (det) {
+            double *q = slabS + ((size_t)blockIdx.x * 4 + wv) * 3;
+            q[0] = active ? s_tau0 : 0.0; q[1] = active ? s_c0 : 0.0; q[2] = active ? s_beta : 0.0;
+        } else if (active) {
+            atomicAdd(accS + 0, (float)s_tau0);
+            atomicAdd(accS + 1, (float)s_c0);
+            atomicAdd(accS + 2, (float)s_beta);
+        }
+    }
+}

@@ -82,6 +82,46 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_s_barrier();
 #endif
 }
+// 4 bytes per lane into LDS (any source alignment: tools/ubench/glds_align.hip); see glds16a for M0
+__device__ __forceinline__ void glds4a(const void *sbase, unsigned voff, unsigned lds_dst) {
+#if QFA_TRACKED_LOADS
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(sbase) + voff),
+        (__attribute__((address_space(3))) void *)(size_t)__builtin_amdgcn_readfirstlane((int)lds_dst), 4, 0, 0);
+#else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#endif
+}
+// s_waitcnt vmcnt(k) for a wave-uniform run-time k (0..63): all but the k youngest vector-memory requests retired
+__device__ __forceinline__ void dma_wait_n(int k) {
+#if QFA_TRACKED_LOADS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#define QFA_W1(K) case K: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+#define QFA_W8(K) QFA_W1(K) QFA_W1(K + 1) QFA_W1(K + 2) QFA_W1(K + 3) QFA_W1(K + 4) QFA_W1(K + 5) QFA_W1(K + 6) QFA_W1(K + 7)
+    switch (k) {
+        QFA_W8(0) QFA_W8(8) QFA_W8(16) QFA_W8(24) QFA_W8(32) QFA_W8(40) QFA_W8(48) QFA_W8(56)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef QFA_W8
+#undef QFA_W1
+#endif
+}
+// a pointer the compiler can see is wave-uniform (an "s" asm operand needs that; values derived from blockIdx through
+// divisions are not always proven uniform)
+template <typename T>
+__device__ __forceinline__ const T *uniform_ptr(const T *p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                   hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return reinterpret_cast<const T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void step_barrier() {        // LDS writes of this step done, then the workgroup barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
+    asm volatile("" ::: "memory");
+}
+
 
 // ------------------------------------------------------------------------------------------------
 template <int KP>
