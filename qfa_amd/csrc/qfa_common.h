@@ -190,8 +190,11 @@ __device__ __forceinline__ f32x4 xdl16(const u32x2 &a, const u32x2 &b, f32x4 c) 
 template <typename V, typename F>
 __device__ __forceinline__ f32x4 six_terms(F &&mm, const V &ah, const V &am, const V &al, const V &bh, const V &bm,
                                            const V &bl, f32x4 c) {
-    c = mm(al, bh, c);
+    // (the first product starts from C = 0 with a freshly allocated destination: its A operand must stay live behind
+    // it -- with `al`, which is used only once, hipcc gave the destination the registers of the A operand
+    // (v_mfma ... v[130:133], v[132:133], ...), and k_grads_s3 came back 2e-3 off; `ah` is used again below)
     c = mm(ah, bl, c);
+    c = mm(al, bh, c);
     c = mm(am, bm, c);
     c = mm(am, bh, c);
     c = mm(ah, bm, c);

@@ -6,7 +6,7 @@
 //   k_s12_x      stage 1 ([f^T y | f^T C^-1' f], K = 32 + 528 as 18 K-steps of six v_mfma_f32_16x16x32_bf16) and stage 2
 //                (u, diag Sigma^-1, dG, the Psi / omega / tau0 / beta / c0 sums) for every (spectrum, pixel); the per-pixel
 //                sums are flushed, beta = wD A^2 and gamma = A u go to HBM ([Bpad64][NpixPad] each);
-//   k_grads_s3   (qfa_step_kernels.h) stage 3 from beta / gamma, once per 16 output columns.
+//   k_grads_s3   (below) stage 3 from beta / gamma, once per 16 output columns.
 // Lane layout as role A of k_grads_x: a wave = 16 spectra, lane (lo = lane & 15, g = lane >> 4) owns spectra
 // s0 + 4 g + r (r = 0..3) at the pixels 32 t + 2 lo + h of half h of tile t; the A operand of stage 1 (y, C^-1' of the
 // wave's spectra as three bf16 pieces, 216 registers) is loaded once per work item -- one wave per SIMD, 512 registers,
@@ -475,5 +475,149 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
             atomicAdd(accS + 1, (float)s_c0);
             atomicAdd(accS + 2, (float)s_beta);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_grads_s3 (N_h = 17..32): stage 3 of pass 2 alone, for the output columns 16 bhalf .. 16 bhalf + 15, from the
+// beta / gamma k_s12_x (or k_grads) stored:  accF[px][b] += sum_s beta_{s,px} (F_tile Z_s)[px][b] + sum_s gamma_{s,px} p_s[b].
+// Work items and flush as k_grads (16-pixel tiles, 4 waves = 64 spectra, per-wave LDS slots summed in fixed order);
+// lane (px = lane & 15, g = lane >> 4): rows 4 g + r of the products.  Z_s (K = a = 32) as two bf16 pieces of all 16
+// spectra in 128 registers, four piece products per spectrum; 70 MFMAs and 64 FMAs per tile, no transcendental.
+// Inputs of a tile arrive by LDS-DMA TWO tiles ahead into the wave's own buffers (ring of 3 x 4 KiB): the beta and gamma
+// tiles of its 16 spectra ([s][16 px] float, 64-byte row segments: one instruction each, and already the layout the
+// beta-scaling reads) and the two F pieces (1 KiB each).  A wave's queue holds those four requests per tile and its one
+// flush request; the wait at the start of a tile leaves the ten youngest in flight.
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, int ntiles, WorkPlan wp, int bhalf,
+                                                     const float *__restrict__ PFT, const float *__restrict__ SOL,
+                                                     const float *__restrict__ BG, const float *__restrict__ GG,
+                                                     int bg_stride, float *__restrict__ accum, float *__restrict__ slab,
+                                                     int slab_stride) {
+    static_assert(KP == 32, "k_grads_s3: N_h = 17..32");
+    using C = Cfg<KP>;
+    constexpr int RING = 3, BUF_B = 4096;                       // per wave and tile: beta 1 KiB | gamma 1 KiB | Fh 1 KiB | Fm 1 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char lin[4][RING][BUF_B];
+    __shared__ float ldspart[2][4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_uniform(tid >> 6);
+    const int lo = lane & 15, g = lane >> 4;
+    int blk, seg, t0, t1;
+    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
+    const int s0 = (blk * 4 + wv) * 16;
+    const bool active = s0 < B;
+    const int n = t1 - t0;
+    const bool det = slab != nullptr;
+    float *accF = det ? slab + (size_t)blk * (size_t)slab_stride : accum;
+    float *sink = (det ? accF + (slab_stride - 64) : accum) + lane;
+    for (int i = tid; i < 2 * 4 * 256; i += 256) (&ldspart[0][0][0])[i] = 0.f;      // inactive waves' slots stay 0
+
+    // B operands: Z_s[a = 8g + j][col] of all 16 spectra as two bf16 pieces, p of the spectra 4g + j (gamma term)
+    u32x4 Zh[16], Zm[16];
+    u32x2 ph, pm, pl;
+    {
+        const int zcol = 16 * bhalf + lo;
+        float zraw[16][8];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bool v = active && (s0 + s) < B && zcol < KP;
+            const float *sol = SOL + (size_t)(v ? s0 + s : 0) * C::NSOL + C::SOL_Z + zcol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zraw[s][j] = v ? sol[(8 * g + j) * KP] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h, m, l;
+                split2(zraw[s][2 * q], zraw[s][2 * q + 1], h, m, l);
+                Zh[s][q] = h;
+                Zm[s][q] = m;
+            }
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool v = active && (s0 + 4 * g + r) < B && zcol < KP;
+            pr[r] = v ? SOL[(size_t)(s0 + 4 * g + r) * C::NSOL + C::SOL_P + zcol] : 0.f;
+        }
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2(pr[0], pr[1], h0, m0, l0);
+        split2(pr[2], pr[3], h1, m1, l1);
+        ph = u32x2{h0, h1}; pm = u32x2{m0, m1}; pl = u32x2{l0, l1};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the operand loads above are the only tracked ones)
+    const int rot = n > 0 ? (int)(((unsigned)blk * 2654435761u) % (unsigned)min(n, 32)) : 0;
+    auto tile_of = [&](int c) {
+        int x = c + rot;
+        if (x >= n) x -= n;
+        return t0 + x;
+    };
+    // the four input requests of tile tg: lane = (row = lane >> 2, 16-byte piece = lane & 3) of the 64-byte row segments
+    const float *bgw = uniform_ptr(BG + (size_t)(active ? s0 : 0) * bg_stride);
+    const float *ggw = uniform_ptr(GG + (size_t)(active ? s0 : 0) * bg_stride);
+    auto get_tile = [&](int c) {
+        const int tg = tile_of(c);
+        const unsigned dst = wave_uniform(lds_addr(lin[wv][c % RING]));
+        const unsigned o = 4u * ((unsigned)(lane >> 2) * (unsigned)bg_stride + 16u * (unsigned)tg + 4u * (unsigned)(lane & 3));
+        glds16a(bgw, o, dst);
+        glds16a(ggw, o, dst + 1024);
+        const float *fg = uniform_ptr(PFT + (size_t)tg * C::TILE_PFT + C::PFT_MAIN);
+        glds16a(fg, (unsigned)lane * 16u, dst + 2048);
+        glds16a(fg + 256, (unsigned)lane * 16u, dst + 3072);
+    };
+    auto flush = [&](int tg, const float (*pp)[256]) {
+        const int idx = lane + 64 * wv;
+        const float v = (pp[0][idx] + pp[1][idx]) + (pp[2][idx] + pp[3][idx]);
+        const int px = 16 * tg + (idx >> 4), b = 16 * bhalf + (idx & 15);
+        const bool ok = (b < Nh) & (px < Npix);
+        // every lane issues its request (the wait counts it): a lane outside the array adds 0 inside it / stores to the sink
+        float *q = accF + (size_t)min(px, Npix - 1) * Nh + (b < Nh ? b : b % Nh);
+        if (det) *(ok ? q : sink) = v;
+        else atomicAdd(q, ok ? v : 0.f);
+    };
+    if (n <= 0) return;
+    get_tile(0);
+    if (n > 1) get_tile(1);
+    if (n > 1) dma_wait<4>();                                   // tile 0 has landed (tile 1 may be in flight)
+    else dma_wait<0>();
+    __syncthreads();                                            // (also the zeroing of ldspart)
+    for (int c = 0; c < n; ++c) {
+        const int pbuf = c & 1;
+        if (c + 2 < n) get_tile(c + 2);
+        if (active) {
+            const unsigned char *in = lin[wv][c % RING];
+            const float *bet = reinterpret_cast<const float *>(in);           // [s][16 px]
+            const float *gam = reinterpret_cast<const float *>(in + 1024);
+
+            const u32x4 Fh = *reinterpret_cast<const u32x4 *>(in + 2048 + lane * 16),
+                        Fm = *reinterpret_cast<const u32x4 *>(in + 3072 + lane * 16);
+
+            float *part = ldspart[pbuf][wv];
+            unsigned h0, m0, l0, h1, m1, l1;
+            split2(gam[(4 * g + 0) * 16 + lo], gam[(4 * g + 1) * 16 + lo], h0, m0, l0);
+            split2(gam[(4 * g + 2) * 16 + lo], gam[(4 * g + 3) * 16 + lo], h1, m1, l1);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = xdl16_6(u32x2{h0, h1}, u32x2{m0, m1}, u32x2{l0, l1}, ph, pm, pl, zero);
+            const float4 *brow = reinterpret_cast<const float4 *>(bet) + g;          // beta[s][px = 4g .. 4g + 3]
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                f32x4 G = xdl(Fm, Zm[s], zero);
+                G = xdl(Fm, Zh[s], G);
+                G = xdl(Fh, Zm[s], G);
+                G = xdl(Fh, Zh[s], G);
+                const float4 bq = brow[s * 4];
+                acc[0] = fmaf(bq.x, G[0], acc[0]);
+                acc[1] = fmaf(bq.y, G[1], acc[1]);
+                acc[2] = fmaf(bq.z, G[2], acc[2]);
+                acc[3] = fmaf(bq.w, G[3], acc[3]);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = acc[rr];
+        }
+        // The wave's inputs of tile c + 1 must have landed before it goes round; behind them in its queue are the
+        // flush of tile c - 1 and the requests of tile c + 2, which stay in flight.
+        if (c + 1 < n) dma_wait_n((c + 2 < n ? 4 : 0) + (c >= 1 ? 1 : 0));
+        step_barrier();
+        flush(tile_of(c), ldspart[pbuf]);          // ldspart[pbuf] is rewritten two tiles later, behind the next barrier
     }
 }

@@ -1179,137 +1179,6 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_grads_s3 (N_h = 17..32): stage 3 of pass 2 alone, for the output columns 16 bhalf .. 16 bhalf + 15, from the
-// beta / gamma k_grads stored:  accF[px][b] += sum_s beta_{s,px} (F_tile Z_s)[px][b] + sum_s gamma_{s,px} p_s[b].
-// Same work items, lane layout (px = lane & 15, g = lane >> 4: spectra s0 + 4g + r), XDL products, per-wave LDS slots
-// and fixed-order flush as k_grads; per tile a lane loads its four beta, four gamma (64-byte row segments) and its two
-// 16-byte F pieces one tile ahead.  No blue / red distinction, no transcendental: 70 MFMAs and 64 FMAs per tile.
-// ------------------------------------------------------------------------------------------------
-template <int KP>
-__global__ __launch_bounds__(256) void k_grads_s3(int B, int Npix, int Nh, int ntiles, WorkPlan wp, int bhalf,
-                                                  const float *__restrict__ PFT, const float *__restrict__ SOL,
-                                                  const float *__restrict__ BG, const float *__restrict__ GG, int bg_stride,
-                                                  float *__restrict__ accum, float *__restrict__ slab, int slab_stride) {
-    static_assert(KP == 32, "k_grads_s3: N_h = 17..32");
-    using C = Cfg<KP>;
-    __shared__ float ldspart[2][4][256];
-    const int tid = threadIdx.x, lane = tid & 63, wv = wave_uniform(tid >> 6);
-    const int lo = lane & 15, g = lane >> 4;
-    int blk, seg, t0, t1;
-    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
-    const int s0 = (blk * 4 + wv) * 16;
-    const bool active = s0 < B;
-    const int n = t1 - t0;
-    const bool det = slab != nullptr;
-    float *accF = det ? slab + (size_t)blk * (size_t)slab_stride : accum;
-    for (int i = tid; i < 2 * 4 * 256; i += 256) (&ldspart[0][0][0])[i] = 0.f;      // inactive waves' slots stay 0
-
-    // B operands: Z_s[a = 8g + j][col] of all 16 spectra as two bf16 pieces, p of the spectra 4g + j (gamma term)
-    u32x4 Zh[16], Zm[16];
-    u32x2 ph, pm, pl;
-    {
-        const int zcol = 16 * bhalf + lo;
-        float zraw[16][8];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const bool v = active && (s0 + s) < B && zcol < KP;
-            const float *sol = SOL + (size_t)(v ? s0 + s : 0) * C::NSOL + C::SOL_Z + zcol;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) zraw[s][j] = v ? sol[(8 * g + j) * KP] : 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned h, m, l;
-                split2(zraw[s][2 * q], zraw[s][2 * q + 1], h, m, l);
-                Zh[s][q] = h;
-                Zm[s][q] = m;
-            }
-        float pr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool v = active && (s0 + 4 * g + r) < B && zcol < KP;
-            pr[r] = v ? SOL[(size_t)(s0 + 4 * g + r) * C::NSOL + C::SOL_P + zcol] : 0.f;
-        }
-        unsigned h0, m0, l0, h1, m1, l1;
-        split2(pr[0], pr[1], h0, m0, l0);
-        split2(pr[2], pr[3], h1, m1, l1);
-        ph = u32x2{h0, h1}; pm = u32x2{m0, m1}; pl = u32x2{l0, l1};
-    }
-    const int rot = n > 0 ? (int)(((unsigned)blk * 2654435761u) % (unsigned)min(n, 32)) : 0;
-    auto tile_of = [&](int c) {
-        int x = c + rot;
-        if (x >= n) x -= n;
-        return t0 + x;
-    };
-    struct TileIn {
-        float be[4], ga[4];
-        u32x4 Fh, Fm;
-    };
-    auto load_tile = [&](int tg, TileIn &t) {
-        const size_t o = (size_t)(active ? s0 + 4 * g : 0) * bg_stride + 16 * tg + lo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            t.be[r] = BG[o + (size_t)r * bg_stride];
-            t.ga[r] = GG[o + (size_t)r * bg_stride];
-        }
-        const u32x4 *fg = reinterpret_cast<const u32x4 *>(PFT + (size_t)tg * C::TILE_PFT + C::PFT_MAIN) + lane;
-        t.Fh = fg[0];
-        t.Fm = fg[64];
-    };
-    auto flush = [&](int tg, const float (*pp)[256]) {
-        const int idx = lane + 64 * wv;
-        const float v = (pp[0][idx] + pp[1][idx]) + (pp[2][idx] + pp[3][idx]);
-        const int px = 16 * tg + (idx >> 4), b = 16 * bhalf + (idx & 15);
-        if ((b < Nh) & (px < Npix)) {
-            float *q = accF + (size_t)px * Nh + b;
-            if (det) *q = v;
-            else atomicAdd(q, v);
-        }
-    };
-    auto step = [&](int c, const TileIn &cur, TileIn &nxt) {
-        const int pbuf = c & 1;
-        if (c + 1 < n) load_tile(tile_of(c + 1), nxt);
-        if (active) {
-            float *part = ldspart[pbuf][wv];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[(4 * g + r) * 16 + lo] = cur.be[r];
-            unsigned h0, m0, l0, h1, m1, l1;
-            split2(cur.ga[0], cur.ga[1], h0, m0, l0);
-            split2(cur.ga[2], cur.ga[3], h1, m1, l1);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            f32x4 acc = xdl16_6(u32x2{h0, h1}, u32x2{m0, m1}, u32x2{l0, l1}, ph, pm, pl, zero);
-            const float4 *brow = reinterpret_cast<const float4 *>(part) + g;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                f32x4 G = xdl(cur.Fm, Zm[s], zero);
-                G = xdl(cur.Fm, Zh[s], G);
-                G = xdl(cur.Fh, Zm[s], G);
-                G = xdl(cur.Fh, Zh[s], G);
-                const float4 bq = brow[s * 4];
-                acc[0] = fmaf(bq.x, G[0], acc[0]);
-                acc[1] = fmaf(bq.y, G[1], acc[1]);
-                acc[2] = fmaf(bq.z, G[2], acc[2]);
-                acc[3] = fmaf(bq.w, G[3], acc[3]);
-            }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = acc[rr];
-        }
-        __syncthreads();
-        flush(tile_of(c), ldspart[pbuf]);          // ldspart[pbuf] is rewritten two tiles later, behind the next barrier
-    };
-    if (n <= 0) return;
-    TileIn ra, rb;
-    load_tile(tile_of(0), ra);
-    __syncthreads();
-    for (int c = 0; c < n; c += 2) {
-        step(c, ra, rb);
-        if (c + 1 < n) step(c + 1, rb, ra);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Deterministic mode, the fixed-order reduction of the slab (rows of `stride` floats, one per block of 64 spectra):
 //   k_reduce_slab_rows : part[chunk][j] = sum of rows [32 chunk, 32 chunk + 32) of column j, rows in order, float64;
 //   k_reduce_slab_fin  : accum[j] += sum of the chunks in order; the three scalar gradients from slabS[item][wave]

@@ -301,7 +301,10 @@ def _worker_train_gpu(rank, world, port, q, backend):
     m = QFA(nb, 96 - nb, 3, dev)
     opt = Adam(m.parameters, dev, scheduler=step_scheduler(0.9, 1), learning_rate=1e-2, weight_decay=1e-1)
     m.enable_data_parallel(optimizer=opt)             # ... rank 0's is broadcast
-    dl = DeviceDataloader(b["flux"], b["error"], b["zqso"], wav, 10, dev, rank=rank, world=world, seed=5)
+    # world 1 shuffles with numpy's global generator as the reference does: unshuffled there, or the one-spectrum tail
+    # batch is the red-only spectrum once in 11 epochs (no blue pixel observed: NaN gradients, quirk Q3)
+    dl = DeviceDataloader(b["flux"], b["error"], b["zqso"], wav, 10, dev, rank=rank, world=world, seed=5,
+                          shuffle=world > 1)
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         m.train(opt, dl, 2, td, quiet=True)
