@@ -15,8 +15,8 @@ no masks).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (pass 2: k_grads_x at N_h = 9..16, k_grads
-otherwise): its
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (pass 2: k_grads_x at N_h = 9..16, k_grads at N_h <= 8,
+the three launches k_s12_x + 2 k_grads_s3 at N_h = 17..32): its
 algorithmic flops over its mean duration measured with HIP events recorded by
 the library on the launch stream inside the timed region.  Two roofs are reported for it: `frac` against the float32
 MFMA / VALU peak (157.3 TFLOP/s, the roof SURVEY.md 8(d) names: the arithmetic is float32), and `frac_xdl` against
@@ -127,7 +127,7 @@ def cpu_baseline(params, batch, n_sample, npix, config):
 
 def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
     """Throughput of QFA.predict (reference model.py:160-180, loop main.py:94-98) on the resident batch and the HBM
-    roofline of its writer (k_predict_x at N_h <= 16, k_predict_out above): algorithmic bytes per spectrum = 4 (2 N_pix + k^2 + k + 1) out
+    roofline of its writer (k_predict_x at N_h <= 16, k_predict_x32 above): algorithmic bytes per spectrum = 4 (2 N_pix + k^2 + k + 1) out
     + 9 N_pix + 4 N_b in; the writer itself moves 8 N_pix bytes per spectrum (cont + unc)."""
     import numpy as np
     import torch
@@ -162,7 +162,7 @@ def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
     w_ms = float(st[2])
     return {"value": B / dt, "unit": "spectra/s", "ms_per_call": dt * 1e3, "spectra": B, "calls": n,
             "stage_ms": {"images_and_pass1": float(st[0]), "solve": float(st[1]), "writer": w_ms},
-            "roofline": {"bound": "hbm", "kernel": "k_predict_x" if nh <= 16 else "k_predict_out", "achieved": by_writer * B / (w_ms * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "k_predict_x" if nh <= 16 else "k_predict_x32", "achieved": by_writer * B / (w_ms * 1e-3) / 1e9,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": by_writer * B / (w_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                          "alg_bytes_per_spectrum_writer": by_writer},
@@ -296,18 +296,21 @@ def main():
     by = alg_bytes(npix, nb)
     rate = world * B * args.steps / dt
     rate_gpu = B * args.steps / dt
-    p2_name = "k_grads_x" if 9 <= nh <= 16 and os.environ.get("QFA_PASS2_XDL", "1") != "0" else "k_grads"
+    if nh > 16:
+        p2_name = "k_s12_x+2*k_grads_s3"      # pass 2 at N_h = 17..32: three launches, timed together by the stage events
+    else:
+        p2_name = "k_grads_x" if 9 <= nh <= 16 and os.environ.get("QFA_PASS2_XDL", "1") != "0" else "k_grads"
     dominant = p2_name if ms_p2 >= ms_p1 else "k_moments"
     dom_ms, dom_flops = (ms_p2, f2) if dominant == p2_name else (ms_p1, f1)
     # the n k^2 (matrix-pipe) part of dom_flops and the bf16 products issued for it: pass 1 4 n k^2 x 6; pass 2
     # n k^2 (stage 1, diag Sigma^-1) x 6 + 2 n k^2 (stage 3, M Z) x 6, or x 4 in k_grads_x
     nk2 = npix * nh * nh
-    if dominant == "k_grads_x":
+    if dominant in ("k_grads_x", "k_s12_x+2*k_grads_s3"):
         xdl_flops = (6 * 1 + 4 * 2) * nk2
     elif dominant == "k_moments":
         xdl_flops = 6 * 4 * nk2
     else:
-        xdl_flops = None          # k_grads (N_h <= 8, 17..32): stage 1 on the float32 MFMA, no XDL roof to price against
+        xdl_flops = None          # k_grads (N_h <= 8): stage 1 on the float32 MFMA, no XDL roof to price against
     ach = dom_flops * B / (dom_ms * 1e-3) / 1e12
     traffic = None
     tfile = os.path.join(REPO, "profiles", f"traffic_{args.config}.json")

@@ -318,22 +318,30 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
         if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
     };
     bool writer_xdl = false;
-    if constexpr (KP <= 16) {
+    if constexpr (KP <= 16 || QFA_P2_S12 != 0) {
         const char *e = std::getenv("QFA_PREDICT_F32");          // =1: the float32-MFMA writer (A/B timing, cross-check)
         writer_xdl = !(e && e[0] == '1');
     }
     mark(0);
-    if (!writer_xdl) launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);      // (PF / PFT: k_moments and k_predict_out only)
+    // (PF / PFT: k_predict_out, and k_moments where pass 1 is not on the XDL pipe)
+    if (!writer_xdl || (KP > 16 && !QFA_P1_XDL32)) launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
     launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, ws, st);
     mark(1);
     sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
     k_solve<KP, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, ll, nullptr, B, Nh, hmean, hcov);
     mark(2);
-    if (writer_xdl)
+    if constexpr (KP > 16 && QFA_P2_S12 != 0) {
+        if (writer_xdl) {              // the image of k_s12_x with mu in the place of Psi (qfa_s12_x.h)
+            unsigned char *IMG = reinterpret_cast<unsigned char *>(ws + L.oPGX);
+            k_prep_s12<KP><<<L.ntiles32, 256, 0, st>>>(p.F, mu, p.omega, Npix, Nb, Nh, IMG);
+            k_predict_x32<KP><<<L.wp2x.items(), 256, 0, st>>>(B, Npix, L.ntiles32, L.wp2x, IMG, SOL, cont, unc);
+        }
+    }
+    if (writer_xdl && KP <= 16)
         qfa_px_launch(KP, p.F, mu, B, Npix, Nh, L.ntiles32, L.wpp, reinterpret_cast<unsigned char *>(ws + L.oPXI), SOL, cont,
                       unc, st);
-    else
+    else if (!writer_xdl)
         k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);
     mark(3);
     return hip_status();

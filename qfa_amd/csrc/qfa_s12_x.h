@@ -479,6 +479,179 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_predict_x32 (N_h = 17..32): the posterior writer on the XDL pipe -- cont = F hmean + mu, unc = sqrt(f^T hcov f) for
+// ALL pixels of every spectrum (reference QFA/model.py:177-180).  It is stage 1 of k_s12_x with [hmean | hcov'] (as
+// k_solve<KP, true> leaves them in SOL) in the place of [y | C^-1']: same image (k_prep_s12 called with mu in the place
+// of Psi, so the half's KiB carries mu of the lane's pixel), same quarter ring, same counted waits; no spectra are read.
+// Lane (lo, g) owns the pixels 32 t + 2 lo + h of the spectra s0 + 4 g + r: one 8-byte store per spectrum row and
+// array behind the second half (128 contiguous bytes per row and wave instruction), eight requests per tile.
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) s12_pair { float v[2]; };       // 4-byte aligned 8-byte store
+template <int KP>
+__global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int ntiles, WorkPlan wp,
+                                                        const unsigned char *__restrict__ IMG,
+                                                        const float *__restrict__ SOL, float *__restrict__ cont,
+                                                        float *__restrict__ unc) {
+    using C = Cfg<KP>;
+    using X = S12<KP>;
+    constexpr int RING = 3;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RING][X::SLOT_B];
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_uniform(tid >> 6);
+    const int lo = lane & 15, g = lane >> 4;
+    int blk, seg, t0, t1;
+    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
+    const int s0 = blk * 64 + wv * 16;
+    const bool active = s0 < B;                                // wave-uniform
+    const int n = t1 - t0;
+    if (n <= 0) return;
+
+    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::NKS];               // A operand: spectrum s0 + lo, k = 32 ks + 8 g + j
+    {
+        const bool v = active && (s0 + lo) < B;
+        const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+#pragma unroll
+        for (int ks = 0; ks < X::NKS; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kk = 8 * g + 2 * q + e;
+                    float val = 0.f;
+                    if (ks == 0) {
+                        if (v && kk < KP) val = sol[kk];
+                    } else {
+                        const int qq = 32 * (ks - 1) + kk;
+                        if (v && qq < X::KK2) val = sol[C::SOL_CI + qq];
+                    }
+                    x[e] = val;
+                }
+                unsigned a, b, c;
+                split2(x[0], x[1], a, b, c);
+                S1h[ks][q] = a; S1m[ks][q] = b; S1l[ks][q] = c;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the operand loads above are the only tracked loads)
+    const bool full_wave = active && s0 + 16 <= B;
+    const int rot = (int)(((unsigned)blk * 2654435761u) % (unsigned)min(n, 4));
+    auto tile_of = [&](int c) {
+        int x = c + rot;
+        if (x >= n) x -= n;
+        return t0 + x;
+    };
+    auto get_quarter = [&](int u) {
+        const int c = u >> 2, h = (u >> 1) & 1, j = u & 1;
+        const unsigned char *src = uniform_ptr(IMG + (size_t)tile_of(c) * X::TILE_B + h * X::HALF_B + j * (X::Q_B + 1024));
+        unsigned char *dst = lds[u % RING];
+        constexpr int NCH = X::Q_B / 1024;
+#pragma unroll
+        for (int i = 0; i < (NCH + 1 + 3) / 4; ++i) {
+            const int ch = wv + 4 * i;
+            if (ch < NCH) glds16a(src + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(dst + ch * 1024)));
+            else if (ch == NCH && j == 0)
+                glds16a(src + X::Q_B, (unsigned)lane * 16u, wave_uniform(lds_addr(dst + X::Q_B)));
+        }
+    };
+    f32x4 afy, aq;
+    float muH = 0.f;
+    auto quarter = [&](auto jtag, const unsigned char *img) {
+        constexpr int j = decltype(jtag)::value;
+        const unsigned char *bp = img + lane * 16;
+        if (j == 0) {
+            afy = f32x4{0.f, 0.f, 0.f, 0.f};
+            aq = f32x4{0.f, 0.f, 0.f, 0.f};
+            muH = reinterpret_cast<const float *>(img + X::Q_B)[lo];
+        }
+        u32x4 bq[2][3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
+#pragma unroll
+        for (int kq = 0; kq < X::NKQ; ++kq) {
+            if (kq + 1 < X::NKQ) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    bq[(kq + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (kq + 1) * 3072 + pc * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 &bh = bq[kq & 1][0], &bm = bq[kq & 1][1], &bl = bq[kq & 1][2];
+            if (j == 0) {
+                if (kq == 0) afy = xdl6(S1h[0], S1m[0], S1l[0], bh, bm, bl, afy);
+                else aq = xdl6(S1h[kq], S1m[kq], S1l[kq], bh, bm, bl, aq);
+            } else {
+                aq = xdl6(S1h[X::NKQ + kq], S1m[X::NKQ + kq], S1l[X::NKQ + kq], bh, bm, bl, aq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    get_quarter(0);
+    if (4 * n > 1) get_quarter(1);
+    dma_wait<0>();
+    step_barrier();
+    auto cnt_q = [&](int u) { return wv == 3 ? 6 + ((u & 1) ? 0 : 1) : 7; };      // pieces of quarter u moved by this wave
+    int rest_prev = 0;                              // stores of the previous sub-step, behind its image DMA in the queue
+    float co0[4], un0[4];
+    for (int c = 0; c < n; ++c) {
+        const int tg = tile_of(c);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int u = 4 * c + 2 * h + j;
+                const bool more = u + 2 < 4 * n;
+                if (more) get_quarter(u + 2);
+                int rest = 0;
+                bool drain = false;
+                if (active) {
+                    if (j == 0) quarter(std::integral_constant<int, 0>{}, lds[u % RING]);
+                    else quarter(std::integral_constant<int, 1>{}, lds[u % RING]);
+                    if (j == 1 && h == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            co0[r] = afy[r] + muH;
+                            un0[r] = __builtin_amdgcn_sqrtf(aq[r]);
+                        }
+                    }
+                    if (j == 1 && h == 1) {
+                        const int px = 32 * tg + 2 * lo;
+                        if (full_wave && 32 * tg + 31 < Npix) {          // wave-uniform: exactly eight store instructions
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const size_t o = (size_t)(s0 + 4 * g + r) * Npix + px;
+                                *reinterpret_cast<s12_pair *>(cont + o) = s12_pair{{co0[r], afy[r] + muH}};
+                                *reinterpret_cast<s12_pair *>(unc + o) = s12_pair{{un0[r], __builtin_amdgcn_sqrtf(aq[r])}};
+                            }
+                            rest = 8;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int sp = s0 + 4 * g + r;
+                                if (sp < B && px < Npix) {
+                                    cont[(size_t)sp * Npix + px] = co0[r];
+                                    unc[(size_t)sp * Npix + px] = un0[r];
+                                }
+                                if (sp < B && px + 1 < Npix) {
+                                    cont[(size_t)sp * Npix + px + 1] = afy[r] + muH;
+                                    unc[(size_t)sp * Npix + px + 1] = __builtin_amdgcn_sqrtf(aq[r]);
+                                }
+                            }
+                            drain = true;
+                        }
+                    }
+                }
+                // the DMA of quarter u + 1 (issued at the start of the previous sub-step) must have landed; behind it in the
+                // queue: the stores of the previous sub-step, this sub-step's DMA and its stores
+                if (!more || drain) dma_wait<0>();
+                else dma_wait_n(rest_prev + cnt_q(u + 2) + rest);
+                rest_prev = drain ? 0 : rest;
+                step_barrier();
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_grads_s3 (N_h = 17..32): stage 3 of pass 2 alone, for the output columns 16 bhalf .. 16 bhalf + 15, from the
 // beta / gamma k_s12_x (or k_grads) stored:  accF[px][b] += sum_s beta_{s,px} (F_tile Z_s)[px][b] + sum_s gamma_{s,px} p_s[b].
 // Work items and flush as k_grads (16-pixel tiles, 4 waves = 64 spectra, per-wave LDS slots summed in fixed order);

@@ -615,10 +615,12 @@ def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B):
             assert rel_l2(a, r) < 5e-5, (name, rel_l2(a, r))
 
 
-@pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 7, 33), (1000, 12, 130), (1913, 8, 50), (33, 3, 17)])
+@pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 7, 33), (1000, 12, 130), (1913, 8, 50), (33, 3, 17),
+                                       (450, 32, 70), (1000, 20, 130), (31, 17, 5), (2100, 27, 64)])
 def test_predict_writer_xdl_matches_f32_writer(dev, npix, nh, B, monkeypatch):
-    """cont / unc of N_h <= 16 come from k_predict_x (split-bf16 products on the XDL pipe); QFA_PREDICT_F32=1 selects
-    the float32-MFMA writer k_predict_out: same values to float32 rounding on ragged shapes, both against the oracle."""
+    """cont / unc come from k_predict_x (N_h <= 16) / k_predict_x32 (N_h = 17..32): split-bf16 products on the XDL
+    pipe; QFA_PREDICT_F32=1 selects the float32-MFMA writer k_predict_out: same values to float32 rounding on ragged
+    shapes, both against the oracle."""
     from oracle import qfa_oracle as O
     from qfa_amd import synthetic
     wav, nb, nr = synthetic.wavelength_grid(npix)
