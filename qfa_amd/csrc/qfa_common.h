@@ -92,9 +92,9 @@ __device__ __forceinline__ void plan_item(const WorkPlan &w, int item, int ntile
 // Moment records of pass 1: [segment 0: Bpad rows][segments 1..: the rows of the segmented blocks only]; the
 // returned base is indexed by the absolute spectrum row.
 template <int NMOM>
-__device__ __forceinline__ float *mom_segment(float *MOM, const WorkPlan &w, int seg, int Bpad) {
+__device__ __forceinline__ float *mom_segment(float *MOM, const WorkPlan &w, int seg, int Bpad, int spb = 64) {
     if (seg == 0) return MOM;
-    const size_t row0 = (size_t)w.full * 64, R = (size_t)Bpad - row0;
+    const size_t row0 = (size_t)w.full * spb, R = (size_t)Bpad - row0;      // spb: spectra per block of the plan
     return MOM + ((size_t)Bpad + (size_t)(seg - 1) * R - row0) * NMOM;
 }
 

@@ -22,6 +22,10 @@ void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int
 
 namespace {
 
+#ifndef QFA_P1_NW
+#define QFA_P1_NW 4         // waves per workgroup of k_moments_x at N_h <= 16: 4 = two workgroups per CU; 8 = one workgroup per CU, two
+                            // phase-shifted groups sharing the image ring (same results, measured slower: 1.44 against 1.31 ms at c3)
+#endif
 #ifndef QFA_P2_S12
 #define QFA_P2_S12 1        // pass 2 at N_h > 16: 1 = k_s12_x + two k_grads_s3, 0 = k_grads (f32 stage 1) + one k_grads_s3
 #endif
@@ -68,6 +72,7 @@ struct Layout {
     int KP, NpixPad, ntiles, Bpad;
     int ntiles32;                                      // pass 1 on the XDL pipe walks 32-pixel tiles (N_h <= 16)
     WorkPlan wp1, wp2;                                 // work items of pass 1 / pass 2
+    int spb1;                                          // spectra per block of pass 1's plan (128 for the 8-wave k_moments_x)
     WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
     WorkPlan wpp;                                      // posterior writer on the XDL pipe (k_predict_x, N_h <= 16)
     size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, total;   // float offsets
@@ -85,7 +90,9 @@ Layout make_layout_t(int B, int Npix) {
     L.ntiles32 = (Npix + 31) / 32;
     L.wp2 = plan_work(B, L.ntiles, 4, 256 * (KP == 8 ? QFA_G8_OCC : (KP > 16 ? 1 : 2)));
     // pass 1 runs on the XDL pipe at every N_h (32-pixel tiles; one workgroup per CU at N_h > 16)
-    L.wp1 = KP <= 16 ? plan_work(B, L.ntiles32, 1) : (QFA_P1_XDL32 ? plan_work(B, L.ntiles32, 1, 256) : plan_work(B, L.ntiles, 2));
+    L.spb1 = KP <= 16 ? 16 * QFA_P1_NW : 64;
+    L.wp1 = KP <= 16 ? (QFA_P1_NW == 8 ? plan_work(B, L.ntiles32, 1, 256, 128) : plan_work(B, L.ntiles32, 1))
+                     : (QFA_P1_XDL32 ? plan_work(B, L.ntiles32, 1, 256) : plan_work(B, L.ntiles, 2));
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
     L.oPF = take((size_t)L.ntiles * C::TILE_PF);
@@ -108,7 +115,7 @@ Layout make_layout_t(int B, int Npix) {
         L.wpp = plan_work(B, L.ntiles32, 1);
     }
     // moment records: segment 0 for every row, segments 1.. for the rows of the segmented blocks only
-    L.oMOM = take(((size_t)L.Bpad + (size_t)(L.wp1.nseg - 1) * (L.Bpad - 64 * (size_t)L.wp1.full)) * C::NMOM);
+    L.oMOM = take(((size_t)L.Bpad + (size_t)(L.wp1.nseg - 1) * (L.Bpad - (size_t)L.spb1 * (size_t)L.wp1.full)) * C::NMOM);
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
     L.oNLL = take((size_t)L.Bpad);
     L.oNBL = take((size_t)L.Bpad);
@@ -169,7 +176,7 @@ template <int KP>
 void sum_segments(float *MOM, const Layout &L, int B, hipStream_t st) {
     const WorkPlan &w = L.wp1;
     if (w.rem == 0 || w.nseg <= 1) return;
-    const size_t row0 = (size_t)w.full * 64;
+    const size_t row0 = (size_t)w.full * L.spb1;
     const size_t rows = (size_t)L.Bpad - row0;                  // Bpad is a multiple of 16, NMOM of 4
     const size_t n4 = rows * Cfg<KP>::NMOM / 4;
     k_sum_segments<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(
@@ -185,11 +192,7 @@ void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t
     if constexpr (KP <= 16 || QFA_P1_XDL32) {
         unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
         k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, Npix, Nb, Nh, PFX);
-#ifndef QFA_XNW
-#define QFA_XNW 4
-#endif
-        constexpr int NW = QFA_XNW;
-        static_assert(NW == 4, "the work plan counts blocks of 64 spectra");
+        constexpr int NW = KP <= 16 ? QFA_P1_NW : 4;      // (L.spb1 = 16 NW spectra per block)
         k_moments_x<KP, PREDICT, NW><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, MOM);
     } else {
         k_moments<KP, PREDICT><<<L.wp1.items(), 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.wp1, ws + L.oPF, MOM);

@@ -209,6 +209,12 @@ __device__ __forceinline__ void land(SpecRegsX &r) {
     if (BLUE) asm volatile("" : "+v"(r.z0), "+v"(r.z1));
 }
 
+#ifndef QFA_P1_EARLY_DMA
+#define QFA_P1_EARLY_DMA 0  // 1: image DMA of tile c + 1 at the START of step c instead of behind the weights (measured: 1.35 against 1.32 ms)
+#endif
+#ifndef QFA_P1_ABL
+#define QFA_P1_ABL 0        // timing-only ablations of k_moments_x (N_h <= 16): 1 no spectra reloads, 2 no MFMAs, 4 no weights, 8 no image DMA
+#endif
 #ifndef QFA_P1_CT_TERMS
 #define QFA_P1_CT_TERMS 6      // experiment: 4 = C and T from the two leading pieces of both operands
 #endif
@@ -221,19 +227,21 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
     return xdl(ah, bh, c);
 }
 template <int KP, bool PREDICT, int NW>
-__global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
+__global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                       const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
                                                       int ntiles, WorkPlan wp, const unsigned char *__restrict__ PFX,
                                                       float *__restrict__ MOM) {
     using C = Cfg<KP>;
     using X = XCfg<KP>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][X::SLOT_B];
+    static_assert(NW == 4 || (NW == 8 && X::NSW == 1), "8 waves: the two-group form of N_h <= 16");
+    constexpr int RING = NW == 8 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RING][X::SLOT_B];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
     int blk, seg, t0, t1;
     plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
-    const int s0 = (blk * 4 + wv) * 16;
+    const int s0 = (blk * NW + wv) * 16;
     const bool active = s0 < B;                                   // wave-uniform
     const int nbt = (Nb + 31) >> 5;                               // tiles that contain blue pixels
     const DevConsts k = load_consts(p, tau);
@@ -264,8 +272,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments_x(qfa_params_t
         constexpr int J = decltype(jtag)::value;
         constexpr int NCH = X::sub_bytes(J) / 1024;
 #pragma unroll
-        for (int i = 0; i < (NCH + 3) / 4; ++i) {
-            const int ch = wv + 4 * i;
+        for (int i = 0; i < (NCH + NW - 1) / NW; ++i) {
+            const int ch = wv + NW * i;
             if (ch < NCH)
                 glds16a(PFX + (size_t)tg * X::TILE_B + X::sub_off(J) + ch * 1024, (unsigned)lane * 16u,
                         wave_uniform(lds_addr(&lds[buf][ch * 1024])));
@@ -434,15 +442,28 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments_x(qfa_params_t
         // raw barrier waits for the DMA only: vmcnt counts in issue order and the spectra loads come after it.
         auto step = [&](int c, SpecRegsX &cur, int buf) {
             Pieces w;
+            if (QFA_P1_EARLY_DMA && c + 1 < n && !(QFA_P1_ABL & 8)) stage(ta + c + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
             land<BLUE>(cur);
-            if (active) weights(ta + c, cur, lds[buf], w);
+            if (QFA_P1_ABL & 4) {            // timing only: no weights (pieces straight from the spectra registers)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w.w1h[q] = w.w1m[q] = w.w1l[q] = __float_as_uint(cur.d0[q]);
+                    w.w3h[q] = w.w3m[q] = w.w3l[q] = __float_as_uint(cur.s0[q]);
+                    w.w2h[q] = w.w2m[q] = w.w2l[q] = __float_as_uint(cur.d1[q]);
+                    w.w4h[q] = w.w4m[q] = w.w4l[q] = __float_as_uint(cur.s1[q]);
+                }
+            } else if (active) weights(ta + c, cur, lds[buf], w);
             __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < n) stage(ta + c + 1, buf ^ 1);
+            if (!QFA_P1_EARLY_DMA && c + 1 < n && !(QFA_P1_ABL & 8)) stage(ta + c + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            const bool reload = active & (c + 2 < n);
+            const bool reload = active & (c + 2 < n) & !(QFA_P1_ABL & 1);
             if (reload) load_spec(ta + c + 2, cur);
             __builtin_amdgcn_sched_barrier(0);
-            if (active) mfmas(lds[buf], w, std::integral_constant<int, 0>{});
+            if (QFA_P1_ABL & 2) {            // timing only: no MFMAs (the pieces stay live)
+                asm volatile("" ::"v"(w.w1h), "v"(w.w1m), "v"(w.w1l), "v"(w.w3h), "v"(w.w3m), "v"(w.w3l));
+                if (BLUE) asm volatile("" ::"v"(w.w2h), "v"(w.w2m), "v"(w.w2l), "v"(w.w4h), "v"(w.w4m), "v"(w.w4l));
+            } else if (active) mfmas(lds[buf], w, std::integral_constant<int, 0>{});
             // retire everything up to and including the DMA: it was issued before the 5 (red: 2 delta, 2 sigma,
             // 1 mask) / 7 (blue: + 2 zabs) spectra loads of this step (the ragged-end path issues more, smaller ones)
             if (reload) dma_wait<BLUE ? 7 : 5>();
@@ -478,6 +499,33 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments_x(qfa_params_t
             asm volatile("" ::: "memory");
         };
 
+        // NW = 8 (N_h <= 16): ONE workgroup of 8 waves = 128 spectra per CU shares the image ring (half the LDS-DMA per
+        // spectrum), waves w and w + 4 share a SIMD.  Group A (waves 0..3) runs [weights c | MFMAs c] in step c, group B
+        // (waves 4..7) [MFMAs c - 1 | weights c]: the VALU phase of one beside the XDL phase of the other.  B reads image
+        // c - 1 while image c + 1 arrives: ring of 3, the DMA issued at the start of the step (its slot was last read in
+        // step c - 1, by B).
+        const bool grpB = NW == 8 && wv >= 4;                    // wave-uniform
+        Pieces wB;
+        auto step8 = [&](int c, SpecRegsX &cur) {
+            const int slot = c % 3, nslot = (c + 1) % 3, pslot = (c + 2) % 3;
+            if (c + 1 < n) stage(ta + c + 1, nslot);
+            __builtin_amdgcn_sched_barrier(0);
+            land<BLUE>(cur);
+            const bool reload = active & (c + 2 < n);
+            // (one weights site and one set of piece registers for both groups)
+            if (grpB && active && c > 0) mfmas(lds[pslot], wB, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) weights(ta + c, cur, lds[slot], wB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (reload) load_spec(ta + c + 2, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!grpB && active) mfmas(lds[slot], wB, std::integral_constant<int, 0>{});
+            if (reload) dma_wait<BLUE ? 7 : 5>();
+            else dma_wait<0>();
+            wg_barrier();
+            asm volatile("" ::: "memory");
+        };
+
         SpecRegsX ra, rb;
         stage(ta, 0);
         if (active) {
@@ -486,6 +534,13 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments_x(qfa_params_t
         }
         dma_wait<0>();
         __syncthreads();
+        if constexpr (NW == 8) {
+            for (int c = 0; c < n; c += 2) {
+                step8(c, ra);
+                if (c + 1 < n) step8(c + 1, rb);
+            }
+            if (grpB && active) mfmas(lds[(n - 1) % 3], wB, std::integral_constant<int, 0>{});
+        } else
         for (int c = 0; c < n; c += 2) {
             if constexpr (X::NSW == 1) {
                 step(c, ra, 0);
@@ -506,7 +561,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments_x(qfa_params_t
 
     if (!active) return;
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4g + r, column 16t + sl
-    float *momseg = mom_segment<C::NMOM>(MOM, wp, seg, Bpad);
+    float *momseg = mom_segment<C::NMOM>(MOM, wp, seg, Bpad, 16 * NW);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int ss = s0 + 4 * g + r;
