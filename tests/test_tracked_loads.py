@@ -35,7 +35,9 @@ def run(lib, out, npix, nh, B):
 @pytest.mark.parametrize("npix,nh,B", [(4000, 16, 3000),      # k_moments_x<16>, k_grads_x, k_predict_x<16>; full tiles
                                        (1913, 8, 2500),       # k_moments_x<8>, k_predict_x<8>; ragged last tile
                                        (1000, 12, 700),       # N_h = 12 on the 16-wide XDL kernels
-                                       (1100, 24, 300)])      # N_h = 24: k_moments_x<32> (two column sweeps per tile)
+                                       (1100, 24, 300),       # N_h = 24: k_moments_x<32> (two column sweeps per tile),
+                                                              # k_s12_x, k_grads_s3, k_predict_x32 (tracked qfa_k32 object)
+                                       (2050, 32, 1000)])     # N_h = 32, several work items per block, ragged last tile
 def test_tracked_build_is_bit_identical(tmp_path, npix, nh, B):
     assert os.path.exists(TRACKED), "libqfa_tracked.so missing: __graft_entry__.build() / make -C qfa_amd/csrc tracked"
     a = run(None, str(tmp_path / "shipped.npz"), npix, nh, B)
