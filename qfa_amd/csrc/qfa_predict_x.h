@@ -73,14 +73,20 @@ struct __attribute__((packed, aligned(4))) pxf2 { float v[2]; };       // 4-byte
 
 // One work item = (block of 64 spectra, range of 32-pixel tiles); SOL as k_solve<KP, true> leaves it
 // ([hmean | hcov' with doubled off-diagonals]).
+#ifndef QFA_PX_SINGLE_B
+#define QFA_PX_SINGLE_B 1
+#endif
 template <int KP>
-__global__ __launch_bounds__(256, 2) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
+__global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
                                                       WorkPlan wp, const unsigned char *__restrict__ PXI,
                                                       const float *__restrict__ SOL, float *__restrict__ cont,
                                                       float *__restrict__ unc) {
     using C = Cfg<KP>;
     using X = PX<KP>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X::TILE_B];
+    // KP = 16: the ring holds two HALVES of a tile (36 KiB instead of 72: four workgroups per CU instead of two; 118 VGPRs
+    // allow it) and a tile step is two half-steps with a barrier each; KP = 8: two whole tiles (36 KiB)
+    constexpr bool HR = KP == 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HR ? 2 * X::S1_HALF : 2 * X::TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
     int blk, seg, t0, t1;
@@ -118,6 +124,21 @@ __global__ __launch_bounds__(256, 2) void k_predict_x(const float *__restrict__ 
         }
     }
     const bool full_wave = active && s0 + 16 <= B;
+    // mu of the lane's two pixels of tile tg, requested one tile ahead by asm loads IN FRONT of the image DMA of that tile:
+    // the counted wait that retires the DMA retires them (as ordinary loads in the loop they made hipcc wait vmcnt(0) in
+    // the middle of the step -- for the DMA just issued and the previous tile's stores)
+    float mn0 = 0.f, mn1 = 0.f;
+    auto load_mu = [&](int tg) {
+        const int p0 = min(32 * tg + 2 * lo, Npix - 1), p1 = min(32 * tg + 2 * lo + 1, Npix - 1);
+        if (QFA_TRACKED_LOADS) {
+            mn0 = mu[p0];
+            mn1 = mu[p1];
+        } else {
+            aload4(mn0, mu, 4u * (unsigned)p0);
+            aload4(mn1, mu, 4u * (unsigned)p1);
+        }
+    };
+    auto land_mu = [&]() { asm volatile("" : "+v"(mn0), "+v"(mn1)); };
     auto get_tile = [&](int c) {
         const unsigned char *src = PXI + (size_t)(t0 + c) * X::TILE_B;
         const unsigned long long a = reinterpret_cast<unsigned long long>(src);
@@ -131,12 +152,120 @@ __global__ __launch_bounds__(256, 2) void k_predict_x(const float *__restrict__ 
                 glds16a(sbase + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(lds + (c & 1) * X::TILE_B + ch * 1024)));
         }
     };
-    if (n > 0) get_tile(0);
+    if constexpr (HR) {
+        if (n <= 0) return;
+        constexpr int NCH = X::S1_HALF / 1024;
+        auto get_half = [&](int u) {
+            const unsigned char *sbase = uniform_ptr(PXI + (size_t)(t0 + (u >> 1)) * X::TILE_B + (u & 1) * X::S1_HALF);
+#pragma unroll
+            for (int i = 0; i < (NCH + 3) / 4; ++i) {
+                const int ch = wv + 4 * i;
+                if (ch < NCH)
+                    glds16a(sbase + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(lds + (u & 1) * X::S1_HALF + ch * 1024)));
+            }
+        };
+        load_mu(t0);
+        get_half(0);
+        dma_wait<0>();
+        wg_barrier();
+        asm volatile("" ::: "memory");
+        float co0[4], un0[4];
+        for (int c = 0; c < n; ++c) {
+            const int tg = t0 + c;
+            land_mu();
+            const float mc[2] = {mn0, mn1};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int u = 2 * c + h;
+                if (h == 0 && c + 1 < n) load_mu(tg + 1);
+                if (u + 1 < 2 * n) get_half(u + 1);
+                bool counted = false;
+                if (active) {
+                    const unsigned char *bp = lds + (u & 1) * X::S1_HALF + lane * 16;
+                    f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+#if QFA_PX_SINGLE_B          // (four waves per SIMD hide the LDS latency; the second B buffer would cost the fourth wave)
+#pragma unroll
+                    for (int ks = 0; ks < X::NKS; ++ks) {
+                        const u32x4 bh = *reinterpret_cast<const u32x4 *>(bp + ks * 3072),
+                                    bm = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 1024),
+                                    bl = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 2048);
+                        if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
+                        else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#else
+                    u32x4 bq[2][3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
+#pragma unroll
+                    for (int ks = 0; ks < X::NKS; ++ks) {
+                        if (ks + 1 < X::NKS) {
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc)
+                                bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
+                        }
+                        const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
+                        if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
+                        else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
+                    }
+#endif
+                    const float m = mc[h];
+                    if (h == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            co0[r] = afy[r] + m;
+                            un0[r] = __builtin_amdgcn_sqrtf(aq[r]);
+                        }
+                    } else {
+                        const int px = 32 * tg + 2 * lo;
+                        if (full_wave && 32 * tg + 31 < Npix) {          // wave-uniform: exactly eight store instructions
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const size_t o = (size_t)(s0 + 4 * g + r) * Npix + px;
+                                *reinterpret_cast<pxf2 *>(cont + o) = pxf2{{co0[r], afy[r] + m}};
+                                *reinterpret_cast<pxf2 *>(unc + o) = pxf2{{un0[r], __builtin_amdgcn_sqrtf(aq[r])}};
+                            }
+                            counted = true;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int s = s0 + 4 * g + r;
+                                if (s < B && px < Npix) {
+                                    cont[(size_t)s * Npix + px] = co0[r];
+                                    unc[(size_t)s * Npix + px] = un0[r];
+                                }
+                                if (s < B && px + 1 < Npix) {
+                                    cont[(size_t)s * Npix + px + 1] = afy[r] + m;
+                                    unc[(size_t)s * Npix + px + 1] = __builtin_amdgcn_sqrtf(aq[r]);
+                                }
+                            }
+                        }
+                    }
+                }
+                // the pieces of half u + 1 were issued before this half-step's stores: all but the eight stores must be done
+                if (counted) dma_wait<8>();
+                else dma_wait<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        return;
+    }
+    if (n > 0) {
+        load_mu(t0);
+        get_tile(0);
+    }
     dma_wait<0>();
     wg_barrier();
     asm volatile("" ::: "memory");
     for (int c = 0; c < n; ++c) {
-        if (c + 1 < n) get_tile(c + 1);
+        land_mu();
+        const float mc[2] = {mn0, mn1};
+        if (c + 1 < n) {
+            load_mu(t0 + c + 1);
+            get_tile(c + 1);
+        }
         bool counted = false;
         if (active) {
             const int tg = t0 + c;
@@ -160,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_predict_x(const float *__restrict__ 
                     if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
                     else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
                 }
-                const float m = mu[min(32 * tg + 2 * lo + h, Npix - 1)];
+                const float m = mc[h];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     co[h][r] = afy[r] + m;

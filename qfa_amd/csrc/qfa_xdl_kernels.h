@@ -203,6 +203,9 @@ __device__ __forceinline__ void aload16(f32x4 &dst, const void *sbase, unsigned 
 __device__ __forceinline__ void aload8(u32x2 &dst, const void *sbase, unsigned voff) {
     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
+__device__ __forceinline__ void aload4(float &dst, const void *sbase, unsigned voff) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
 template <bool BLUE>
 __device__ __forceinline__ void land(SpecRegsX &r) {
     asm volatile("" : "+v"(r.d0), "+v"(r.d1), "+v"(r.s0), "+v"(r.s1), "+v"(r.m));
