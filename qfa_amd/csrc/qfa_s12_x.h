@@ -25,7 +25,7 @@
 #include "qfa_xdl_kernels.h"
 
 #ifndef QFA_S12_ABL
-#define QFA_S12_ABL 0        // timing-only ablations: 1 no beta / gamma stores, 2 no spectra loads, 4 no stage 2
+#define QFA_S12_ABL 0        // timing-only ablations: 1 no beta / gamma stores, 2 no spectra loads (and their share of the waits), 4 no stage 2, 8 staging from cache
 #endif
 typedef float s12_f32x2 __attribute__((ext_vector_type(2)));
 template <int KP>
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
     const float *zbase = uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
     auto stage_tile = [&](int tg, int par) -> int {
         if (QFA_S12_ABL & 2) return 8;
+        if (QFA_S12_ABL & 8) tg = t0;                 // timing only: the staging always re-reads the item's first tile (cache hits)
         const bool zblue = tg < nbt;                                                      // wave-uniform
         const bool fast = (32 * tg + 31 < Npix) && (!zblue || 32 * tg + 31 < Nb) && !QFA_TRACKED_LOADS;
         const float *zb = zblue ? zbase : dbase;
