@@ -1,15 +1,23 @@
-"""Audit of the compiled k_grads_x (qfa_amd/csrc: `make asmgx` -> /tmp/qfa_gx.s): the spectra prefetch is issued by asm
-statements that hipcc does not track, so nothing but program order protects their destination registers.  For every
-such load (between ;;#ASMSTART / ;;#ASMEND) check that no instruction reads or writes its destination registers before
-the next `s_waitcnt vmcnt(...)`; also require zero scratch (spills of loop-carried registers produced wrong results
-in this kernel once).  Exit code 1 on a violation."""
+"""Audit of the compiled kernels (qfa_amd/csrc: `make asm asmgx asm32` -> /tmp/qfa_*.s): register prefetches are issued by
+asm statements that hipcc does not track, so nothing but program order protects their destination registers.  For every
+such load (between ;;#ASMSTART / ;;#ASMEND) of every kernel check that no instruction reads or writes its destination
+registers before the next `s_waitcnt vmcnt(...)`; in k_grads_x and k_predict_x also require zero scratch (spills of
+loop-carried registers produced wrong results in k_grads_x once, and a scratch reload makes hipcc wait vmcnt(0) in the
+middle of the counted queue).  The scan is linear in program order (the code behind an unconditional branch starts
+with nothing pending; a counted wait is taken to retire every asm load before it): a build-time tripwire beside the
+dynamic check, tests/test_tracked_loads.py.  Exit code 1 on a violation.
+
+    tools/audit_asm_loads.py [file.s ...]          (default /tmp/qfa_gx.s)"""
 import re, sys
-src = open(sys.argv[1] if len(sys.argv) > 1 else "/tmp/qfa_gx.s").read()
+paths = sys.argv[1:] or ["/tmp/qfa_gx.s"]
+src = "\n".join(open(p).read() for p in paths)
+NO_SCRATCH = ("_Z9k_grads_x", "_Z11k_predict_x")
 bad = 0
-for m in re.finditer(r"^(_Z9k_grads_x\w+):[^\n]*\n(.*?)^\.Lfunc_end", src, re.S | re.M):
+for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", src, re.S | re.M):
     name, body = m.group(1), m.group(2).split("\n")
     in_asm = False
     pending = {}                                  # register number -> line of the load
+    fallthrough = True
     nload = 0
     for ln, line in enumerate(body):
         t = line.strip()
@@ -17,9 +25,17 @@ for m in re.finditer(r"^(_Z9k_grads_x\w+):[^\n]*\n(.*?)^\.Lfunc_end", src, re.S 
             in_asm = True; continue
         if t.startswith(";;#ASMEND"):
             in_asm = False; continue
+        if re.match(r"\.LBB\w+:", t):               # a label behind an unconditional branch: another path starts here
+            if not fallthrough:
+                pending = {}
+            fallthrough = True
+            continue
         if not t or t.startswith(";") or t.startswith("."):
             continue
-        if "scratch_" in t:
+        if t.startswith("s_branch"):
+            fallthrough = False
+            continue
+        if "scratch_" in t and name.startswith(NO_SCRATCH):
             print(f"{name}: scratch access: {t}"); bad += 1
         if t.startswith("s_waitcnt") and "vmcnt" in t:
             pending.clear(); continue
@@ -38,5 +54,6 @@ for m in re.finditer(r"^(_Z9k_grads_x\w+):[^\n]*\n(.*?)^\.Lfunc_end", src, re.S 
         if hit:
             print(f"{name}: line {ln}: `{t}` touches {sorted(hit)} loaded at lines {sorted(set(pending[r] for r in hit))} before a vmcnt wait")
             bad += 1
-    print(f"{name}: {nload} asm loads audited")
+    if nload or name.startswith(NO_SCRATCH):
+        print(f"{name[:60]}: {nload} asm loads audited")
 sys.exit(1 if bad else 0)
