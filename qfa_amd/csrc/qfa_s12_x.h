@@ -663,6 +663,9 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
 // beta-scaling reads) and the two F pieces (1 KiB each).  A wave's queue holds those four requests per tile and its one
 // flush request; the wait at the start of a tile leaves the ten youngest in flight.
 // ------------------------------------------------------------------------------------------------
+#ifndef QFA_S3_ABL
+#define QFA_S3_ABL 0         // timing-only ablations of k_grads_s3: 1 no flush, 2 no input DMA, 4 no beta-scaled products (gamma term only)
+#endif
 template <int KP>
 __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, int ntiles, WorkPlan wp, int bhalf,
                                                      const float *__restrict__ PFT, const float *__restrict__ SOL,
@@ -730,6 +733,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
     const float *bgw = uniform_ptr(BG + (size_t)(active ? s0 : 0) * bg_stride);
     const float *ggw = uniform_ptr(GG + (size_t)(active ? s0 : 0) * bg_stride);
     auto get_tile = [&](int c) {
+        if ((QFA_S3_ABL & 2) && c > 0) return;
         const int tg = tile_of(c);
         const unsigned dst = wave_uniform(lds_addr(lin[wv][c % RING]));
         const unsigned o = 4u * ((unsigned)(lane >> 2) * (unsigned)bg_stride + 16u * (unsigned)tg + 4u * (unsigned)(lane & 3));
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
             f32x4 acc = xdl16_6(u32x2{h0, h1}, u32x2{m0, m1}, u32x2{l0, l1}, ph, pm, pl, zero);
             const float4 *brow = reinterpret_cast<const float4 *>(bet) + g;          // beta[s][px = 4g .. 4g + 3]
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
+            for (int s = 0; s < ((QFA_S3_ABL & 4) ? 0 : 16); ++s) {
                 f32x4 G = xdl(Fm, Zm[s], zero);
                 G = xdl(Fm, Zh[s], G);
                 G = xdl(Fh, Zm[s], G);
@@ -790,8 +794,9 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
         }
         // The wave's inputs of tile c + 1 must have landed before it goes round; behind them in its queue are the
         // flush of tile c - 1 and the requests of tile c + 2, which stay in flight.
-        if (c + 1 < n) dma_wait_n((c + 2 < n ? 4 : 0) + (c >= 1 ? 1 : 0));
+        if (QFA_S3_ABL & 3) dma_wait<0>();
+        else if (c + 1 < n) dma_wait_n((c + 2 < n ? 4 : 0) + (c >= 1 ? 1 : 0));
         step_barrier();
-        flush(tile_of(c), ldspart[pbuf]);          // ldspart[pbuf] is rewritten two tiles later, behind the next barrier
+        if (!(QFA_S3_ABL & 1)) flush(tile_of(c), ldspart[pbuf]);          // ldspart[pbuf] is rewritten two tiles later, behind the next barrier
     }
 }
