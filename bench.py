@@ -21,8 +21,8 @@ algorithmic flops over its mean duration measured with HIP
 the library on the launch stream inside the timed region.  Two roofs are reported for it: `frac` against the float32
 MFMA / VALU peak (157.3 TFLOP/s, the roof SURVEY.md 8(d) names: the arithmetic is float32), and `frac_xdl` against
 the bf16 XDL pipe the contractions are actually issued on -- every float32 product is six bf16 MFMAs over operands
-split into three bf16 pieces (four over two pieces in stage 3 of k_grads_x), so the kernel's
-contraction flops x 6 (x 4) are priced against the dense bf16 peak (2.5 PFLOP/s).  The kernels are BUILT against the XDL roof; `frac` can therefore exceed what the
+split into three bf16 pieces (three over the two leading pieces in stage 3 of pass 2), so the kernel's
+contraction flops x 6 (x 3) are priced against the dense bf16 peak (2.5 PFLOP/s).  The kernels are BUILT against the XDL roof; `frac` can therefore exceed what the
 f32 pipe could give.  After the timed region the same step runs for >= 3 s more (`sustained_*`: the clock the chip
 holds under seconds of this load, not a burst), then `QFA.predict` is timed (`predict`: spectra/s and the HBM roofline
 of its output writer), then `cpu_baseline` times the dense O(N_pix^3) CPU port of the reference's per-spectrum step
@@ -303,10 +303,10 @@ def main():
     dominant = p2_name if ms_p2 >= ms_p1 else "k_moments"
     dom_ms, dom_flops = (ms_p2, f2) if dominant == p2_name else (ms_p1, f1)
     # the n k^2 (matrix-pipe) part of dom_flops and the bf16 products issued for it: pass 1 4 n k^2 x 6; pass 2
-    # n k^2 (stage 1, diag Sigma^-1) x 6 + 2 n k^2 (stage 3, M Z) x 6, or x 4 in k_grads_x
+    # n k^2 (stage 1, diag Sigma^-1) x 6 + 2 n k^2 (stage 3, M Z) x 3 (QFA_S3_TERMS, qfa_common.h)
     nk2 = npix * nh * nh
     if dominant in ("k_grads_x", "k_s12_x+2*k_grads_s3"):
-        xdl_flops = (6 * 1 + 4 * 2) * nk2
+        xdl_flops = (6 * 1 + 3 * 2) * nk2
     elif dominant == "k_moments":
         xdl_flops = 6 * 4 * nk2
     else:
@@ -332,8 +332,8 @@ def main():
                    "arithmetic": "float32 throughout; pass 1 (N_h <= 16) and pass 2 (N_h = 9..16) issue their contractions as "
                                  "bf16 XDL MFMAs over operands split into three bf16 pieces (float32-exact split, float32 "
                                  "accumulate): six piece products per float32 product (error vs float64 at or below the f32 "
-                                 "MFMA's, tools/ubench/bf16x3_numerics.hip), four over the two leading pieces in stage 3 "
-                                 "of pass 2 (2^-17 per product; the F gradient's error against the float64 oracle does not "
+                                 "MFMA's, tools/ubench/bf16x3_numerics.hip), three over the two leading pieces in stage 3 "
+                                 "of pass 2 (<= 3 x 2^-18 per product; the F gradient's error against the float64 oracle does not "
                                  "move, profiles/r2_accuracy.txt); k x k solve in float64"},
         "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                      "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
@@ -343,8 +343,8 @@ def main():
                      "achieved_xdl": xdl_flops * B / (dom_ms * 1e-3) / 1e12 if xdl_flops else None,
                      "frac_xdl": xdl_flops * B / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if xdl_flops else None,
                      "xdl_flops_per_spectrum": xdl_flops,
-                     "built_against": "xdl (bf16 MFMA: six piece products per float32 product, four in stage 3 of "
-                                      "k_grads_x); frac = the survey's float32 roof"},
+                     "built_against": "xdl (bf16 MFMA: six piece products per float32 product, three in stage 3 of "
+                                      "pass 2); frac = the survey's float32 roof"},
         "stage_ms": {"pf_image": ms_prep, "pass1_moments": ms_p1, "solve": ms_solve, "pass2_grads": ms_p2,
                      "rest_of_step": dt / args.steps * 1e3 - float(stage.sum())},
         "step_roofline": {"achieved_fp32_frac": rate_gpu * (f1 + f2) / (PEAK_FP32_TFLOPS * 1e12),

@@ -200,6 +200,16 @@ __device__ __forceinline__ f32x4 six_terms(F &&mm, const V &ah, const V &am, con
     c = mm(ah, bm, c);
     return mm(ah, bh, c);
 }
+// Stage 3 of pass 2 (G_s = F_tile Z_s, then summed over K and over every spectrum of the batch) issues fewer piece
+// products than the six of a float32-grade product.  With h, m, l the bf16 pieces of an operand (|m| <= 2^-9 |h|,
+// |l| <= 2^-18 |h|):  6 = all products down to 2^-18 (error ~ 2^-24);  4 = ah bh + ah bm + am bh + am bm (drops ah bl and
+// al bh: <= 2 x 2^-18 per product);  3 = ah bh + ah bm + am bh (drops am bm as well: <= 3 x 2^-18 = 1.1e-5 per product).
+// Measured against the float64 oracle the F gradient does not tell them apart (profiles/r2_ablation_k_grads_x.txt:
+// rel-L2 1.9e-5 with 6, 4 and 3 at (4000, 16), 4.9e-6 / 6.8e-6 / 7.3e-6 at (640, 16); the float32 numpy oracle itself
+// is at 1.7e-5 .. 6.3e-5), and three are 0.13 - 0.17 ms faster than four at c3 (2.47 -> 2.30 - 2.34).
+#ifndef QFA_S3_TERMS
+#define QFA_S3_TERMS 3
+#endif
 __device__ __forceinline__ f32x4 xdl6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
                                       const u32x4 &bm, const u32x4 &bl, f32x4 c) {
     return six_terms([](const u32x4 &a, const u32x4 &b, f32x4 cc) { return xdl(a, b, cc); }, ah, am, al, bh, bm, bl, c);

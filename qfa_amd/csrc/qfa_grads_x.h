@@ -82,7 +82,7 @@ __device__ __forceinline__ f32x16 xdl32(const u32x4 &a, const u32x4 &b, f32x16 c
                                                    0);
 }
 #ifndef QFA_GX_S3_TERMS
-#define QFA_GX_S3_TERMS 4      // bf16 piece products per stage-3 contraction: 6 (|error| ~ 2^-24) or 4 (~ 2^-17, see header)
+#define QFA_GX_S3_TERMS QFA_S3_TERMS      // bf16 piece products per stage-3 contraction (qfa_common.h): 6, 4 or 3
 #endif
 __device__ __forceinline__ f32x16 xdl32_6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
                                           const u32x4 &bm, const u32x4 &bl, f32x16 c) {
@@ -90,9 +90,9 @@ __device__ __forceinline__ f32x16 xdl32_6(const u32x4 &ah, const u32x4 &am, cons
         c = xdl32(al, bh, c);
         c = xdl32(ah, bl, c);
     }
+    c = xdl32(ah, bm, c);           // (first: its operands stay live -- see six_terms in qfa_common.h)
     if (QFA_GX_S3_TERMS >= 4) c = xdl32(am, bm, c);
     c = xdl32(am, bh, c);
-    c = xdl32(ah, bm, c);
     return xdl32(ah, bh, c);
 }
 // eight float32 values -> three u32x4 of packed bf16 pieces

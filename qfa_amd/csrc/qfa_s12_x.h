@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
 // beta / gamma k_s12_x (or k_grads) stored:  accF[px][b] += sum_s beta_{s,px} (F_tile Z_s)[px][b] + sum_s gamma_{s,px} p_s[b].
 // Work items and flush as k_grads (16-pixel tiles, 4 waves = 64 spectra, per-wave LDS slots summed in fixed order);
 // lane (px = lane & 15, g = lane >> 4): rows 4 g + r of the products.  Z_s (K = a = 32) as two bf16 pieces of all 16
-// spectra in 128 registers, four piece products per spectrum; 70 MFMAs and 64 FMAs per tile, no transcendental.
+// spectra in 128 registers, QFA_S3_TERMS (three) piece products per spectrum; 54 MFMAs and 64 FMAs per tile, no transcendental.
 // Inputs of a tile arrive by LDS-DMA TWO tiles ahead into the wave's own buffers (ring of 3 x 4 KiB): the beta and gamma
 // tiles of its 16 spectra ([s][16 px] float, 64-byte row segments: one instruction each, and already the layout the
 // beta-scaling reads) and the two F pieces (1 KiB each).  A wave's queue holds those four requests per tile and its one
@@ -779,8 +779,8 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
             const float4 *brow = reinterpret_cast<const float4 *>(bet) + g;          // beta[s][px = 4g .. 4g + 3]
 #pragma unroll
             for (int s = 0; s < ((QFA_S3_ABL & 4) ? 0 : 16); ++s) {
-                f32x4 G = xdl(Fm, Zm[s], zero);
-                G = xdl(Fm, Zh[s], G);
+                f32x4 G = xdl(Fm, Zh[s], zero);
+                if (QFA_S3_TERMS >= 4) G = xdl(Fm, Zm[s], G);
                 G = xdl(Fh, Zm[s], G);
                 G = xdl(Fh, Zh[s], G);
                 const float4 bq = brow[s * 4];
