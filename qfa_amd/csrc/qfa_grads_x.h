@@ -255,9 +255,6 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #ifndef QFA_GX_BPRIO
 #define QFA_GX_BPRIO 1        // priority of the role-B waves (0..3; 4 = 1 on red tiles only): 1 or 2 measured -0.05..-0.1 ms at c3
 #endif
-#ifndef QFA_GX_STAGE_MID
-#define QFA_GX_STAGE_MID 1
-#endif
 #ifndef QFA_GX_ROLE
 #define QFA_GX_ROLE 0      // register-pressure experiments: 1 = role A only, 2 = role B only
 #endif
@@ -531,32 +528,29 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         auto tileA = [&](int c, int &cnt_cur, int cnt_other) {
             const bool work = c < n && active;
             const int tg = work ? tile_of(c) : 0;
-            if (work) {
-                // everything but the requests of tile c + 1 has landed after this
-                if (QFA_GX_ABL & 1) {}
-                else if (c + 1 < n && cnt_other == 8) dma_wait<8>();
-                else if (c + 1 < n && cnt_other == 14) dma_wait<14>();
-                else dma_wait<0>();
-                if (tg < nbt) { GXS(5) } else { GXS(21) }
-                take_tile(c & 1, cur);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging buffer read: it may be overwritten now
-                __builtin_amdgcn_sched_barrier(0);
-                cnt_cur = 0;
-                if (tg < nbt) { GXS(0) } else { GXS(16) }
-#if !QFA_GX_STAGE_MID
-                if (c + 2 < n) cnt_cur = stage_tile(tile_of(c + 2), c & 1);
-#endif
-            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (work) {
-                    // the requests for tile c + 2 go out behind stage 1 of the first half: at the start of a half-step
-                    // role B's image DMA and flushes fill the CU's address queue and a wave that issues behind them
-                    // stalls until they have drained
+                    // Behind stage 1 of the first half (which needs no spectra): the wait for this tile's staged spectra,
+                    // their copy into registers, then the requests for tile c + 2 into the buffer just read.  (At the start
+                    // of a half-step role B's image DMA and flushes fill the CU's address queue and a wave that issues
+                    // behind them stalls until they have drained.  The wait itself is ~200 cycles here against 460 - 1 480
+                    // at the start of the step, but the step does not get shorter: whatever comes first behind the barrier
+                    // absorbs the stall -- measured 2.29 - 2.30 ms either way.)
                     auto mid = [&]() {
-#if QFA_GX_STAGE_MID
-                        if (h == 0 && c + 2 < n) cnt_cur = stage_tile(tile_of(c + 2), c & 1);
-#endif
+                        if (h != 0) return;
+                        // everything but the requests of tile c + 1 has landed after this
+                        if (QFA_GX_ABL & 1) {}
+                        else if (c + 1 < n && cnt_other == 8) dma_wait<8>();
+                        else if (c + 1 < n && cnt_other == 14) dma_wait<14>();
+                        else dma_wait<0>();
+                        if (tg < nbt) { GXS(5) } else { GXS(21) }
+                        take_tile(c & 1, cur);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging buffer read: it may be overwritten now
+                        __builtin_amdgcn_sched_barrier(0);
+                        cnt_cur = 0;
+                        if (tg < nbt) { GXS(0) } else { GXS(16) }
+                        if (c + 2 < n) cnt_cur = stage_tile(tile_of(c + 2), c & 1);
                     };
                     if (tg < nbt) halfA(std::true_type{}, tg, h, cur, c & 1, mid);
                     else halfA(std::false_type{}, tg, h, cur, c & 1, mid);
