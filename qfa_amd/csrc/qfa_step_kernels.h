@@ -383,7 +383,7 @@ static __global__ void k_sum_segments(float4 *__restrict__ mom, const float4 *__
 // log det C = sum log(pivot) (finite where the reference's float32 det overflows, QFA/utils.py:54).
 // ------------------------------------------------------------------------------------------------
 template <int KP, bool PREDICT>
-__global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
+__global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
                                                float *__restrict__ nll_out, float *__restrict__ nblue_out, int B,
                                                int Nh, float *__restrict__ hmean, float *__restrict__ hcov,
                                                unsigned *__restrict__ ticket = nullptr) {
@@ -395,6 +395,20 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
     const int s = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + lane / KP;
     const bool valid = s < B;
     const float *mom = MOM + (size_t)(valid ? s : B - 1) * C::NMOM;
+
+    // KP = 32: a broadcast inside the 32-lane group costs six instructions per float64 (two v_readlane per dword and
+    // a select), and the elimination needs KP^2 of them: the kernel was 17 000 instructions per wave.  The pivot column
+    // (and b, y, T below) therefore goes through LDS: the owning lane stores it, every lane reads it back as
+    // same-address (broadcast) reads, two float64 per ds_read_b128.  One wave owns its LDS area: LDS executes a wave's
+    // operations in order, so a wait for the wave's own stores is all the synchronisation there is.
+    constexpr bool VIA_LDS = KP == 32;
+    __shared__ __attribute__((aligned(16))) double s_col[VIA_LDS ? 4 * G * KP : 1];
+    __shared__ __attribute__((aligned(16))) float s_T[VIA_LDS ? 4 * G * KP * KP : 1];
+    double *col = s_col + ((threadIdx.x >> 6) * G + lane / KP) * (VIA_LDS ? KP : 0);
+    auto wave_lds_sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
 
     double Cc[KP];
     static_for<KP>([&](auto R) {
@@ -408,7 +422,11 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
     static_for<KP>([&](auto JJ) {
         constexpr int jj = decltype(JJ)::value;
         // pivot column jj lives in lane jj; every element is broadcast right where it is consumed
-        const double piv = group_bcast<KP>(Cc[jj], jj);
+        if constexpr (VIA_LDS) {
+            if (c == jj) static_for<KP>([&](auto R) { col[decltype(R)::value] = Cc[decltype(R)::value]; });
+            wave_lds_sync();
+        }
+        const double piv = VIA_LDS ? col[jj] : group_bcast<KP>(Cc[jj], jj);
         pprod *= piv;
         if ((jj & 7) == 7 || jj == KP - 1) {
             logdet += log(pprod);
@@ -420,19 +438,24 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
         static_for<KP>([&](auto I) {
             constexpr int i = decltype(I)::value;
             if constexpr (i != jj) {
-                const double cij = group_bcast<KP>(Cc[i], jj);         // A[i][jj] before this step's update
+                const double cij = VIA_LDS ? col[i] : group_bcast<KP>(Cc[i], jj);   // A[i][jj] before this step's update
                 Cc[i] = fma(-cij, rjc, Cc[i] * keep);
             }
         });
         Cc[jj] = rjc;
+        if constexpr (VIA_LDS) wave_lds_sync();     // the reads of this column are done before the next one is stored
         __builtin_amdgcn_sched_barrier(0);      // keep the broadcasts of step jj+1 out of step jj (VGPR pressure)
     });
     // y = C^-1 b  (Cc[r] = Cinv[r][c] = Cinv[c][r])
     const double bc = (double)mom[C::MOM_B + c];
     double y = 0.0;
+    if constexpr (VIA_LDS) {
+        col[c] = bc;
+        wave_lds_sync();
+    }
     static_for<KP>([&](auto R) {
         constexpr int r = decltype(R)::value;
-        y += Cc[r] * group_bcast<KP>(bc, r);
+        y += Cc[r] * (VIA_LDS ? col[r] : group_bcast<KP>(bc, r));
     });
     double quad = bc * y;
 #pragma unroll
@@ -465,28 +488,62 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_solve(const float *__r
     // T column c (= row c); Z row c: Z[c][b] = sum_m Cinv[c][m] T[m][b] (float32 products of the
     // float64-inverted C^-1: Z is stored in float32 anyway); p_c = b2_c - sum_m T[c][m] y_m
     float Tc[KP];
+    const float *momT = mom;
+    if constexpr (VIA_LDS) asm volatile("" : "+v"(momT));          // (keeps these 32 loads behind the elimination: registers)
     static_for<KP>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const int a = r < c ? r : c, b = r < c ? c : r;
-        Tc[r] = mom[C::MOM_T + pair_index(a, b, KP)];
+        Tc[r] = momT[C::MOM_T + pair_index(a, b, KP)];
     });
     float Zr[KP];
     static_for<KP>([&](auto Bq) { Zr[decltype(Bq)::value] = 0.f; });
-    static_for<KP>([&](auto M) {
-        constexpr int m = decltype(M)::value;
-        const float cm = (float)Cc[m];
-        static_for<KP>([&](auto Bq) {
-            constexpr int b = decltype(Bq)::value;
-            Zr[b] = fmaf(cm, group_bcast<KP>(Tc[m], b), Zr[b]);
-        });
-        static_for<KP>([&](auto Bq) { pin(Zr[decltype(Bq)::value]); });   // finish row m before row m+1's broadcasts
-        __builtin_amdgcn_sched_barrier(0);
-    });
     double pc = (double)mom[C::MOM_B2 + c];
-    static_for<KP>([&](auto M) {
-        constexpr int m = decltype(M)::value;
-        pc -= (double)Tc[m] * group_bcast<KP>(y, m);
-    });
+    if constexpr (VIA_LDS) {
+        // T[m][b] for every lane: the group's copy of T in LDS ([m][b], lane c stores column c = row c), read back four
+        // floats at a time; y the same way through the column buffer
+        float *Tl = s_T + ((threadIdx.x >> 6) * G + lane / KP) * KP * KP;
+        wave_lds_sync();                                        // (the reads of b above)
+        static_for<KP>([&](auto M) { Tl[decltype(M)::value * KP + c] = Tc[decltype(M)::value]; });
+        col[c] = y;
+        wave_lds_sync();
+        static_for<KP>([&](auto M) {                            // p first: T's registers are free during Z
+            constexpr int m = decltype(M)::value;
+            pc -= (double)Tc[m] * col[m];
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<KP>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            const float cm = (float)Cc[m];
+            static_for<KP / 4>([&](auto Bq) {
+                constexpr int b = 4 * decltype(Bq)::value;
+                const float4 t = *reinterpret_cast<const float4 *>(Tl + m * KP + b);
+                Zr[b] = fmaf(cm, t.x, Zr[b]);
+                Zr[b + 1] = fmaf(cm, t.y, Zr[b + 1]);
+                Zr[b + 2] = fmaf(cm, t.z, Zr[b + 2]);
+                Zr[b + 3] = fmaf(cm, t.w, Zr[b + 3]);
+            });
+            static_for<KP>([&](auto Bq) { pin(Zr[decltype(Bq)::value]); });   // finish row m before row m + 1 is read
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    } else {
+        static_for<KP>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            const float cm = (float)Cc[m];
+            static_for<KP>([&](auto Bq) {
+                constexpr int b = decltype(Bq)::value;
+                Zr[b] = fmaf(cm, group_bcast<KP>(Tc[m], b), Zr[b]);
+            });
+            static_for<KP>([&](auto Bq) { pin(Zr[decltype(Bq)::value]); });   // finish row m before row m+1's broadcasts
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    if constexpr (!VIA_LDS) {
+        static_for<KP>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            pc -= (double)Tc[m] * group_bcast<KP>(y, m);
+        });
+    }
     if (valid) {
         static_for<KP>([&](auto Bq) {
             constexpr int b = decltype(Bq)::value;
