@@ -170,6 +170,11 @@ def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
 
 
 def main():
+    # The contract is ONE line on stdout.  RCCL prints a version banner to stdout when the first communicator is made
+    # (and Gloo its connection report): everything but the result line goes to stderr, the result to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -372,8 +377,9 @@ def main():
             torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, batch, n_cpu, npix, args.config)
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
