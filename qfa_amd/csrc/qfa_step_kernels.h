@@ -700,8 +700,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
     //   ALL 16 spectra as bf16 pieces h, m (registers) and l (LDS); beta is applied to G_s on the VALU.
     constexpr int NZR = XS3 ? 1 : 4, NZA = XS3 ? 1 : KP, NZS = XS3 ? 16 : 1;
     float Zr[NZR][NZA], pr[4];
-    // (KP = 32: K = a = 32 per MFMA, 8 values per lane and piece, the two leading pieces only -- four products of
-    // 2^-17 each, as in k_grads_x: the third piece would take 16 KB of LDS per wave)
+    // (KP = 32: K = a = 32 per MFMA, 8 values per lane and piece, the two leading pieces only -- four products,
+    // <= 2^-17 each (k_grads_x and k_grads_s3 issue three, QFA_S3_TERMS): the third piece would take 16 KB of LDS per wave)
     using ZV = std::conditional_t<KP == 32, u32x4, u32x2>;
     constexpr int NZJ = KP == 32 ? 8 : 4;              // values of Z per lane and spectrum
     ZV Zh[NZS], Zm[NZS];
