@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--sustain", type=float, default=3.0, help="seconds of extra steps after the timed region (0 = skip)")
     ap.add_argument("--no-predict", action="store_true")
     ap.add_argument("--deterministic", action="store_true", help="fixed-order accumulation (model.deterministic)")
+    ap.add_argument("--flags", type=lambda x: int(x, 0), default=0, help="QFA_F_* kernel-form flags (include/qfa_hip.h); 0 = defaults")
     args = ap.parse_args()
 
     import numpy as np
@@ -233,6 +234,7 @@ def main():
 
     model = QFA(nb, nr, nh, dev, model_params=params)
     model.deterministic = bool(args.deterministic)
+    model.flags = args.flags
     model.mu = torch.tensor(mu, device=dev)
     if use_dist:
         model.enable_data_parallel()

@@ -7,8 +7,8 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers owned by the caller (torch tensors: tensor.data_ptr());
- *     the library allocates nothing, keeps no global mutable state and is re-entrant across
- *     streams and devices;
+ *     the library allocates nothing, reads no environment variable, keeps no mutable state (but the
+ *     per-device compute-unit count, queried once) and is re-entrant across streams and devices;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
  *   - arrays are row-major, contiguous, float32; masks are 1 byte per pixel (torch.bool);
  *   - return value: 0 = ok, negative = invalid argument (QFA_E_*), positive = hipError_t;
@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define QFA_ABI_VERSION 1
+#define QFA_ABI_VERSION 2   /* v2: qfa_batch_t carries the factored-z input form; *_ex_f32 entry points with `flags` */
 
 #define QFA_E_NULL      (-1)   /* a required pointer is NULL            */
 #define QFA_E_SIZE      (-2)   /* B/Npix/Nb/Nh out of range              */
@@ -61,7 +61,23 @@ typedef struct {
     const uint8_t *mask;    /* (B, Npix)  1 = pixel is used; masked pixels may hold -999 */
     const float   *A_blue;  /* optional (B, Nb): host-supplied exp(-tau(zabs)) for a custom tau
                                callable (reference QFA/model.py:26,43); NULL = use `tau` */
+    /* Factored-z input form (ABI v2).  The reference's loader builds zabs[s][i] = (1 + z_qso[s]) wav[i] / 1215.67 - 1
+     * (QFA/dataloader.py:102): 1 + zabs is the product of a per-spectrum and a per-pixel factor.  A caller that has
+     * them passes zq1 = 1 + z_qso (B,) and pix_ratio = wav_blue / 1215.67 (Nb,) and may leave zabs NULL: the (B, Nb)
+     * array is then never read (4 Nb bytes per spectrum and pass) and (1+z)^beta, tau(z) become products of a
+     * per-spectrum and a per-pixel term (three transcendentals per blue element instead of six).  Both NULL = read
+     * zabs.  Not combined with A_blue (a custom tau callable is evaluated on zabs by the caller). */
+    const float   *zq1;        /* optional (B,)  */
+    const float   *pix_ratio;  /* optional (Nb,) */
 } qfa_batch_t;
+
+/* `flags` of the *_ex_f32 entry points (0 = the defaults; A/B timing and the cross-checks in tests/). */
+#define QFA_F_PASS2_F32    0x1u  /* N_h <= 16: pass 2 in its float32-MFMA form (k_grads)                        */
+#define QFA_F_PASS2_XDL    0x2u  /* N_h <= 16: pass 2 in its all-XDL form (k_grads_x / k_grads_w)               */
+#define QFA_F_S3_FAST      0x4u  /* stage 3 of pass 2 with three bf16 piece products (operands carried to ~17
+                                    bits, <= 1.1e-5 per product) instead of the float32-grade six              */
+#define QFA_F_PREDICT_F32  0x8u  /* posterior writer in its float32-MFMA form (k_predict_out)                   */
+#define QFA_F_PASS2_ROLES  0x10u /* N_h <= 16: the two-role form of the all-XDL pass 2 (k_grads_x)              */
 
 int qfa_abi_version(void);
 
@@ -111,6 +127,13 @@ int qfa_nll_grad_det_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_
                          float *nll, float *accum, void *workspace, size_t workspace_bytes,
                          void *slab, size_t slab_bytes, void *stream, void *const *events);
 
+/* The general form of the three calls above: slab may be NULL (then slab_bytes is ignored), events may be NULL,
+ * flags = QFA_F_* (0 = defaults). */
+int qfa_nll_grad_ex_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau,
+                        int B, int Npix, int Nb, int Nh,
+                        float *nll, float *accum, void *workspace, size_t workspace_bytes,
+                        void *slab, size_t slab_bytes, unsigned flags, void *stream, void *const *events);
+
 /* Replaces the normalisation of QFA.forward (reference QFA/model.py:104): elementwise
  * grad = sum / count (0/0 = NaN), loss = sum_nll / n_spectra (model.py:100).  Reads `accum`
  * (after the optional all-reduce) and writes gradients with the reference's shapes.
@@ -135,6 +158,11 @@ int qfa_predict_events_f32(const qfa_params_t *p, const float *mu, const qfa_bat
                            const qfa_tau_t *tau, int B, int Npix, int Nb, int Nh,
                            float *ll, float *hmean, float *hcov, float *cont, float *unc,
                            void *workspace, size_t workspace_bytes, void *stream, void *const *events);
+
+int qfa_predict_ex_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b,
+                       const qfa_tau_t *tau, int B, int Npix, int Nb, int Nh,
+                       float *ll, float *hmean, float *hcov, float *cont, float *unc,
+                       void *workspace, size_t workspace_bytes, unsigned flags, void *stream, void *const *events);
 
 /* Replaces Adam.update (reference QFA/optimizer.py:37-52) followed by the clamp of QFA.clip
  * (QFA/model.py:233-241) for ONE tensor of n elements:

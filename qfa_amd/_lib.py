@@ -13,13 +13,16 @@ LIB_PATH = os.environ.get("QFA_HIP_LIB", os.path.join(_HERE, "libqfa_hip.so"))
 
 EXPORTS = (
     "qfa_abi_version", "qfa_tau_model", "qfa_workspace_bytes", "qfa_accum_floats",
-    "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_nll_grad_det_f32", "qfa_det_slab_bytes", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_predict_events_f32",
+    "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_nll_grad_det_f32", "qfa_nll_grad_ex_f32", "qfa_predict_ex_f32", "qfa_det_slab_bytes", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_predict_events_f32",
     "qfa_adam_clip_f32",
     "qfa_adam_clip_multi_f32", "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32", "qfa_build_batch_f32", "qfa_mu_estimate_f64",
     "qfa_mu_sums_f64", "qfa_mu_finish_f64",
 )
 
 TAU_IDS = {"becker": 0, "fg": 1, "kamble": 2, "mock": 3}
+ABI_VERSION = 2
+# `flags` of qfa_nll_grad_ex_f32 / qfa_predict_ex_f32 (include/qfa_hip.h QFA_F_*)
+F_PASS2_F32, F_PASS2_XDL, F_S3_FAST, F_PREDICT_F32, F_PASS2_ROLES = 0x1, 0x2, 0x4, 0x8, 0x10
 
 
 class QFAHipError(RuntimeError):
@@ -44,7 +47,7 @@ class AdamMulti(C.Structure):       # qfa_adam_multi_t
 
 
 class Batch(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("delta", "error", "zabs", "mask", "A_blue")]
+    _fields_ = [(n, C.c_void_p) for n in ("delta", "error", "zabs", "mask", "A_blue", "zq1", "pix_ratio")]
 
 
 _lib = None
@@ -74,6 +77,10 @@ def lib():
                                         p, C.POINTER(C.c_void_p)]),
         "qfa_nll_grad_det_f32": (i, [C.POINTER(Params), C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i, p, p, p, sz,
                                      p, sz, p, C.POINTER(C.c_void_p)]),
+        "qfa_nll_grad_ex_f32": (i, [C.POINTER(Params), C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i, p, p, p, sz,
+                                    p, sz, C.c_uint, p, C.POINTER(C.c_void_p)]),
+        "qfa_predict_ex_f32": (i, [C.POINTER(Params), p, C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i,
+                                   p, p, p, p, p, p, sz, C.c_uint, p, C.POINTER(C.c_void_p)]),
         "qfa_det_slab_bytes": (sz, [i, i, i, i]),
         "qfa_finalize_grads_f32": (i, [p, p, i, i, i, i, p, p, p, p, p, p, p, p]),
         "qfa_predict_f32": (i, [C.POINTER(Params), p, C.POINTER(Batch), C.POINTER(TauModel), i, i, i, i,
@@ -97,7 +104,7 @@ def lib():
         fn = getattr(h, name)
         fn.restype = res
         fn.argtypes = args
-    if h.qfa_abi_version() != 1:
+    if h.qfa_abi_version() != ABI_VERSION:
         raise QFAHipError("libqfa_hip.so ABI version mismatch")
     _lib = h
     return h

@@ -83,17 +83,24 @@ size_t qfa_det_slab_bytes(int B, int Npix, int Nb, int Nh) {
 int qfa_nll_grad_det_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix, int Nb,
                          int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes, void *slab,
                          size_t slab_bytes, void *stream, void *const *events) {
+    return qfa_nll_grad_ex_f32(p, b, tau, B, Npix, Nb, Nh, nll, accum, workspace, workspace_bytes, slab, slab_bytes, 0u,
+                               stream, events);
+}
+
+int qfa_nll_grad_ex_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau, int B, int Npix, int Nb,
+                        int Nh, float *nll, float *accum, void *workspace, size_t workspace_bytes, void *slab,
+                        size_t slab_bytes, unsigned flags, void *stream, void *const *events) {
     if (!p || !b || !tau || !accum || !workspace) return QFA_E_NULL;
     if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
-    if (!b->delta || !b->error || !b->mask || (Nb > 0 && !b->zabs)) return QFA_E_NULL;
+    if (int e = check_batch(*b, Nb)) return e;
     if (int e = check_shape(B, Npix, Nb, Nh)) return e;
     if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
     if (slab && slab_bytes < det_slab_bytes(B, Npix, Nb, Nh)) return QFA_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab);
-    if (kp_for(Nh) == 16) return run_nll_grad<16>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab);
-    return qfa_k32_nll_grad(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab);
+    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
+    if (kp_for(Nh) == 16) return run_nll_grad<16>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
+    return qfa_k32_nll_grad(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
 }
 
 int qfa_finalize_grads_f32(const float *accum, const float *F, int Npix, int Nb, int Nh, int normalize, float *gF,
@@ -117,16 +124,23 @@ int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b
 int qfa_predict_events_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b, const qfa_tau_t *tau, int B,
                            int Npix, int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc,
                            void *workspace, size_t workspace_bytes, void *stream, void *const *events) {
+    return qfa_predict_ex_f32(p, mu, b, tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, workspace, workspace_bytes, 0u,
+                              stream, events);
+}
+
+int qfa_predict_ex_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b, const qfa_tau_t *tau, int B,
+                       int Npix, int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc,
+                       void *workspace, size_t workspace_bytes, unsigned flags, void *stream, void *const *events) {
     if (!p || !b || !tau || !mu || !ll || !hmean || !hcov || !cont || !unc || !workspace) return QFA_E_NULL;
     if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
-    if (!b->delta || !b->error || !b->mask || (Nb > 0 && !b->zabs)) return QFA_E_NULL;
+    if (int e = check_batch(*b, Nb)) return e;
     if (int e = check_shape(B, Npix, Nb, Nh)) return e;
     if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (kp_for(Nh) == 8) return run_predict<8>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events);
-    if (kp_for(Nh) == 16) return run_predict<16>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events);
-    return qfa_k32_predict(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events);
+    if (kp_for(Nh) == 8) return run_predict<8>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
+    if (kp_for(Nh) == 16) return run_predict<16>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
+    return qfa_k32_predict(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
 }
 
 int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float *p_out, size_t n, double lr, double b1,

@@ -98,6 +98,30 @@ __device__ __forceinline__ float *mom_segment(float *MOM, const WorkPlan &w, int
     return MOM + ((size_t)Bpad + (size_t)(seg - 1) * R - row0) * NMOM;
 }
 
+// Scalar gradients (g_tau0, g_c0, g_beta: sums of cancelling per-pixel terms over every spectrum of the launch) are
+// accumulated in float64 end to end: float32 inside a tile, float64 across tiles and lanes, float64 atomics across
+// waves into this record (in the workspace, zeroed by k_solve), and ONE rounding to float32 per launch when the wave
+// that arrives last folds the totals into the tail of the packed buffer.  (Rounds 1-2 added every wave's sum as a
+// float32 atomic: up to 6 000 cancelling partials, 18x the error of a float32 numpy sum on the golden batch.)
+struct Scal64 {
+    double s[3];
+    unsigned ticket, pad;
+};
+// one call per wave of the launch (any lane subset; lane 0 acts), `nwaves` calls in all
+__device__ __forceinline__ void scal64_commit(Scal64 *q, double a, double b, double c, unsigned nwaves, float *accS) {
+    if ((threadIdx.x & 63) != 0) return;
+    if (a != 0.0) atomicAdd(&q->s[0], a);
+    if (b != 0.0) atomicAdd(&q->s[1], b);
+    if (c != 0.0) atomicAdd(&q->s[2], c);
+    __threadfence();                                              // release: the sums before the ticket
+    if (atomicAdd(&q->ticket, 1u) == nwaves - 1u) {
+        __threadfence();                                          // acquire: the other waves' sums
+        accS[0] += (float)__hip_atomic_load(&q->s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        accS[1] += (float)__hip_atomic_load(&q->s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        accS[2] += (float)__hip_atomic_load(&q->s[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // scalars the kernels need, read once from device memory
 struct DevConsts {
     float tau0, c0, beta;
@@ -288,8 +312,14 @@ __device__ __forceinline__ DevConsts load_consts(const qfa_params_t &p, const qf
     k.tau0 = *p.tau0;
     k.c0 = *p.c0;
     k.beta = *p.beta;
-    k.t_amp = tau.amp;
-    k.t_lscale = __log2f(tau.scale);
+    // log2(scale) rounded to float32 is off by up to 1.3e-7 -- the SAME error for every element of the step, i.e. a
+    // coherent relative bias of up to 2.6e-7 in tau and ~1e-7 in A = exp(-tau).  Invisible in any per-element result, but
+    // the scalar gradients are sums of terms that cancel 50-900x while a coherent bias adds up (tools/bias_probe.py: blue
+    // sumA +4.0e-7 with the hardware log2 of the constant, round 2).  So: the float32 part of log2(scale) goes into the
+    // exponent, its remainder into the amplitude, both from float64.
+    const double l2s = log2((double)tau.scale);
+    k.t_lscale = (float)l2s;
+    k.t_amp = (float)((double)tau.amp * exp2((double)tau.expo * (l2s - (double)k.t_lscale)));
     k.t_expo = tau.expo;
     k.t_off = tau.offset;
     return k;

@@ -81,17 +81,16 @@ __device__ __forceinline__ f32x16 xdl32(const u32x4 &a, const u32x4 &b, f32x16 c
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
                                                    0);
 }
-#ifndef QFA_GX_S3_TERMS
-#define QFA_GX_S3_TERMS QFA_S3_TERMS      // bf16 piece products per stage-3 contraction (qfa_common.h): 6, 4 or 3
-#endif
+// TERMS: bf16 piece products per stage-3 contraction (qfa_common.h): 6 (float32-grade, the default) or 3 (QFA_F_S3_FAST)
+template <int TERMS>
 __device__ __forceinline__ f32x16 xdl32_6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
                                           const u32x4 &bm, const u32x4 &bl, f32x16 c) {
-    if (QFA_GX_S3_TERMS == 6) {
+    c = xdl32(ah, bm, c);           // (first: its operands stay live -- see six_terms in qfa_common.h)
+    if (TERMS == 6) {
         c = xdl32(al, bh, c);
         c = xdl32(ah, bl, c);
     }
-    c = xdl32(ah, bm, c);           // (first: its operands stay live -- see six_terms in qfa_common.h)
-    if (QFA_GX_S3_TERMS >= 4) c = xdl32(am, bm, c);
+    if (TERMS >= 4) c = xdl32(am, bm, c);
     c = xdl32(am, bh, c);
     return xdl32(ah, bh, c);
 }
@@ -202,13 +201,13 @@ __device__ unsigned long long qfa_gx_stamps[2 * 32];
 #else
 #define GXS(i) {}
 #endif
-template <int KP, bool HASA>
+template <int KP, bool HASA, int TERMS>
 __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix, int Nb,
                                                     int Nh, int ntiles, WorkPlan wp,
                                                     const unsigned char *__restrict__ PGX,
                                                     const float *__restrict__ SOL, float *__restrict__ accum,
                                                     float *__restrict__ slab, double *__restrict__ slabS,
-                                                    int slab_stride) {
+                                                    int slab_stride, Scal64 *__restrict__ sc64) {
     using C = Cfg<KP>;
     using GX = GXT<KP>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GX::L_TOTAL];
@@ -583,14 +582,14 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     double *q = slabS + ((size_t)blockIdx.x * GX::NG + w) * 3;
                     q[0] = s_tau0; q[1] = s_c0; q[2] = s_beta;
                 } else {
-                    atomicAdd(accS + 0, (float)s_tau0);
-                    atomicAdd(accS + 1, (float)s_c0);
-                    atomicAdd(accS + 2, (float)s_beta);
+                    scal64_commit(sc64, s_tau0, s_c0, s_beta, gridDim.x * (unsigned)GX::NG, accS);
                 }
             }
         } else if (det && lane == 0) {
             double *q = slabS + ((size_t)blockIdx.x * GX::NG + w) * 3;
             q[0] = 0.0; q[1] = 0.0; q[2] = 0.0;
+        } else if (!det) {
+            scal64_commit(sc64, 0.0, 0.0, 0.0, gridDim.x * (unsigned)GX::NG, accS);
         }
     } else if (QFA_GX_ROLE != 1) {
         // ================================================================ role B: image DMA, flushes, stage 3
@@ -718,11 +717,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 const float gx[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
                 u32x4 Gh, Gm, Gl;
                 split8(gx, Gh, Gm, Gl);
-                acc = xdl32_6(Gh, Gm, Gl, Ph, Pm, Pl, zero);
+                acc = xdl32_6<TERMS>(Gh, Gm, Gl, Ph, Pm, Pl, zero);
             }
 #pragma unroll
             for (int m = (NMG / 2) * PART; m < (NMG / 2) * (PART + 1); ++m) {
-                const f32x16 G = xdl32_6(Fh, Fm, Fl, Zh[m], Zm[m], Zl[m], zero);
+                const f32x16 G = xdl32_6<TERMS>(Fh, Fm, Fl, Zh[m], Zm[m], Zl[m], zero);
                 const float *brow = bslot + (SPM * m + sc) * 32 + 4 * h2;       // pixels 8 q + 4 h2 + (0..3)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

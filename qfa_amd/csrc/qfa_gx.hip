@@ -10,18 +10,23 @@ size_t qfa_gx_image_bytes(int KP, int ntiles32) { return (size_t)ntiles32 * (KP 
 template <int KP>
 static void gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                       int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
-                      double *slabS, int slab_stride, hipStream_t st) {
+                      double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st) {
     k_prep_pgx<KP><<<ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, PGX);
-    if (b.A_blue)
-        k_grads_x<KP, true><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride);
-    else
-        k_grads_x<KP, false><<<wp.items(), 512, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride);
+    auto go = [&](auto hasa, auto terms) {
+        k_grads_x<KP, decltype(hasa)::value, decltype(terms)::value><<<wp.items(), 512, 0, st>>>(
+            p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, sc64);
+    };
+    using T6 = std::integral_constant<int, 6>;
+    using T3 = std::integral_constant<int, 3>;
+    const bool fast = (flags & QFA_F_S3_FAST) != 0;
+    if (b.A_blue) { if (fast) go(std::true_type{}, T3{}); else go(std::true_type{}, T6{}); }
+    else { if (fast) go(std::false_type{}, T3{}); else go(std::false_type{}, T6{}); }
 }
 void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
-                   double *slabS, int slab_stride, hipStream_t st) {
-    if (KP == 8) gx_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, st);
-    else gx_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, st);
+                   double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st) {
+    if (KP == 8) gx_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, sc64, flags, st);
+    else gx_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, sc64, flags, st);
 }
 
 size_t qfa_px_image_bytes(int KP, int ntiles32) {

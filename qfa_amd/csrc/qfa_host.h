@@ -3,8 +3,6 @@
 // stay in VGPRs; pass 1 and stage 3 of pass 2 on the bf16 XDL pipe) and qfa_k32.hip (N_h in 17..32: 280 accumulator registers per lane need the AGPR
 // half of the register file, so that translation unit is built without the flag).
 #pragma once
-#include <cstdlib>
-
 #include "qfa_step_kernels.h"
 #include "qfa_xdl_kernels.h"
 #include "qfa_s12_x.h"
@@ -13,7 +11,7 @@
 size_t qfa_gx_image_bytes(int KP, int ntiles32);
 void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
-                   double *slabS, int slab_stride, hipStream_t st);
+                   double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st);
 
 // posterior writer for N_h <= 16 on the XDL pipe (qfa_predict_x.h, built in qfa_gx.hip)
 size_t qfa_px_image_bytes(int KP, int ntiles32);
@@ -35,6 +33,22 @@ namespace {
 
 inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
 
+// Compute units of the current device, queried once per device (launch geometry: resident-workgroup slots of the
+// work plans).  256 on MI355X; also the answer when no device is visible (sizing calls in a CPU-only process).
+inline int cu_count() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    int n = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 256;
+    }
+    __atomic_store_n(&cache[dev], n, __ATOMIC_RELAXED);
+    return n;
+}
+
 // Work plan of a pass (WorkPlan, qfa_common.h): the blocks of 64 spectra that fill whole rounds of the 512
 // resident-workgroup slots walk the whole pixel axis; the remaining blocks are cut into 1..8 pixel segments.  The
 // plan minimises rounds x (tiles per item + prologue), the prologue of an item (operand loads, pipeline fill)
@@ -42,7 +56,7 @@ inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
 // tiles per item while the chip stays at most half full (the step of a small batch is latency-bound).
 constexpr int kMaxSeg = 32;
 
-inline WorkPlan plan_work(int B, int ntiles, int pro, int slots = 256 * 2, int spb = 64) {
+inline WorkPlan plan_work(int B, int ntiles, int pro, int slots, int spb = 64) {
     // slots = CUs x resident workgroups per CU; spb = spectra per block (64; 32 for k_grads_x)
     const int nblk = (B + spb - 1) / spb;
     WorkPlan best{0, nblk, 1, ntiles};
@@ -88,11 +102,12 @@ Layout make_layout_t(int B, int Npix) {
     L.ntiles = L.NpixPad / 16;
     L.Bpad = round_up(B, 16);
     L.ntiles32 = (Npix + 31) / 32;
-    L.wp2 = plan_work(B, L.ntiles, 4, 256 * (KP == 8 ? QFA_G8_OCC : (KP > 16 ? 1 : 2)));
+    const int NCU = cu_count();
+    L.wp2 = plan_work(B, L.ntiles, 4, NCU * (KP == 8 ? QFA_G8_OCC : (KP > 16 ? 1 : 2)));
     // pass 1 runs on the XDL pipe at every N_h (32-pixel tiles; one workgroup per CU at N_h > 16)
     L.spb1 = KP <= 16 ? 16 * QFA_P1_NW : 64;
-    L.wp1 = KP <= 16 ? (QFA_P1_NW == 8 ? plan_work(B, L.ntiles32, 1, 256, 128) : plan_work(B, L.ntiles32, 1))
-                     : (QFA_P1_XDL32 ? plan_work(B, L.ntiles32, 1, 256) : plan_work(B, L.ntiles, 2));
+    L.wp1 = KP <= 16 ? (QFA_P1_NW == 8 ? plan_work(B, L.ntiles32, 1, NCU, 128) : plan_work(B, L.ntiles32, 1, 2 * NCU))
+                     : (QFA_P1_XDL32 ? plan_work(B, L.ntiles32, 1, NCU) : plan_work(B, L.ntiles, 2, 2 * NCU));
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
     L.oPF = take((size_t)L.ntiles * C::TILE_PF);
@@ -103,23 +118,24 @@ Layout make_layout_t(int B, int Npix) {
     L.wp2x = WorkPlan{0, 0, 1, 0};
     if constexpr (KP == 8 || KP == 16) {
         L.oPGX = take(qfa_gx_image_bytes(KP, L.ntiles32) / 4);
-        L.wp2x = plan_work(B, L.ntiles32, 3, 256, 64);
+        L.wp2x = plan_work(B, L.ntiles32, 3, NCU, 64);
     } else if constexpr (QFA_P2_S12 != 0) {            // N_h = 17..32: stages 1 and 2 of pass 2 by k_s12_x (qfa_s12_x.h)
         L.oPGX = take((size_t)L.ntiles32 * (S12<KP>::TILE_B / 4));
-        L.wp2x = plan_work(B, L.ntiles32, 3, 256, 64);
+        L.wp2x = plan_work(B, L.ntiles32, 3, NCU, 64);
     }
     L.oPXI = 0;
     L.wpp = WorkPlan{0, 0, 1, 0};
     if constexpr (KP <= 16) {
         L.oPXI = take(qfa_px_image_bytes(KP, L.ntiles32) / 4);
-        L.wpp = plan_work(B, L.ntiles32, 1);
+        L.wpp = plan_work(B, L.ntiles32, 1, 2 * NCU);
     }
     // moment records: segment 0 for every row, segments 1.. for the rows of the segmented blocks only
     L.oMOM = take(((size_t)L.Bpad + (size_t)(L.wp1.nseg - 1) * (L.Bpad - (size_t)L.spb1 * (size_t)L.wp1.full)) * C::NMOM);
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
     L.oNLL = take((size_t)L.Bpad);
     L.oNBL = take((size_t)L.Bpad);
-    L.oRED = take(2 * 2 * NRED + 2);                    // k_reduce_nll: 2 x NRED doubles + the ticket counter
+    L.oRED = take(2 * 2 * NRED + 2 + sizeof(Scal64) / 4);   // k_reduce_nll: 2 x NRED doubles + the ticket counter; then the
+                                                            // float64 scalar-gradient sums of pass 2 (Scal64)
     L.oBG = 0;
     L.bg_stride = round_up(Npix, 32);
     if constexpr (KP == 32) L.oBG = take(2 * (size_t)round_up(B, 64) * L.bg_stride);
@@ -135,6 +151,17 @@ Layout make_layout(int B, int Npix, int Nh) {
     }
 }
 
+// the batch's pointers: delta, error, mask always; the blue side needs zabs, or the factored form zq1 + pix_ratio
+// (then zabs may be NULL), which does not combine with a host-supplied A_blue (include/qfa_hip.h)
+inline int check_batch(const qfa_batch_t &b, int Nb) {
+    if (!b.delta || !b.error || !b.mask) return QFA_E_NULL;
+    const bool fac = b.zq1 || b.pix_ratio;
+    if (fac && !(b.zq1 && b.pix_ratio)) return QFA_E_NULL;
+    if (fac && b.A_blue) return QFA_E_NULL;
+    if (Nb > 0 && !fac && !b.zabs) return QFA_E_NULL;
+    return 0;
+}
+
 inline int check_shape(int B, int Npix, int Nb, int Nh) {
     if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || Nh < 1 || Nh > 32) return QFA_E_SIZE;
     if ((long long)64 * Npix >= (1LL << 31)) return QFA_E_SIZE;      // 32-bit byte offsets inside a wave's 16 rows
@@ -145,17 +172,17 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
     return 0;
 }
 
-// Which form of pass 2 runs at N_h <= 16 (KP = 8 or 16): the all-XDL two-role form (k_grads_x) or the float32-MFMA
-// form (k_grads, the only one for N_h = 17..32).  Default, from measurements on MI355X (profiles/r2_ablation_k_grads_x.txt):
+// Which form of pass 2 runs at N_h <= 16 (KP = 8 or 16): the all-XDL form (k_grads_x) or the float32-MFMA form
+// (k_grads, the only one for N_h = 17..32).  Default, from measurements on MI355X (profiles/r2_ablation_k_grads_x.txt):
 //   KP = 16: k_grads_x -- 2.4-2.6 ms at c3 against 3.2, and no slower at any batch size down to 64 spectra;
 //   KP = 8 : k_grads   -- k_grads_x<8> is correct (same tests) but slower there (0.22 against 0.17 ms at c2, 2.3 against
 //            1.8 ms at 160 000 x 2000): its tile step is bound by the VALU work of stage 2 and the hand-overs, which
 //            do not shrink with N_h, while k_grads runs two workgroups per CU.
-// QFA_PASS2_XDL=0 / 1 in the environment forces one form (A/B timing and the cross-check of the two forms in tests/);
-// read at every call, nothing is cached.
-inline bool pass2_use_xdl(int KP) {
-    const char *e = std::getenv("QFA_PASS2_XDL");
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+// QFA_F_PASS2_F32 / QFA_F_PASS2_XDL in the call's `flags` force one form (A/B timing and the cross-check of the two
+// forms in tests/).
+inline bool pass2_use_xdl(int KP, unsigned flags) {
+    if (flags & QFA_F_PASS2_F32) return false;
+    if (flags & QFA_F_PASS2_XDL) return true;
     return KP == 16;
 }
 
@@ -238,7 +265,7 @@ inline void launch_reduce_slab(const float *slab, const DetLayout &D, int B, int
 
 template <int KP>
 int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                 float *nll, float *accum, float *ws, hipStream_t st, void *const *events, void *slabv = nullptr) {
+                 float *nll, float *accum, float *ws, hipStream_t st, void *const *events, void *slabv, unsigned flags) {
     const Layout L = make_layout_t<KP>(B, Npix);
     float *slab = reinterpret_cast<float *>(slabv);
     DetLayout D{};
@@ -251,7 +278,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
     };
     bool pass2_xdl = false;
-    if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP);
+    if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP, flags);
     mark(0);
     // the float32 images PF / PFT serve k_moments (N_h > 16) and k_grads: not needed when both passes run on the XDL pipe
     if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
@@ -262,13 +289,14 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     constexpr int G = 64 / KP;
     double *red = reinterpret_cast<double *>(ws + L.oRED);
     unsigned *ticket = reinterpret_cast<unsigned *>(red + 2 * NRED);
+    Scal64 *sc64 = reinterpret_cast<Scal64 *>(ticket + 2);      // (zeroed by k_solve, like the ticket)
     k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr, ticket);
     const int nred = B <= 2048 ? 1 : (B >= 2048 * NRED ? NRED : (B + 2047) / 2048);     // small batches: one block, no hand-over
     k_reduce_nll<<<nred, 256, 0, st>>>(nllbuf, NBL, B, accum + accS, red, ticket);
     mark(3);
     if (pass2_xdl) {
         qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
-                      accum, slab, slabS, (int)D.stride, st);
+                      accum, slab, slabS, (int)D.stride, sc64, flags, st);
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
         return hip_status();
@@ -279,31 +307,35 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         unsigned char *IMG = reinterpret_cast<unsigned char *>(ws + L.oPGX);
         k_prep_s12<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, IMG);
         if (b.A_blue)
-            k_s12_x<KP, true><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride);
+            k_s12_x<KP, true><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride, sc64);
         else
-            k_s12_x<KP, false><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride);
-        for (int bh = 0; 16 * bh < Nh; ++bh)
-            k_grads_s3<KP><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, bh, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
+            k_s12_x<KP, false><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride, sc64);
+        for (int bh = 0; 16 * bh < Nh; ++bh) {
+            if (flags & QFA_F_S3_FAST)
+                k_grads_s3<KP, 3><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, bh, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
+            else
+                k_grads_s3<KP, 4><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, bh, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
+        }
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
         return hip_status();
     }
     if constexpr (KP == 32) {
         // columns 0..15 by k_grads, which also stores beta and gamma; columns 16..31 by the stage-3-only kernel
-        float *BG = Nh > 16 ? ws + L.oBG : nullptr, *GG = Nh > 16 ? BG + (size_t)round_up(B, 64) * L.NpixPad : nullptr;
+        float *BG = Nh > 16 ? ws + L.oBG : nullptr, *GG = Nh > 16 ? BG + (size_t)round_up(B, 64) * L.bg_stride : nullptr;
         if (b.A_blue)
-            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, 0, PFT, SOL, accum, slab, slabS, (int)D.stride, BG, GG, L.bg_stride);
+            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, 0, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64, BG, GG, L.bg_stride);
         else
-            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, 0, PFT, SOL, accum, slab, slabS, (int)D.stride, BG, GG, L.bg_stride);
+            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, 0, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64, BG, GG, L.bg_stride);
         if (Nh > 16)
-            k_grads_s3<KP><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, 1, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
+            k_grads_s3<KP, 4><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, 1, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
     } else {
     for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
         if (16 * bh >= Nh) break;
         if (b.A_blue)
-            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride);
+            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64);
         else
-            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride);
+            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64);
     }
     }
     if (slab) launch_reduce_slab(slab, D, B, L.wp2.items() * 4, accum, st);
@@ -314,7 +346,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
 template <int KP>
 int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
                 int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
-                hipStream_t st, void *const *events) {
+                hipStream_t st, void *const *events, unsigned flags) {
     const Layout L = make_layout_t<KP>(B, Npix);
     float *PF = ws + L.oPF, *PFT = ws + L.oPFT, *MOM = ws + L.oMOM, *SOL = ws + L.oSOL;
     auto mark = [&](int i) {
@@ -322,8 +354,7 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     };
     bool writer_xdl = false;
     if constexpr (KP <= 16 || QFA_P2_S12 != 0) {
-        const char *e = std::getenv("QFA_PREDICT_F32");          // =1: the float32-MFMA writer (A/B timing, cross-check)
-        writer_xdl = !(e && e[0] == '1');
+        writer_xdl = !(flags & QFA_F_PREDICT_F32);               // (the float32-MFMA writer: A/B timing, cross-check)
     }
     mark(0);
     // (PF / PFT: k_predict_out, and k_moments where pass 1 is not on the XDL pipe)
@@ -355,7 +386,7 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
 
 // N_h in 17..32 (defined in qfa_k32.hip)
 int qfa_k32_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                     float *nll, float *accum, float *ws, hipStream_t st, void *const *events, void *slab);
+                     float *nll, float *accum, float *ws, hipStream_t st, void *const *events, void *slab, unsigned flags);
 int qfa_k32_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
                     int Nb, int Nh, float *ll, float *hmean, float *hcov, float *cont, float *unc, float *ws,
-                    hipStream_t st, void *const *events);
+                    hipStream_t st, void *const *events, unsigned flags);

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
                                                   int Nh, int ntiles, WorkPlan wp, const unsigned char *__restrict__ IMG,
                                                   const float *__restrict__ SOL, float *__restrict__ BG,
                                                   float *__restrict__ GG, int bg_stride, float *__restrict__ accum,
-                                                  float *__restrict__ slab, double *__restrict__ slabS, int slab_stride) {
+                                                  float *__restrict__ slab, double *__restrict__ slabS, int slab_stride,
+                                                  Scal64 *__restrict__ sc64) {
     using C = Cfg<KP>;
     using X = S12<KP>;
     constexpr int RING = 3;                                    // quarters in LDS: two of DMA distance (the image streams
@@ -471,10 +472,8 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
         if (det) {
             double *q = slabS + ((size_t)blockIdx.x * 4 + wv) * 3;
             q[0] = active ? s_tau0 : 0.0; q[1] = active ? s_c0 : 0.0; q[2] = active ? s_beta : 0.0;
-        } else if (active) {
-            atomicAdd(accS + 0, (float)s_tau0);
-            atomicAdd(accS + 1, (float)s_c0);
-            atomicAdd(accS + 2, (float)s_beta);
+        } else {
+            scal64_commit(sc64, active ? s_tau0 : 0.0, active ? s_c0 : 0.0, active ? s_beta : 0.0, gridDim.x * 4u, accS);
         }
     }
 }
@@ -666,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
 #ifndef QFA_S3_ABL
 #define QFA_S3_ABL 0         // timing-only ablations of k_grads_s3: 1 no flush, 2 no input DMA, 4 no beta-scaled products (gamma term only)
 #endif
-template <int KP>
+template <int KP, int TERMS>      // TERMS: bf16 piece products per stage-3 contraction -- 4 (default) or 3 (QFA_F_S3_FAST)
 __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, int ntiles, WorkPlan wp, int bhalf,
                                                      const float *__restrict__ PFT, const float *__restrict__ SOL,
                                                      const float *__restrict__ BG, const float *__restrict__ GG,
@@ -780,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
 #pragma unroll
             for (int s = 0; s < ((QFA_S3_ABL & 4) ? 0 : 16); ++s) {
                 f32x4 G = xdl(Fm, Zh[s], zero);
-                if (QFA_S3_TERMS >= 4) G = xdl(Fm, Zm[s], G);
+                if (TERMS >= 4) G = xdl(Fm, Zm[s], G);
                 G = xdl(Fh, Zm[s], G);
                 G = xdl(Fh, Zh[s], G);
                 const float4 bq = brow[s * 4];

@@ -389,7 +389,11 @@ __global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM,
                                                unsigned *__restrict__ ticket = nullptr) {
     using C = Cfg<KP>;
     constexpr int G = 64 / KP;
-    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;     // arrival counter of k_reduce_nll (next launch)
+    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) {
+        *ticket = 0u;                                                    // arrival counter of k_reduce_nll (this step)
+        Scal64 *q = reinterpret_cast<Scal64 *>(ticket + 2);              // float64 scalar-gradient sums of pass 2
+        q->s[0] = 0.0; q->s[1] = 0.0; q->s[2] = 0.0; q->ticket = 0u;
+    }
     const int lane = threadIdx.x & 63;
     const int c = lane % KP;
     const int s = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + lane / KP;
@@ -632,6 +636,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
                                                               const float *__restrict__ SOL,
                                                               float *__restrict__ accum, float *__restrict__ slab,
                                                               double *__restrict__ slabS, int slab_stride,
+                                                              Scal64 *__restrict__ sc64,
                                                               float *__restrict__ BG = nullptr,
                                                               float *__restrict__ GG = nullptr, int bg_stride = 0) {
     // BG != NULL (KP = 32): beta = wD A^2 and gamma = A u of every (spectrum, pixel) are also stored, [Bpad][bg_stride]
@@ -1215,6 +1220,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
         if (det && lane == 0 && bhalf == 0) {              // the reducer reads every (item, wave) record
             double *q = slabS + ((size_t)blockIdx.x * 4 + wv) * 3;
             q[0] = 0.0; q[1] = 0.0; q[2] = 0.0;
+        } else if (!det && bhalf == 0) {
+            scal64_commit(sc64, 0.0, 0.0, 0.0, gridDim.x * 4u, accS);
         }
         return;
     }
@@ -1228,9 +1235,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
             double *q = slabS + ((size_t)blockIdx.x * 4 + wv) * 3;
             q[0] = s_tau0; q[1] = s_c0; q[2] = s_beta;
         } else {
-            atomicAdd(accS + 0, (float)s_tau0);
-            atomicAdd(accS + 1, (float)s_c0);
-            atomicAdd(accS + 2, (float)s_beta);
+            scal64_commit(sc64, s_tau0, s_c0, s_beta, gridDim.x * 4u, accS);
         }
     }
 }

@@ -82,6 +82,8 @@ class QFA(object):
         # deterministic=True: per-block slab + fixed-order reducer instead of float32 atomics in pass 2
         # (qfa_nll_grad_det_f32): bit-identical sums from run to run, at the price of a (B/64) x accum-sized slab
         self.deterministic = False
+        # kernel-form switches of the *_ex_f32 entry points (_lib.F_*; 0 = defaults): A/B timing, cross-checks in tests/
+        self.flags = 0
 
     # ------------------------------------------------------------------ parameters
     def random_init_func(self) -> None:
@@ -163,6 +165,8 @@ class QFA(object):
         bs.zabs = _lib.require_device_tensor(zabs, f32, "zabs").value if self.Nb > 0 else None
         bs.mask = _lib.require_device_tensor(mask, torch.bool, "mask").value
         bs.A_blue = None
+        bs.zq1 = None
+        bs.pix_ratio = None
         if self._tau_callable is not None and self.Nb > 0:
             a = torch.exp(-1. * self._tau_callable(zabs)).to(f32).contiguous()   # user code (model.py:125)
             keep.append(a)
@@ -263,11 +267,11 @@ class QFA(object):
                 sl = torch.empty(slab_bytes, dtype=torch.uint8, device=self.device)
                 self._ws["slab"] = sl
             slab = C.c_void_p(sl.data_ptr())
-        _lib.check(_lib.lib().qfa_nll_grad_det_f32(
+        _lib.check(_lib.lib().qfa_nll_grad_ex_f32(
             C.byref(ps), C.byref(bs), C.byref(self._tau_model), B, self.Npix, self.Nb, self.Nh,
             C.c_void_p(nll.data_ptr()) if nll is not None else None, C.c_void_p(acc.data_ptr()),
-            C.c_void_p(ws.data_ptr()), ws.numel(), slab, slab_bytes, _lib.current_stream(self.device), evs),
-            "qfa_nll_grad_f32")
+            C.c_void_p(ws.data_ptr()), ws.numel(), slab, slab_bytes, int(self.flags), _lib.current_stream(self.device),
+            evs), "qfa_nll_grad_ex_f32")
         return acc
 
     def _finalize(self, acc, normalize=True):
@@ -337,11 +341,11 @@ class QFA(object):
         evs = None
         if events is not None:
             evs = (C.c_void_p * 4)(*[C.c_void_p(e.cuda_event) for e in events])
-        _lib.check(_lib.lib().qfa_predict_events_f32(
+        _lib.check(_lib.lib().qfa_predict_ex_f32(
             C.byref(ps), C.c_void_p(mu.data_ptr()), C.byref(bs), C.byref(self._tau_model), B, self.Npix, self.Nb,
             self.Nh, C.c_void_p(ll.data_ptr()), C.c_void_p(hmean.data_ptr()), C.c_void_p(hcov.data_ptr()),
             C.c_void_p(cont.data_ptr()), C.c_void_p(unc.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
-            _lib.current_stream(dev), evs), "qfa_predict_f32")
+            int(self.flags), _lib.current_stream(dev), evs), "qfa_predict_ex_f32")
         return ll, hmean, hcov, cont, unc
 
     def predict_to_npz(self, dataloader, output_dir, batch_size=4096):

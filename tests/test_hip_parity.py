@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import golden, rel_l2
+from qfa_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -370,13 +371,13 @@ def test_custom_tau_on_the_xdl_pass2(dev, npix, nh, B, monkeypatch):
     m1 = make_model(dev, p, mu)
     m2 = make_model(dev, p, mu, tau=lambda z: 0.751 * ((1 + z) / 4.5) ** 2.90 - 0.132)
     bt = batch_t(b, dev)
-    monkeypatch.setenv("QFA_PASS2_XDL", "1")
+    m1.flags = m2.flags = _lib.F_PASS2_XDL
     acc_x = m2.accumulate(*bt).clone()
     l1, g1 = m1.forward(*bt)
     l2, g2 = m2.forward(*bt)
-    monkeypatch.setenv("QFA_PASS2_XDL", "0")
+    m2.flags = _lib.F_PASS2_F32
     acc_f = m2.accumulate(*bt).clone()
-    monkeypatch.delenv("QFA_PASS2_XDL", raising=False)
+    m1.flags = m2.flags = 0
     for name, sl in PS.sections(m2).items():
         a, r = acc_x[sl].double().cpu().numpy(), acc_f[sl].double().cpu().numpy()
         if name in ("cnt", "n_blue", "n_spectra"):
@@ -554,8 +555,8 @@ def test_tolerance_sweep_float64_oracle_vs_float32_hip(dev, npix, nh):
                                        (1913, 8, 130), (200, 8, 70), (97, 5, 33), (64, 3, 9), (450, 1, 65)])
 def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatch):
     """N_h <= 16 has two forms of pass 2: k_grads (float32-MFMA stage 1) and k_grads_x (qfa_grads_x.h, KP = 8 or 16:
-    everything on the XDL pipe, two roles per SIMD, 32-pixel tiles; the default); QFA_PASS2_XDL=1 / 0 in the
-    environment selects one.  Ragged shapes (pixel axis not a multiple of 32, blue/red boundary inside a tile,
+    everything on the XDL pipe, two roles per SIMD, 32-pixel tiles; the default); QFA.flags = F_PASS2_XDL / F_PASS2_F32
+    selects one.  Ragged shapes (pixel axis not a multiple of 32, blue/red boundary inside a tile,
     spectra not a multiple of 16/64): both forms against each other section by section and against the oracle."""
     import torch
     from oracle import qfa_oracle as O
@@ -566,12 +567,12 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
     b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=3 * npix + nh)
     m = make_model(dev, p, mu)
     bt = batch_t(b, dev)
-    monkeypatch.setenv("QFA_PASS2_XDL", "1")
+    m.flags = _lib.F_PASS2_XDL
     acc_x = m.accumulate(*bt).clone()
     lx, gx = m._finalize(acc_x, True)
-    monkeypatch.setenv("QFA_PASS2_XDL", "0")
+    m.flags = _lib.F_PASS2_F32
     acc_f = m.accumulate(*bt).clone()
-    monkeypatch.delenv("QFA_PASS2_XDL", raising=False)
+    m.flags = 0
     for name, sl in PS.sections(m).items():
         a, r = acc_x[sl].double().cpu().numpy(), acc_f[sl].double().cpu().numpy()
         if name in ("cnt", "n_blue", "n_spectra"):
@@ -619,7 +620,7 @@ def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B):
                                        (450, 32, 70), (1000, 20, 130), (31, 17, 5), (2100, 27, 64)])
 def test_predict_writer_xdl_matches_f32_writer(dev, npix, nh, B, monkeypatch):
     """cont / unc come from k_predict_x (N_h <= 16) / k_predict_x32 (N_h = 17..32): split-bf16 products on the XDL
-    pipe; QFA_PREDICT_F32=1 selects the float32-MFMA writer k_predict_out: same values to float32 rounding on ragged
+    pipe; QFA.flags = F_PREDICT_F32 selects the float32-MFMA writer k_predict_out: same values to float32 rounding on ragged
     shapes, both against the oracle."""
     from oracle import qfa_oracle as O
     from qfa_amd import synthetic
@@ -628,11 +629,10 @@ def test_predict_writer_xdl_matches_f32_writer(dev, npix, nh, B, monkeypatch):
     b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=5 * npix + nh)
     m = make_model(dev, p, mu)
     bt = batch_t(b, dev, "flux")
-    monkeypatch.delenv("QFA_PREDICT_F32", raising=False)
     ll, hm, hc, cont, unc = [x.cpu().numpy() for x in m.predict(*bt)]
-    monkeypatch.setenv("QFA_PREDICT_F32", "1")
+    m.flags = _lib.F_PREDICT_F32
     ll2, hm2, hc2, cont2, unc2 = [x.cpu().numpy() for x in m.predict(*bt)]
-    monkeypatch.delenv("QFA_PREDICT_F32", raising=False)
+    m.flags = 0
     assert np.array_equal(ll, ll2) and np.array_equal(hm, hm2)
     assert np.max(np.abs(cont - cont2)) <= 2e-6 * np.max(np.abs(cont2))
     assert np.max(np.abs(unc - unc2)) <= 5e-6 * np.max(np.abs(unc2))

@@ -19,7 +19,7 @@ for B in [int(x) for x in sys.argv[3:]]:
     m = QFA(nb, nr, nh, dev, model_params=p)
     sl = PS.sections(m)
     for form in os.environ.get("DIAG_FORMS", "xdl,f32").split(","):
-        os.environ["QFA_PASS2_XDL"] = "0" if form == "f32" else "1"
+        m.flags = 0x1 if form == "f32" else 0x2          # _lib.F_PASS2_F32 / F_PASS2_XDL
         m.deterministic = True
         NR = int(os.environ.get('DIAG_RUNS', '4'))
         nll = [torch.empty(B, device=dev) for _ in range(NR)]

@@ -2,7 +2,7 @@
 # GPU box: s_memtime shares of one workgroup's tile steps in k_grads_x (library variant built with -DQFA_GX_STAMPS=1:
 # tools/build_gx_variant.sh st -DQFA_GX_STAMPS=1).  usage: tools/gx_stamps.sh <variant name>
 cd $GRAFT_REPO_ROOT
-QFA_PASS2_XDL=1 QFA_HIP_LIB=$PWD/qfa_amd/libqfa_$1.so python - <<'PY'
+QFA_HIP_LIB=$PWD/qfa_amd/libqfa_$1.so python - <<'PY'
 import ctypes, sys, os, runpy
 sys.argv = ["bench.py", "--config", "c3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-predict", "--sustain", "0"] + os.environ.get("STAMP_BENCH_ARGS", "").split()
 try:
