@@ -73,11 +73,12 @@ typedef struct {
 
 /* `flags` of the *_ex_f32 entry points (0 = the defaults; A/B timing and the cross-checks in tests/). */
 #define QFA_F_PASS2_F32    0x1u  /* N_h <= 16: pass 2 in its float32-MFMA form (k_grads)                        */
-#define QFA_F_PASS2_XDL    0x2u  /* N_h <= 16: pass 2 in its all-XDL form (k_grads_x / k_grads_w)               */
+#define QFA_F_PASS2_XDL    0x2u  /* N_h <= 16: pass 2 in its all-XDL form (k_grads_x)                        */
 #define QFA_F_S3_FAST      0x4u  /* stage 3 of pass 2 with three bf16 piece products (operands carried to ~17
                                     bits, <= 1.1e-5 per product) instead of the float32-grade six              */
 #define QFA_F_PREDICT_F32  0x8u  /* posterior writer in its float32-MFMA form (k_predict_out)                   */
-#define QFA_F_PASS2_ROLES  0x10u /* N_h <= 16: the two-role form of the all-XDL pass 2 (k_grads_x)              */
+#define QFA_F_PASS2_WFORM  0x10u /* N_h <= 16: the one-wave-per-SIMD form of the all-XDL pass 2 (k_grads_w: stage 3
+                                    re-associated as a K = spectrum GEMM; same results, slower -- DESIGN.md)    */
 
 int qfa_abi_version(void);
 

@@ -125,7 +125,7 @@ def _lowrank_core(F, A, D, w, delta):
 
 
 def nll_and_grads_single(params, delta, error, zabs, mask, tau_which="becker", tau_series=1,
-                         dtype=np.float64, A_blue=None):
+                         dtype=np.float64, A_blue=None, return_abs=False):
     """One spectrum: negative log-likelihood and the reference's six 'gradients'.
 
     Follows QFA/model.py:107-158 in low-rank form.
@@ -163,6 +163,12 @@ def nll_and_grads_single(params, delta, error, zabs, mask, tau_which="becker", t
     grads = {"F": gF, "Psi": gPsi, "omega": gOm,
              "tau0": np.asarray(g_tau0, dtype=dtype), "c0": np.asarray(g_c0, dtype=dtype),
              "beta": np.asarray(g_beta, dtype=dtype)}
+    if return_abs:
+        # sum of |terms| of the three scalar sums: their condition (|sum| / sum|terms| is 1/50 .. 1/900 on data drawn
+        # from the model); a float32 implementation is judged against 2^-24 x this, not against the cancelled sum
+        absum = {"tau0": float(np.sum(np.abs(e * pw))), "c0": float(np.sum(np.abs(e))),
+                 "beta": float(np.sum(np.abs(e * p["tau0"] * pw * np.log(1.0 + z))))}
+        return nll, grads, absum
     return nll, grads
 
 

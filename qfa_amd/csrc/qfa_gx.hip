@@ -1,11 +1,38 @@
 // qfa_gx.hip -- pass 2 on the XDL pipe (qfa_grads_x.h) in its own translation unit: the kernel is large and
 // is iterated on separately from the rest of the library.
 #include "qfa_grads_x.h"
+#include "qfa_grads_w.h"
 #include "qfa_predict_x.h"
 
 #include "qfa_host.h"
 
-size_t qfa_gx_image_bytes(int KP, int ntiles32) { return (size_t)ntiles32 * (KP == 8 ? GXT<8>::TILE_B : GXT<16>::TILE_B); }
+size_t qfa_gx_image_bytes(int KP, int ntiles32) {            // the larger of the two forms' images (one region serves both)
+    const size_t x = KP == 8 ? GXT<8>::TILE_B : GXT<16>::TILE_B, w = KP == 8 ? GWT<8>::TILE_B : GWT<16>::TILE_B;
+    return (size_t)ntiles32 * (x > w ? x : w);
+}
+
+// pass 2, one-wave-per-SIMD form (qfa_grads_w.h)
+template <int KP>
+static void gw_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                      int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, float4 *ZS, float *accum,
+                      float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st) {
+    const bool zf = b.zq1 && b.pix_ratio && Nb > 0;
+    k_prep_pgw<KP><<<ntiles32, 256, 0, st>>>(p, tau, zf ? b.pix_ratio : nullptr, Npix, Nb, Nh, PGW);
+    if (zf) k_zfac_spec<<<(B + 255) / 256, 256, 0, st>>>(b.zq1, p, tau, B, ZS);
+    auto go = [&](auto hasa, auto zfac) {
+        k_grads_w<KP, decltype(hasa)::value, decltype(zfac)::value><<<wp.items(), 256, 0, st>>>(
+            p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, ZS, accum, slab, slabS, slab_stride, sc64);
+    };
+    if (b.A_blue) go(std::true_type{}, std::false_type{});
+    else if (zf) go(std::false_type{}, std::true_type{});
+    else go(std::false_type{}, std::false_type{});
+}
+void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, float *ZS, float *accum, float *slab,
+                   double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st) {
+    if (KP == 8) gw_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, reinterpret_cast<float4 *>(ZS), accum, slab, slabS, slab_stride, sc64, st);
+    else gw_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, reinterpret_cast<float4 *>(ZS), accum, slab, slabS, slab_stride, sc64, st);
+}
 
 template <int KP>
 static void gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,

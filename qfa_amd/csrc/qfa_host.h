@@ -13,6 +13,11 @@ void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
                    double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st);
 
+// the one-wave-per-SIMD form of the all-XDL pass 2 (qfa_grads_w.h, built in qfa_gx.hip): QFA_F_PASS2_WFORM
+void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, float *ZS, float *accum, float *slab,
+                   double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st);
+
 // posterior writer for N_h <= 16 on the XDL pipe (qfa_predict_x.h, built in qfa_gx.hip)
 size_t qfa_px_image_bytes(int KP, int ntiles32);
 void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int Nh, int ntiles32, const WorkPlan &wp,
@@ -89,7 +94,7 @@ struct Layout {
     int spb1;                                          // spectra per block of pass 1's plan (128 for the 8-wave k_moments_x)
     WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
     WorkPlan wpp;                                      // posterior writer on the XDL pipe (k_predict_x, N_h <= 16)
-    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, total;   // float offsets
+    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, oZS, total;   // float offsets
     int bg_stride;                                     // beta / gamma hand-over of pass 2 at N_h = 17..32 ([2][Bpad][NpixPad])
 };
 
@@ -134,6 +139,7 @@ Layout make_layout_t(int B, int Npix) {
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
     L.oNLL = take((size_t)L.Bpad);
     L.oNBL = take((size_t)L.Bpad);
+    L.oZS = take(4 * (size_t)L.Bpad);                   // per-spectrum factors of the factored-z input form (float4 each)
     L.oRED = take(2 * 2 * NRED + 2 + sizeof(Scal64) / 4);   // k_reduce_nll: 2 x NRED doubles + the ticket counter; then the
                                                             // float64 scalar-gradient sums of pass 2 (Scal64)
     L.oBG = 0;
@@ -295,8 +301,12 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     k_reduce_nll<<<nred, 256, 0, st>>>(nllbuf, NBL, B, accum + accS, red, ticket);
     mark(3);
     if (pass2_xdl) {
-        qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
-                      accum, slab, slabS, (int)D.stride, sc64, flags, st);
+        if (!(flags & QFA_F_PASS2_WFORM))
+            qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
+                          accum, slab, slabS, (int)D.stride, sc64, flags, st);
+        else
+            qfa_gw_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
+                          ws + L.oZS, accum, slab, slabS, (int)D.stride, sc64, st);
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
         return hip_status();

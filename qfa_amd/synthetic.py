@@ -35,6 +35,14 @@ def wavelength_grid(n_pix=None):
     return wav, nb, len(wav) - nb
 
 
+def desi_grid():
+    """A rest-frame grid with the pixel counts of the reference's second shipped model, data/model_parameters_desi.npz
+    (N_pix = 9243, N_b = 2238): linear, 1040 A + 0.0785 A per pixel (the file does not record its own grid)."""
+    wav = 1040.0 + (LYA - 1040.0) / 2237.5 * np.arange(9243)
+    nb = int(np.sum(wav < LYA))
+    return wav, nb, len(wav) - nb
+
+
 def mock_parameters(n_pix, nb, nh, seed=0, mu=None):
     """Smooth random loadings and realistic noise scales (SURVEY 8(d) 'Parameters')."""
     rng = np.random.default_rng(seed)

@@ -23,9 +23,11 @@ TOL_SECTION = {"accF": 3e-5, "sumA": 3e-6, "gPsi": 1e-5, "gOmega": 1e-5, "g_tau0
                "g_beta": 3e-5, "sum_nll": 1e-6, "nll_per_spectrum_rel_l2": 3e-6, "nll_per_spectrum_max_rel": 5e-5}
 # sampled sub-batch vs float64 oracle (achieved: loss 2e-7, per-spectrum NLL <= 2.6e-6, F <= 3.4e-5, Psi/omega <= 4.4e-6).
 # The three scalar gradients of data drawn from the model itself are sums of cancelling terms (the expected gradient is
-# zero): their error is bounded against what the float32 numpy oracle achieves on the same sub-batch.
-TOL_ORACLE = {"loss": 2e-6, "nll_per_spectrum_max_rel": 5e-6, "F": 1e-4, "Psi": 2e-5, "omega": 2e-5}
-SCALAR_VS_NP32 = 6.0
+# zero; sum|terms| / |sum| = 50..900): a fixed bound on the error in units of sum|terms| -- 1.5e-7 = 2.5 x 2^-24 (achieved
+# 5e-8..8e-8, profiles/r3_scalar_probe.txt) -- AND a fixed relative bound on the cancelled sum itself.
+TOL_ORACLE = {"loss": 2e-6, "nll_per_spectrum_max_rel": 5e-6, "F": 1e-4, "Psi": 2e-5, "omega": 2e-5,
+              "tau0_over_abs": 1.5e-7, "c0_over_abs": 1.5e-7, "beta_over_abs": 1.5e-7,
+              "tau0": 2e-4, "c0": 2e-4, "beta": 2e-4}
 
 
 @pytest.fixture(scope="module")
@@ -59,8 +61,6 @@ def run_config(dev, npix, nh, B, masks, seed, n_oracle, tol_oracle=None):
         assert oe["nan_pattern_" + k], k
     for name, tol in tol_oracle.items():
         assert oe[name] < tol, (name, oe[name], tol)
-    for k in ("tau0", "c0", "beta"):
-        assert oe[k] < max(5e-5, SCALAR_VS_NP32 * oe[k + "_np32"]), (k, oe[k], oe[k + "_np32"])
     del batch
     torch.cuda.empty_cache()
 

@@ -10,10 +10,12 @@ shipped build in profiles/r2_accuracy.txt:
   (profiles/r2_accuracy_precise_math.txt), so the float32 summation order is the responsible term, not the hardware
   transcendentals), hmean/hcov 1e-4.
 Continuum error is measured as max|err| / max|cont| (the mock continua cross zero)."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import golden, rel_l2
+from conftest import GOLDEN, golden, rel_l2
 from qfa_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -572,9 +574,18 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
     lx, gx = m._finalize(acc_x, True)
     m.flags = _lib.F_PASS2_F32
     acc_f = m.accumulate(*bt).clone()
+    m.flags = _lib.F_PASS2_XDL | _lib.F_PASS2_WFORM           # the one-wave-per-SIMD form (k_grads_w, qfa_grads_w.h)
+    acc_w = m.accumulate(*bt).clone()
     m.flags = 0
     for name, sl in PS.sections(m).items():
+        aw = acc_w[sl].double().cpu().numpy()
         a, r = acc_x[sl].double().cpu().numpy(), acc_f[sl].double().cpu().numpy()
+        if name in ("cnt", "n_blue", "n_spectra"):
+            assert np.array_equal(aw, r), name
+        elif aw.size == 1:
+            assert abs(aw[0] - r[0]) <= 1e-4 * abs(r[0]) + 1e-6, (name, aw, r)
+        else:
+            assert rel_l2(aw, r) < 5e-5, (name, rel_l2(aw, r))
         if name in ("cnt", "n_blue", "n_spectra"):
             assert np.array_equal(a, r), name
         elif a.size == 1:
@@ -640,3 +651,36 @@ def test_predict_writer_xdl_matches_f32_writer(dev, npix, nh, B, monkeypatch):
         o = O.predict_single(p, mu, b["flux"][s], b["error"][s], b["zabs"][s], b["mask"][s])
         assert np.max(np.abs(cont[s] - o[3])) / np.max(np.abs(o[3])) < 1e-4
         assert rel_l2(unc[s], o[4]) < 1e-4
+
+
+def test_g13_desi_model(dev):
+    """The reference's DESI model (N_pix = 9243, N_b = 2238, N_h = 8; data/model_parameters_desi.npz) through the HIP path
+    against the imported reference's outputs (golden g13): prediction_for_single_spectra with the full mask and with the
+    blue side masked, and loglikelihood_and_gradient_for_single_spectra (QFA/model.py:107-180)."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import QFA, synthetic
+    p, mu = O.load_params_npz(os.path.join(GOLDEN, "model_parameters_desi.npz"))
+    wav, nb, nr = synthetic.desi_grid()
+    g = golden("g13_desi.npz")
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 2, seed=int(g["seed"]))
+    m = QFA(nb, nr, 8, dev)
+    with pytest.warns(UserWarning):
+        m.load_from_npz(os.path.join(GOLDEN, "model_parameters_desi.npz"))         # (c0 <- beta, as the reference loads it)
+    T = lambda x: torch.tensor(x, device=dev)
+    for tag, mk in (("full", b["mask"][0]), ("red", b["mask"][0] & (np.arange(len(wav)) >= nb))):
+        ll, hm, hc, cont, unc = m.prediction_for_single_spectra(T(b["flux"][0]), T(b["error"][0]), T(b["zabs"][0]), T(mk))
+        assert ll.shape == (1, 1) and hm.shape == (8, 1) and hc.shape == (8, 8) and cont.shape == (9243,)
+        assert abs(ll.item() - float(g[f"ll_{tag}"].squeeze())) / abs(float(g[f"ll_{tag}"].squeeze())) < 1e-5
+        assert rel_l2(hm.cpu().numpy(), g[f"hmean_{tag}"]) < 1e-4
+        assert rel_l2(hc.cpu().numpy(), g[f"hcov_{tag}"]) < 1e-4
+        c = cont.cpu().numpy()
+        assert np.max(np.abs(c - g[f"cont_{tag}"])) / np.max(np.abs(g[f"cont_{tag}"])) < 1e-4      # north_star: 1e-4 relative
+        assert rel_l2(unc.cpu().numpy(), g[f"unc_{tag}"]) < 1e-4
+    nll, gr = m.loglikelihood_and_gradient_for_single_spectra(T(b["delta"][1]), T(b["error"][1]), T(b["zabs"][1]), T(b["mask"][1]))
+    assert abs(nll.item() - float(g["nll"].squeeze())) / abs(float(g["nll"].squeeze())) < 1e-5
+    assert rel_l2(gr["F"].cpu().numpy(), g["g_F"]) < 3e-4
+    assert rel_l2(gr["Psi"].cpu().numpy(), g["g_Psi"]) < 2e-5 and rel_l2(gr["omega"].cpu().numpy(), g["g_omega"]) < 2e-5
+    for k in ("tau0", "c0", "beta"):
+        assert abs(gr[k].item() - float(g[f"g_{k}"])) / abs(float(g[f"g_{k}"])) < 3e-4, k
+    assert (gr["F"].cpu().numpy()[~b["mask"][1]] == 0).all()

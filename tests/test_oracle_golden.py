@@ -219,3 +219,29 @@ def test_g11_dataloader_preprocessing():
         assert rel_l2(O.delta_from_flux(wav, flux, zq, mu, nb), g[f"delta_{tag}"]) < 1e-12
     # the second grid reaches below Ly-beta: two series contribute there
     assert int(np.sum(g["wav_lyb"][0] < O._LYMAN_LAM)) == 2
+
+
+def test_g13_desi_model_reference_import_outputs():
+    """The reference's second shipped model (data/model_parameters_desi.npz: N_pix = 9243, N_b = 2238, N_h = 8): one
+    prediction (full mask, blue side masked) and one single-spectrum NLL + gradients from the imported reference
+    (tests/golden/make_golden_desi.py) -- the one real large-N_pix workload the reference ships."""
+    import os
+    from conftest import GOLDEN
+    p, mu = O.load_params_npz(os.path.join(GOLDEN, "model_parameters_desi.npz"))
+    wav, nb, nr = synthetic.desi_grid()
+    assert (len(wav), nb, p["F"].shape) == (9243, 2238, (9243, 8))
+    g = golden("g13_desi.npz")
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 2, seed=int(g["seed"]))
+    for tag, mk in (("full", b["mask"][0]), ("red", b["mask"][0] & (np.arange(len(wav)) >= nb))):
+        ll, hm, hc, cont, unc = O.predict_single(p, mu, b["flux"][0], b["error"][0], b["zabs"][0], mk)
+        assert abs(ll - float(g[f"ll_{tag}"].squeeze())) / abs(float(g[f"ll_{tag}"].squeeze())) < 5e-6
+        assert rel_l2(hm, g[f"hmean_{tag}"].squeeze()) < 1e-4
+        assert rel_l2(hc, g[f"hcov_{tag}"]) < 1e-4
+        assert rel_l2(cont, g[f"cont_{tag}"]) < 2e-6
+        assert rel_l2(unc, g[f"unc_{tag}"]) < 2e-5
+    nll, gr = O.nll_and_grads_single(p, b["delta"][1], b["error"][1], b["zabs"][1], b["mask"][1])
+    assert abs(nll - float(g["nll"].squeeze())) / abs(float(g["nll"].squeeze())) < 5e-6
+    assert rel_l2(gr["F"], g["g_F"]) < 3e-4
+    assert rel_l2(gr["Psi"], g["g_Psi"]) < 2e-5 and rel_l2(gr["omega"], g["g_omega"]) < 2e-5
+    for k in ("tau0", "c0", "beta"):
+        assert abs(gr[k] - g[f"g_{k}"]) / abs(g[f"g_{k}"]) < 2e-4, k

@@ -1,0 +1,147 @@
+"""Stage 3 of pass 2 (the F-gradient contraction G_s = F_tile Z_s, summed over K and over every spectrum of the batch)
+under conditions chosen to expose a narrow product: F columns spanning 10^3 in scale, parameters after 200 training
+steps (near-stationary: the gradient is a small difference of large sums), and the NORMALISED gradients of a 20 000-
+spectrum batch of the headline shape against the float64 oracle on the host cores -- HIP against the oracle, not HIP
+against HIP.  The default build issues six bf16 piece products per float32 product (float32 grade);
+flags = F_S3_FAST selects three (operands carried to ~17 bits) and is measured beside it.  Reference semantics:
+QFA/model.py:100-104,136-137 (sum over spectra / count), :204-215 (the training loop)."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from qfa_amd import _lib
+
+pytestmark = pytest.mark.gpu
+KEYS = ("F", "Psi", "omega", "tau0", "c0", "beta")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _model(dev, p, mu, nb, nr, nh, flags=0):
+    import torch
+    from qfa_amd import QFA
+    m = QFA(nb, nr, nh, dev, model_params=p)
+    m.mu = torch.tensor(mu, device=dev)
+    m.flags = flags
+    return m
+
+
+def _bt(b, dev):
+    import torch
+    return tuple(torch.tensor(b[k], device=dev) for k in ("delta", "error", "zabs", "mask"))
+
+
+def _gF_terms_scale(m, acc):
+    """per-element size of the two sums whose difference is gF = F sumA - accF (the yardstick in the cancellation regime)"""
+    n = m.Npix * m.Nh
+    accF = acc[:n].double().cpu().numpy().reshape(m.Npix, m.Nh)
+    cnt = acc[n + 2 * m.Npix + m.Nb: n + 3 * m.Npix + m.Nb].double().cpu().numpy()
+    return np.linalg.norm(accF / np.maximum(cnt, 1.0)[:, None])
+
+
+@pytest.mark.parametrize("npix,nh,B", [(640, 16, 48), (640, 32, 40), (352, 12, 70)])
+def test_f_columns_spanning_three_decades(dev, npix, nh, B):
+    """F columns scaled by 10^-1.5 .. 10^+1.5 (the spectra are drawn from THAT model): G = F Z then has products of very
+    different size under one accumulator.  Six-term default within the fixed tolerances; the three-term form is looser."""
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=900 + nh)
+    p = dict(p)
+    p["F"] = (p["F"] * (10.0 ** np.linspace(-1.5, 1.5, nh))[None, :]).astype(np.float32)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=901 + nh)
+    ol, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
+    errs = {}
+    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)):
+        m = _model(dev, p, mu, nb, nr, nh, fl)
+        loss, g = m.forward(*_bt(b, dev))
+        assert abs(loss.item() - ol) <= 5e-6 * abs(ol)
+        errs[name] = {k: rel_l2(g[k].cpu().numpy(), og[k]) for k in KEYS}
+        # column by column: a small column must not drown in the error of a large one
+        gf, rf = g["F"].cpu().numpy().astype(np.float64), og["F"]
+        errs[name]["F_worst_column"] = max(rel_l2(gf[:, a], rf[:, a]) for a in range(nh))
+    print("F columns over 10^3:", npix, nh, errs)
+    six = errs["six"]
+    assert six["F"] < 1e-4 and six["F_worst_column"] < 2e-4, six
+    assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
+    assert errs["fast"]["F"] < 1e-3, errs["fast"]                # (not the default; recorded in profiles/r3_accuracy.txt)
+
+
+@pytest.mark.parametrize("nh", [16, 32])
+def test_near_stationary_parameters_after_200_steps(dev, nh):
+    """200 Adam steps on a fixed data set, then the gradient of a batch at THOSE parameters: the F gradient is now a small
+    difference of F sumA and accF.  Error measured against the float64 oracle, relative to the gradient AND to the size of
+    the cancelling sums."""
+    from oracle import qfa_oracle as O
+    from qfa_amd import Adam, step_scheduler, synthetic
+    npix, N, B = 640, 512, 128
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=40 + nh)
+    data = synthetic.make_batch_numpy(p, mu, wav, nb, N, seed=41 + nh)
+    p0 = dict(p)
+    p0["F"] = (p["F"] * 0.7 + 0.03 * np.random.default_rng(5).standard_normal(p["F"].shape)).astype(np.float32)
+    m = _model(dev, p0, mu, nb, nr, nh)
+    opt = Adam(m.parameters, dev, scheduler=step_scheduler(0.9, 20), learning_rate=2e-3, weight_decay=1e-3)
+    bt = _bt(data, dev)
+    for step in range(200):
+        a = (step % (N // B)) * B
+        m.step(opt, *(x[a:a + B] for x in bt))
+        if (step + 1) % (N // B) == 0:
+            opt.step()
+    trained = {k: m.parameters[k].cpu().numpy() for k in KEYS}
+    assert all(np.isfinite(v).all() for v in trained.values())
+    sub = {k: data[k][:96] for k in ("delta", "error", "zabs", "mask")}
+    ol, og = O.forward(trained, sub["delta"], sub["error"], sub["zabs"], sub["mask"])
+    out = {}
+    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)):
+        mm = _model(dev, trained, mu, nb, nr, nh, fl)
+        acc = mm.accumulate(*_bt(sub, dev)).clone()
+        loss, g = mm._finalize(acc, True)
+        d = g["F"].cpu().numpy().astype(np.float64) - og["F"]
+        out[name] = {"F_rel": rel_l2(g["F"].cpu().numpy(), og["F"]), "F_over_terms": np.linalg.norm(d) / _gF_terms_scale(mm, acc),
+                     "Psi": rel_l2(g["Psi"].cpu().numpy(), og["Psi"]), "omega": rel_l2(g["omega"].cpu().numpy(), og["omega"]),
+                     "cancellation": _gF_terms_scale(mm, acc) / np.linalg.norm(og["F"])}
+    print("after 200 steps:", nh, out)
+    six = out["six"]
+    assert six["F_over_terms"] < 1e-6 and six["F_rel"] < 2e-4, six          # fixed: a few float32 ulps of the cancelling sums
+    assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
+    assert out["fast"]["F_rel"] < 2e-3, out["fast"]
+
+
+def test_headline_shape_20000_spectra_normalised_gradients_vs_float64_oracle(dev, tmp_path):
+    """c3's shape (4000 px, N_h = 16, masks), 20 000 spectra drawn from the model: the NORMALISED gradients of one HIP
+    launch against the float64 oracle summed over the same spectra on the host cores."""
+    import torch
+    from qfa_amd import synthetic
+    from tools import oracle_pool
+    from tools import parity_sections as PS
+    npix, nh, B = 4000, 16, 20000
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=20220700)
+    batch = PS.make_config_batch(p, mu, wav, nb, B, 20220733, dev, True)
+    host = {k: x.cpu().numpy() for k, x in zip(("delta", "error", "zabs", "mask"), batch)}
+    ol, og, sums, counts = oracle_pool.oracle_sums(p, host, str(tmp_path / "oracle"))
+    out = {}
+    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)):
+        m = _model(dev, p, mu, nb, nr, nh, fl)
+        acc = m.accumulate(*batch).clone()
+        loss, g = m._finalize(acc, True)
+        e = {k: rel_l2(g[k].cpu().numpy(), og[k]) for k in KEYS}
+        e["loss"] = abs(loss.item() - ol) / abs(ol)
+        d = g["F"].cpu().numpy().astype(np.float64) - og["F"]
+        e["F_over_terms"] = np.linalg.norm(d) / _gF_terms_scale(m, acc)
+        e["cancellation"] = _gF_terms_scale(m, acc) / np.linalg.norm(og["F"])
+        out[name] = e
+    print("20000 x 4000, N_h = 16 vs float64 oracle:", out)
+    six, fast = out["six"], out["fast"]
+    assert six["loss"] < 2e-6
+    assert six["F"] < 2e-4 and six["F_over_terms"] < 5e-7, six
+    assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
+    assert six["F"] <= 1.05 * fast["F"] + 1e-6, (six["F"], fast["F"])      # six piece products are never the worse form
+    del batch
+    torch.cuda.empty_cache()

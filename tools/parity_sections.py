@@ -76,8 +76,10 @@ def section_errors(model, batch, chunk=512):
 
 def oracle_subbatch_errors(model, p, batch, idx):
     """normalised gradients + loss + per-spectrum NLL of the sub-batch `idx` (its own launch) vs the float64 oracle.
-    Keys "<k>_np32": the same error for the oracle evaluated in float32 numpy -- the yardstick for gradients that are
-    sums of strongly cancelling terms (the three scalar gradients on data drawn from the model itself)."""
+    Keys "<k>_np32": the same error for the oracle evaluated in float32 numpy.  The three scalar gradients are sums of
+    strongly cancelling terms (data drawn from the model itself: expectation zero): "<k>_over_abs" is their error divided
+    by the sum of |terms| (what a float32 implementation can be held to: a few 2^-24), "<k>_cancellation" the ratio
+    sum|terms| / |sum|."""
     from oracle import qfa_oracle as O
     d, e, z, mk = (x[idx] for x in batch)
     n = d.shape[0]
@@ -87,8 +89,11 @@ def oracle_subbatch_errors(model, p, batch, idx):
     dn, en, zn, mn = (x.cpu().numpy() for x in (d, e, z, mk))
     per = np.empty(n)
     sums = counts = sums32 = None
+    absum = {"tau0": 0.0, "c0": 0.0, "beta": 0.0}
     for s in range(n):
-        per[s], g = O.nll_and_grads_single(p, dn[s], en[s], zn[s], mn[s])
+        per[s], g, ab = O.nll_and_grads_single(p, dn[s], en[s], zn[s], mn[s], return_abs=True)
+        for k in absum:
+            absum[k] += ab[k]
         _, g32 = O.nll_and_grads_single(p, dn[s], en[s], zn[s], mn[s], dtype=np.float32)
         if sums is None:
             sums = {k: np.zeros_like(v) for k, v in g.items()}
@@ -109,4 +114,9 @@ def oracle_subbatch_errors(model, p, batch, idx):
             out[k] = float(np.linalg.norm(ours[ok] - ref[ok]) / max(np.linalg.norm(ref[ok]), 1e-300))
             r32 = (sums32[k] / counts[k]).astype(np.float64)
             out[k + "_np32"] = float(np.linalg.norm(r32[ok] - ref[ok]) / max(np.linalg.norm(ref[ok]), 1e-300))
+        for k in ("tau0", "c0", "beta"):                # error in units of sum|terms| (condition-free), and the condition
+            ours = float(gr[k].item())
+            ref = float(sums[k] / counts[k])
+            out[k + "_over_abs"] = abs(ours - ref) * float(counts[k]) / max(absum[k], 1e-300)
+            out[k + "_cancellation"] = absum[k] / max(abs(float(sums[k])), 1e-300)
     return out
