@@ -23,11 +23,11 @@ TOL_SECTION = {"accF": 3e-5, "sumA": 3e-6, "gPsi": 1e-5, "gOmega": 1e-5, "g_tau0
                "g_beta": 3e-5, "sum_nll": 1e-6, "nll_per_spectrum_rel_l2": 3e-6, "nll_per_spectrum_max_rel": 5e-5}
 # sampled sub-batch vs float64 oracle (achieved: loss 2e-7, per-spectrum NLL <= 2.6e-6, F <= 3.4e-5, Psi/omega <= 4.4e-6).
 # The three scalar gradients of data drawn from the model itself are sums of cancelling terms (the expected gradient is
-# zero; sum|terms| / |sum| = 50..900): a fixed bound on the error in units of sum|terms| -- 1.5e-7 = 2.5 x 2^-24 (achieved
-# 5e-8..8e-8, profiles/r3_scalar_probe.txt) -- AND a fixed relative bound on the cancelled sum itself.
+# zero; sum|terms| / |sum| = 200..4 500 on these sub-batches): a FIXED bound on the error in units of sum|terms| -- 1.5e-7 =
+# 2.5 x 2^-24 (achieved 6e-8..7.5e-8, profiles/r3_accuracy.txt; the relative error of the cancelled sum is that times the
+# cancellation: 1.4e-5 at c2, 3e-4 at c3, where the float32 numpy oracle itself is at 3.5e-4).
 TOL_ORACLE = {"loss": 2e-6, "nll_per_spectrum_max_rel": 5e-6, "F": 1e-4, "Psi": 2e-5, "omega": 2e-5,
-              "tau0_over_abs": 1.5e-7, "c0_over_abs": 1.5e-7, "beta_over_abs": 1.5e-7,
-              "tau0": 2e-4, "c0": 2e-4, "beta": 2e-4}
+              "tau0_over_abs": 1.5e-7, "c0_over_abs": 1.5e-7, "beta_over_abs": 1.5e-7}
 
 
 @pytest.fixture(scope="module")
