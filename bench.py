@@ -15,18 +15,20 @@ no masks).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (pass 2: k_grads_x at N_h = 9..16, k_grads at N_h <= 8,
-the three launches k_s12_x + 2 k_grads_s3 at N_h = 17..32): its
-algorithmic flops over its mean duration measured with HIP events recorded by
-the library on the launch stream inside the timed region.  Two roofs are reported for it: `frac` against the float32
-MFMA / VALU peak (157.3 TFLOP/s, the roof SURVEY.md 8(d) names: the arithmetic is float32), and `frac_xdl` against
-the bf16 XDL pipe the contractions are actually issued on -- every float32 product is six bf16 MFMAs over operands
-split into three bf16 pieces (three over the two leading pieces in stage 3 of pass 2), so the kernel's
-contraction flops x 6 (x 3) are priced against the dense bf16 peak (2.5 PFLOP/s).  The kernels are BUILT against the XDL roof; `frac` can therefore exceed what the
-f32 pipe could give.  After the timed region the same step runs for >= 3 s more (`sustained_*`: the clock the chip
-holds under seconds of this load, not a burst), then `QFA.predict` is timed (`predict`: spectra/s and the HBM roofline
-of its output writer), then `cpu_baseline` times the dense O(N_pix^3) CPU port of the reference's per-spectrum step
-(oracle/dense_port.py) on a bounded sample of the same batch (rank 0, N = 1 only).
+`python bench.py --gpus N` without a launcher starts the N ranks itself (fresh child processes, before this process
+touches the GPU) and relays rank 0's line.  Rank 0 prints ONE JSON line.
+
+`roofline` describes the dominant kernel (pass 2: k_grads_x at N_h = 9..16, k_grads at N_h <= 8, the three launches
+k_s12_x + 2 k_grads_s3 at N_h = 17..32; its mean duration is measured with HIP events recorded by the library on the
+launch stream inside the timed region).  The contractions are float32 products ISSUED as bf16 piece products on the XDL
+pipe (operands split into three bf16 pieces, six products per float32 product: DESIGN.md section 4), so `achieved` =
+the issued bf16 flops per launch / duration and `peak` = the dense bf16 MFMA peak (2.5 PFLOP/s); the algorithmic float32
+flops against the float32 roof the survey names are kept as `achieved_alg_fp32` / `frac_vs_fp32_roof` (that fraction can
+exceed 1: the kernel does not run on that pipe).  `step_roofline` holds the step's HBM side: algorithmic bytes, the
+measured bytes (profiles/traffic_<config>.json, rocprofv3 PMC) and their ratio.  After the timed region the same step
+runs for >= 3 s more (`sustained_*`: the clock the chip holds under seconds of this load, not a burst), then `QFA.predict`
+is timed (`predict`: spectra/s and the HBM roofline of its output writer), then `cpu_baseline` times the dense O(N_pix^3)
+CPU port of the reference's per-spectrum step (oracle/dense_port.py) on a bounded sample of the same batch (rank 0, N = 1).
 """
 import argparse
 import json
@@ -44,12 +46,16 @@ CONFIGS = {
     "c3": (100000, 4000, 16, True, 32),
     "c1": (128, 1913, 8, True, 64),
     "c5": (20000, 8000, 32, True, 4),
+    # the reference's own shapes: its default batch (QFA/config.py:32) on the SDSS grid, and its second shipped model
+    # (data/model_parameters_desi.npz: N_pix = 9243, N_b = 2238, N_h = 8)
+    "c1b": (500, 1913, 8, True, 64),
+    "desi": (40000, 9243, 8, True, 4),
 }
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (XDL) peak
 PEAK_HBM_GBS = 8000.0
 # the true reference (imported in the survey container, SURVEY.md section 6 / BASELINE.md section 2): forward, 8 cores
-REFERENCE_8CORE = {"c1": 13.4, "c2": 12.2, "c3": 1.54, "c5": 0.21}
+REFERENCE_8CORE = {"c1": 13.4, "c1b": 13.4, "c2": 12.2, "c3": 1.54, "c5": 0.21}
 
 
 def alg_flops(npix, k):
@@ -169,6 +175,52 @@ def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
             "call_hbm_frac": (B / dt) * by_total / (PEAK_HBM_GBS * 1e9), "alg_bytes_per_spectrum": by_total}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as FRESH child processes
+    (torch.distributed.run) before this process has touched the GPU, relay rank 0's single JSON line, exit with the
+    launcher's status.  (Never an exec of a process that has initialised HIP.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(r.stdout.decode(errors="replace")[-4000:])
+    raise SystemExit(r.returncode if (r.returncode or lines) else 1)
+
+
+def dry_run(args, real_stdout):
+    """Launcher rehearsal without a GPU (tests/test_bench_launch.py): rendezvous, barrier, MAX all-reduce of the step time and
+    the one-line protocol of the real run; no spectra are processed and the line says so."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps({"metric": "spectra/sec per EM step", "value": None, "dry_run": True,
+                                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                           "max_over_ranks": float(t.item())}) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     # The contract is ONE line on stdout.  RCCL prints a version banner to stdout when the first communicator is made
     # (and Gloo its connection report): everything but the result line goes to stderr, the result to the real stdout.
@@ -186,7 +238,13 @@ def main():
     ap.add_argument("--no-predict", action="store_true")
     ap.add_argument("--deterministic", action="store_true", help="fixed-order accumulation (model.deterministic)")
     ap.add_argument("--flags", type=lambda x: int(x, 0), default=0, help="QFA_F_* kernel-form flags (include/qfa_hip.h); 0 = defaults")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal without a GPU: no spectra are processed")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.dup2(real_stdout, 1)
+        self_launch(args)
+    if args.dry_run:
+        return dry_run(args, real_stdout)
 
     import numpy as np
     import torch
@@ -197,8 +255,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running with {world} rank(s)", file=sys.stderr)
     local %= max(1, torch.cuda.device_count())          # (fewer devices than ranks: a rehearsal on one GPU shares it)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -217,10 +274,13 @@ def main():
     B, npix, nh, masks, n_cpu = CONFIGS[args.config]
     if args.batch:
         B = args.batch
-    wav, nb, nr = synthetic.wavelength_grid(None if args.config == "c1" else npix)
+    if args.config == "desi":
+        wav, nb, nr = synthetic.desi_grid()
+    else:
+        wav, nb, nr = synthetic.wavelength_grid(None if args.config in ("c1", "c1b") else npix)
     npix = len(wav)
     params, mu = synthetic.mock_parameters(npix, nb, nh, seed=20220700)
-    cfg_index = {"c1": 1, "c2": 2, "c3": 3, "c5": 5}[args.config]
+    cfg_index = {"c1": 1, "c2": 2, "c3": 3, "c5": 5, "c1b": 11, "desi": 13}[args.config]
     # generate in slabs to bound temporary memory
     parts = []
     slab = 25000
@@ -303,31 +363,56 @@ def main():
     by = alg_bytes(npix, nb)
     rate = world * B * args.steps / dt
     rate_gpu = B * args.steps / dt
+    fl = int(args.flags)
+    fast = bool(fl & 0x4)                     # QFA_F_S3_FAST
     if nh > 16:
         p2_name = "k_s12_x+2*k_grads_s3"      # pass 2 at N_h = 17..32: three launches, timed together by the stage events
-    else:
-        p2_name = "k_grads_x" if 9 <= nh <= 16 and os.environ.get("QFA_PASS2_XDL", "1") != "0" else "k_grads"
-    dominant = p2_name if ms_p2 >= ms_p1 else "k_moments"
+    else:                                     # the same rule as pass2_use_xdl (qfa_host.h)
+        xdl_form = False if (fl & 0x1) else (True if (fl & 0x2) else nh > 8)
+        p2_name = ("k_grads_w" if (fl & 0x10) else "k_grads_x") if xdl_form else "k_grads"
+    dominant = p2_name if ms_p2 >= ms_p1 else "k_moments_x"
     dom_ms, dom_flops = (ms_p2, f2) if dominant == p2_name else (ms_p1, f1)
-    # the n k^2 (matrix-pipe) part of dom_flops and the bf16 products issued for it: pass 1 4 n k^2 x 6; pass 2
-    # n k^2 (stage 1, diag Sigma^-1) x 6 + 2 n k^2 (stage 3, M Z) x 3 (QFA_S3_TERMS, qfa_common.h)
+    # The contractions are ISSUED as bf16 piece products on the XDL pipe: per spectrum
+    #   pass 1                 4 n k^2 x 6
+    #   pass 2, N_h <= 16      n k^2 x 6 (stage 1, diag Sigma^-1) + 2 n k^2 x 6 (stage 3, M Z; x 3 with QFA_F_S3_FAST)
+    #   pass 2, N_h = 17..32   n k^2 x 6 + 2 n k^2 x 4 (x 3 with QFA_F_S3_FAST)
+    # `roofline` prices the issued bf16 flops of the dominant kernel against the dense bf16 MFMA peak.
     nk2 = npix * nh * nh
-    if dominant in ("k_grads_x", "k_s12_x+2*k_grads_s3"):
-        xdl_flops = (6 * 1 + 3 * 2) * nk2
-    elif dominant == "k_moments":
+    s3 = 3 if fast else (6 if nh <= 16 else 4)
+    if dominant in ("k_grads_x", "k_grads_w", "k_s12_x+2*k_grads_s3"):
+        xdl_flops = (6 * 1 + s3 * 2) * nk2
+    elif dominant == "k_moments_x":
         xdl_flops = 6 * 4 * nk2
     else:
-        xdl_flops = None          # k_grads (N_h <= 8): stage 1 on the float32 MFMA, no XDL roof to price against
-    ach = dom_flops * B / (dom_ms * 1e-3) / 1e12
-    traffic = None
+        xdl_flops = None          # k_grads (N_h <= 8): stage 1 on the float32 MFMA -- priced against the float32 roof
+    ach32 = dom_flops * B / (dom_ms * 1e-3) / 1e12
+    traffic = traffic_step = None
     tfile = os.path.join(REPO, "profiles", f"traffic_{args.config}.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             if tj.get("B") == B:
-                traffic = tj.get(dominant + "_hbm_bytes_per_launch")
+                traffic = tj.get(dominant.replace("k_moments_x", "k_moments") + "_hbm_bytes_per_launch")
+                traffic_step = sum(v for kk, v in tj.items() if kk.endswith("_hbm_bytes_per_launch"))
         except Exception:
             traffic = None
+    if xdl_flops:
+        ach = xdl_flops * B / (dom_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel_ms": dom_ms,
+                "flops_per_spectrum": xdl_flops,
+                "priced": "bf16 piece-product flops issued on the XDL pipe (six per float32 product"
+                          + (", three in stage 3: QFA_F_S3_FAST" if fast else (", four in stage 3 at N_h > 16" if nh > 16 else ""))
+                          + ") over the dense bf16 MFMA peak",
+                "alg_flops_per_spectrum": dom_flops, "achieved_alg_fp32": ach32,
+                "frac_vs_fp32_roof": ach32 / PEAK_FP32_TFLOPS}
+    else:
+        roof = {"bound": "mfma", "kernel": dominant, "achieved": ach32, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach32 / PEAK_FP32_TFLOPS, "traffic": traffic, "kernel_ms": dom_ms,
+                "flops_per_spectrum": dom_flops, "priced": "algorithmic float32 flops over the float32 MFMA / VALU peak",
+                "alg_flops_per_spectrum": dom_flops}
+    hbm_frac = rate_gpu * by / (PEAK_HBM_GBS * 1e9)
+    step_ms = dt / args.steps * 1e3
     out = {
         "metric": "spectra/sec per EM step", "value": rate, "unit": "spectra/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -339,26 +424,24 @@ def main():
                    "arithmetic": "float32 throughout; pass 1 (N_h <= 16) and pass 2 (N_h = 9..16) issue their contractions as "
                                  "bf16 XDL MFMAs over operands split into three bf16 pieces (float32-exact split, float32 "
                                  "accumulate): six piece products per float32 product (error vs float64 at or below the f32 "
-                                 "MFMA's, tools/ubench/bf16x3_numerics.hip), three over the two leading pieces in stage 3 "
-                                 "of pass 2 (<= 3 x 2^-18 per product; the F gradient's error against the float64 oracle does not "
-                                 "move, profiles/r2_accuracy.txt); k x k solve in float64"},
-        "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
-                     "kernel_ms": dom_ms, "alg_flops_per_spectrum": dom_flops,
-                     # the roof the kernel is built against: contraction flops issued six-fold on the bf16 XDL pipe
-                     "peak_xdl": PEAK_BF16_TFLOPS,
-                     "achieved_xdl": xdl_flops * B / (dom_ms * 1e-3) / 1e12 if xdl_flops else None,
-                     "frac_xdl": xdl_flops * B / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if xdl_flops else None,
-                     "xdl_flops_per_spectrum": xdl_flops,
-                     "built_against": "xdl (bf16 MFMA: six piece products per float32 product, three in stage 3 of "
-                                      "pass 2); frac = the survey's float32 roof"},
+                                 "MFMA's, tools/ubench/bf16x3_numerics.hip) in every stage"
+                                 + (" EXCEPT stage 3 of pass 2, run here with three (--flags 0x4: operands carried to ~17 bits)" if fast else "")
+                                 + ("; at N_h > 16 stage 3 of pass 2 issues four products over two pieces" if nh > 16 and not fast else "")
+                                 + "; k x k solve and scalar-gradient sums in float64", "flags": fl},
+        "roofline": roof,
         "stage_ms": {"pf_image": ms_prep, "pass1_moments": ms_p1, "solve": ms_solve, "pass2_grads": ms_p2,
                      "rest_of_step": dt / args.steps * 1e3 - float(stage.sum())},
-        "step_roofline": {"achieved_fp32_frac": rate_gpu * (f1 + f2) / (PEAK_FP32_TFLOPS * 1e12),
-                          "achieved_hbm_frac": rate_gpu * by / (PEAK_HBM_GBS * 1e9),
-                          "alg_flops_per_spectrum": f1 + f2, "alg_bytes_per_spectrum": by,
-                          "binding_roof": "fp32 (VALU + MFMA); HBM ceiling at this config is "
-                                          f"{100.0 * (PEAK_FP32_TFLOPS * 1e12 / (f1 + f2)) * by / (PEAK_HBM_GBS * 1e9):.1f}%"},
+        "step_roofline": {"achieved_hbm_frac": hbm_frac, "achieved_hbm_GBs": rate_gpu * by / 1e9,
+                          "alg_bytes_per_spectrum": by, "alg_flops_per_spectrum": f1 + f2,
+                          "achieved_fp32_frac": rate_gpu * (f1 + f2) / (PEAK_FP32_TFLOPS * 1e12),
+                          # measured HBM bytes of the step's kernels (profiles/traffic_<config>.json: rocprofv3 PMC) over the
+                          # algorithmic bytes: > 1 = re-reads (both passes read the spectra: the k x k solve sits between)
+                          "measured_hbm_bytes_per_step": traffic_step,
+                          "traffic_ratio": traffic_step / (by * B) if traffic_step else None,
+                          "measured_hbm_frac": traffic_step / (step_ms * 1e-3) / (PEAK_HBM_GBS * 1e9) if traffic_step else None,
+                          "binding_roof": "XDL issue / latency (see roofline.frac) and HBM together: the step moves "
+                                          f"{hbm_frac * 100:.1f}% of HBM peak in algorithmic bytes"
+                                          + (f" and {traffic_step / (step_ms * 1e-3) / (PEAK_HBM_GBS * 1e9) * 100:.0f}% in measured bytes" if traffic_step else "")},
         "loss": float(losses[-1].item()),
     }
     if sustained is not None:

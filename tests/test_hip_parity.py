@@ -22,7 +22,10 @@ pytestmark = pytest.mark.gpu
 
 KEYS = ("F", "Psi", "omega", "tau0", "c0", "beta")
 TOL_NLL = 5e-6
-TOL_G = {"F": 1e-4, "Psi": 2e-5, "omega": 2e-5, "tau0": 2e-4, "c0": 2e-4, "beta": 2e-4}
+# scalar gradients: sums of terms that cancel 50-900x on these batches (tools/scalar_probe.py).  Achieved after round 3's
+# fix of the log2(scale) constant: <= 5.5e-5 on the worst case (G4 beta, 908x cancellation: 6e-8 of sum|terms|; the
+# reference's own float32 result is at 1.8e-5 there), <= 1.2e-5 elsewhere.
+TOL_G = {"F": 1e-4, "Psi": 2e-5, "omega": 2e-5, "tau0": 1e-4, "c0": 1e-4, "beta": 1e-4}
 
 
 @pytest.fixture(scope="module")
