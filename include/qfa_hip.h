@@ -77,6 +77,9 @@ typedef struct {
 #define QFA_F_S3_FAST      0x4u  /* stage 3 of pass 2 with three bf16 piece products (operands carried to ~17
                                     bits, <= 1.1e-5 per product) instead of the float32-grade six              */
 #define QFA_F_PREDICT_F32  0x8u  /* posterior writer in its float32-MFMA form (k_predict_out)                   */
+#define QFA_F_SYNC         0x20u /* debugging: synchronise `stream` before returning, so that an asynchronous fault of
+                                    THIS call's kernels is returned by THIS call (positive hipError_t) instead of
+                                    surfacing at the caller's next synchronisation without context               */
 #define QFA_F_PASS2_WFORM  0x10u /* N_h <= 16: the one-wave-per-SIMD form of the all-XDL pass 2 (k_grads_w: stage 3
                                     re-associated as a K = spectrum GEMM; same results, slower -- DESIGN.md)    */
 

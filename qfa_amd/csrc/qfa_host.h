@@ -192,7 +192,12 @@ inline bool pass2_use_xdl(int KP, unsigned flags) {
     return KP == 16;
 }
 
-inline int hip_status() {
+// launch errors of the calls just made; with QFA_F_SYNC also the asynchronous ones (the stream is drained first)
+inline int hip_status(hipStream_t st = nullptr, unsigned flags = 0) {
+    if (flags & QFA_F_SYNC) {
+        hipError_t s = hipStreamSynchronize(st);
+        if (s != hipSuccess) { (void)hipGetLastError(); return (int)s; }
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -309,7 +314,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
                           ws + L.oZS, accum, slab, slabS, (int)D.stride, sc64, st);
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
-        return hip_status();
+        return hip_status(st, flags);
     }
     if constexpr (KP == 32 && QFA_P2_S12 != 0) {
         // stages 1 and 2 for every (spectrum, pixel) on the XDL pipe, beta / gamma through HBM, then stage 3 per 16 columns
@@ -328,7 +333,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         }
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
-        return hip_status();
+        return hip_status(st, flags);
     }
     if constexpr (KP == 32) {
         // columns 0..15 by k_grads, which also stores beta and gamma; columns 16..31 by the stage-3-only kernel
@@ -350,7 +355,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     }
     if (slab) launch_reduce_slab(slab, D, B, L.wp2.items() * 4, accum, st);
     mark(4);
-    return hip_status();
+    return hip_status(st, flags);
 }
 
 template <int KP>
@@ -388,7 +393,7 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     else if (!writer_xdl)
         k_predict_out<KP><<<(B + 63) / 64, 256, 0, st>>>(mu, B, Npix, L.ntiles, PFT, SOL, cont, unc);
     mark(3);
-    return hip_status();
+    return hip_status(st, flags);
 }
 
 

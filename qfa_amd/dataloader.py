@@ -202,12 +202,15 @@ class DeviceDataloader(object):
     def sample(self):
         """a random batch with replacement (reference QFA/dataloader.py:140-152; the reference's version cannot run:
         it asks for ``torch.tensor32``, quirk Q9)"""
+        if self.local_size == 0:                            # an empty data-parallel shard
+            return self._build(np.zeros((0,), dtype=np.int64))
         return self._build(np.random.randint(0, self.local_size, size=(self.batch_size,)))
 
     def set_device(self, device):
         """reference QFA/dataloader.py:175-179.  The spectra already live on the device given to the constructor;
         any other device is refused (there is no host path)."""
-        if torch.device(device) != self.device and torch.device(device).index is not None:
+        d = torch.device(device)
+        if d.type != self.device.type or (d.index is not None and d.index != self.device.index):
             raise _lib.QFAHipError(f"DeviceDataloader is resident on {self.device}; cannot serve {device}")
 
     def set_tau(self, tau):
@@ -226,7 +229,10 @@ class DeviceDataloader(object):
     def get_rows(self, lo, hi):
         """raw flux, error, zabs, mask, paths of the resident rows [lo, hi) in ONE launch -- what ``__getitem__``
         returns per spectrum, for a whole slice (the batched predict writer)."""
-        rows = np.arange(int(lo), min(int(hi), self.local_size))
+        rows = np.arange(max(int(lo), 0), min(int(hi), self.local_size))
+        if len(rows) == 0:                                  # past the end, or an empty data-parallel shard
+            e = lambda n, dt=f32: torch.empty((0, n), dtype=dt, device=self.device)
+            return e(self.Npix), e(self.Npix), e(self.Nb), e(self.Npix, torch.bool), self.pathlist[:0]
         _, err, zabs, mask = self._build(rows)
         return self.flux[rows[0]:rows[-1] + 1], err, zabs, mask, self.pathlist[rows]
 

@@ -95,6 +95,32 @@ def all_reduce_(t, group=None):
     return all_reduce_accum(t, group)
 
 
+def agree_on_layout(tensors, group=None, what="replicated tensors"):
+    """Raise (on every rank) unless all ranks are about to issue the SAME collectives: same number of tensors, same
+    element counts.  One MAX and one MIN all-reduce of a fixed-size signature -- the list itself may differ from rank to
+    rank (a rank that loaded a file carrying ``mu`` next to one that did not), and a per-tensor broadcast over lists of
+    different length deadlocks instead of failing."""
+    import torch
+    import torch.distributed as dist
+    NSLOT = 32
+    if len(tensors) > NSLOT:
+        raise ValueError("agree_on_layout: too many tensors")
+    sig = torch.full((NSLOT + 1,), -1.0, dtype=torch.float64)
+    sig[0] = len(tensors)
+    for i, t in enumerate(tensors):
+        sig[1 + i] = float(t.numel())
+    dev = tensors[0].device if tensors else torch.device("cpu")
+    if dist.get_backend(group) != "gloo" and dev.type != "cpu":
+        sig = sig.to(dev)
+    hi, lo = sig.clone(), sig.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    if not bool((hi == lo).all()):
+        raise RuntimeError(f"data-parallel ranks disagree on the {what}: this rank has {len(tensors)} tensors of sizes "
+                           f"{[int(t.numel()) for t in tensors]} (e.g. mu present on some ranks only); load the same "
+                           "checkpoint on every rank before enable_data_parallel / sync_replicas")
+
+
 def replicas_in_sync(tensors, group=None):
     """True when every rank holds bit-identical copies of ``tensors`` (a list).  Each rank reduces its copy to
     four float64 moments; max - min of those over the ranks must be exactly zero."""

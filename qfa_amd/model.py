@@ -227,9 +227,11 @@ class QFA(object):
 
     def sync_replicas(self, optimizer=None, src=0):
         """Broadcast parameters, mu and (optionally) the Adam moments and epoch index from rank ``src``."""
-        from .distributed import broadcast_
+        from .distributed import agree_on_layout, broadcast_
         self._params_struct()                           # contiguous float32 tensors on the device
-        for t in self._replica_tensors(optimizer):
+        ts = self._replica_tensors(optimizer)
+        agree_on_layout(ts, self._dp_group)             # every rank issues the same broadcasts, or every rank raises
+        for t in ts:
             if t.numel():
                 broadcast_(t, src, self._dp_group)
         if optimizer is not None:
@@ -240,7 +242,8 @@ class QFA(object):
 
     def check_replicas(self, optimizer=None):
         """Raise unless every rank holds bit-identical parameters (and Adam state): a collective, call it on all ranks."""
-        from .distributed import replicas_in_sync
+        from .distributed import agree_on_layout, replicas_in_sync
+        agree_on_layout(self._replica_tensors(optimizer), self._dp_group)
         ts = [t for t in self._replica_tensors(optimizer) if t.numel()]
         if not replicas_in_sync(ts, self._dp_group):
             raise _lib.QFAHipError("data-parallel replicas differ (parameters / mu / Adam state): call "
@@ -441,6 +444,21 @@ class QFA(object):
         # the captured step graph is a single-process tool (launch-bound small batches); under data parallelism the
         # per-rank batch is large (c4: 125 000 spectra) and the collective stays an eager RCCL call
         sg = self.step_graph(optimizer, dataloader.batch_size) if (use_graph and not self._dp) else None
+        # Side effects under data parallelism: the replicas are identical, so ONE rank prints, logs and writes the
+        # checkpoints (concurrent np.savez of the same path from every rank can interleave into a corrupt zip); the
+        # others wait at a barrier so that nobody reads a half-written file.
+        lead = True
+        if self._dp:
+            import torch.distributed as dist
+            lead = dist.get_rank(self._dp_group) == 0
+
+        def save(name):
+            if lead:
+                self.save_to_npz(output_dir, name)
+            if self._dp:
+                import torch.distributed as dist
+                dist.barrier(group=self._dp_group)
+
         for epoch in range(n_epochs):
             dataloader.rewind()
             total = torch.zeros((), dtype=torch.float64, device=self.device)
@@ -456,18 +474,18 @@ class QFA(object):
             total_loss = total.item() / Niter          # one host sync per epoch; ZeroDivisionError if Niter == 0
             msg = "epoch: {:03d}/{:03d}  ;  loss:  {:.2f}  ;  time:  {:.2f} s ".format(
                 epoch, n_epochs, total_loss, time.time() - t0)
-            if not quiet:
+            if not quiet and lead:
                 print(msg)
-            if logger is not None:
+            if logger is not None and lead:
                 logger.info(msg)
             if total_loss < 0.:
                 self.smooth()
-                self.save_to_npz(output_dir, "model_parameters_epoch_%02i.npz" % (epoch + 1))
+                save("model_parameters_epoch_%02i.npz" % (epoch + 1))
                 break
             if (epoch + 1) % smooth_interval == 0:
                 self.smooth()
             if (epoch + 1) % save_interval == 0:
-                self.save_to_npz(output_dir, "model_parameters_epoch_%02i.npz" % (epoch + 1))
+                save("model_parameters_epoch_%02i.npz" % (epoch + 1))
 
     fit = train
 
@@ -477,7 +495,10 @@ class QFA(object):
         os.makedirs(output_dir, exist_ok=True)
         arrs = {k: getattr(self, k).detach().cpu().numpy() for k in PARAM_KEYS}
         arrs["mu"] = self.mu.detach().cpu().numpy()
-        np.savez(os.path.join(output_dir, file_name), **arrs)
+        final = os.path.join(output_dir, file_name)
+        tmp = final + f".tmp{os.getpid()}.npz"          # complete file under a private name, then an atomic rename
+        np.savez(tmp, **arrs)
+        os.replace(tmp, final)
 
     def load_from_npz(self, path: str, reference_c0_quirk: bool = True):
         """reference QFA/model.py:282-295.  With ``reference_c0_quirk`` (default) c0 is read from

@@ -284,7 +284,7 @@ def test_dp_training_loop_world2_gloo_cpu():
         assert np.allclose(params[k], ref[k], rtol=1e-9, atol=1e-12), k
 
 
-def _worker_train_gpu(rank, world, port, q, backend):
+def _worker_train_gpu(rank, world, port, q, backend, outdir=None):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -306,8 +306,18 @@ def _worker_train_gpu(rank, world, port, q, backend):
     dl = DeviceDataloader(b["flux"], b["error"], b["zqso"], wav, 10, dev, rank=rank, world=world, seed=5,
                           shuffle=world > 1)
     import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        m.train(opt, dl, 2, td, quiet=True)
+    if outdir is not None:
+        # ONE output directory for every rank, a checkpoint after every epoch: only the lead rank may write
+        # (concurrent np.savez of one path corrupts the zip); every rank then reads the files back
+        m.train(opt, dl, 2, outdir, save_interval=1, quiet=True)
+        ck = os.path.join(outdir, "checkpoints")
+        names = sorted(os.listdir(ck))
+        assert names == ["model_parameters_epoch_01.npz", "model_parameters_epoch_02.npz"], names
+        f = np.load(os.path.join(ck, names[-1]))
+        assert np.array_equal(f["F"], m.F.cpu().numpy()) and np.array_equal(f["Psi"], m.Psi.cpu().numpy())
+    else:
+        with tempfile.TemporaryDirectory() as td:
+            m.train(opt, dl, 2, td, quiet=True)
     F0 = m.F.cpu().numpy().copy()
     # a replica that drifts is caught by the check train() runs before its first step
     caught = False
@@ -327,11 +337,11 @@ def _worker_train_gpu(rank, world, port, q, backend):
     dist.destroy_process_group()
 
 
-def _run_train_gpu(world, backend):
+def _run_train_gpu(world, backend, outdir=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 33500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker_train_gpu, args=(r, world, port, q, backend)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_train_gpu, args=(r, world, port, q, backend, outdir)) for r in range(world)]
     [pr.start() for pr in procs]
     gathered = _collect(procs, q, 300)
     [pr.join(120) for pr in procs]
@@ -347,7 +357,9 @@ def test_dp_train_two_ranks_sharded_loader_matches_single_process():
     from qfa_amd import QFA, Adam, step_scheduler
     from qfa_amd.dataloader import DeviceDataloader
     from qfa_amd.distributed import ShardPlan
-    g = _run_train_gpu(2, "gloo")
+    import tempfile
+    with tempfile.TemporaryDirectory() as shared:            # both ranks train into the SAME output directory
+        g = _run_train_gpu(2, "gloo", shared)
     (p0, mu0, n0, c0), (p1, mu1, n1, c1) = g
     assert (n0, n1) == (6, 5) and c0 and c1
     for k in KEYS:
@@ -385,3 +397,41 @@ def test_rccl_path_world1_rehearsal():
     g = _run_train_gpu(1, "nccl")
     (p0, mu0, n0, c0), = g
     assert n0 == 11 and all(np.isfinite(p0[k]).all() for k in KEYS)
+
+
+def _worker_layout(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qfa_amd.distributed import agree_on_layout
+    same = [torch.zeros(5), torch.zeros(0), torch.zeros(3)]
+    agree_on_layout(same)                                            # identical lists: passes on every rank
+    mine = same + ([torch.zeros(7)] if rank == 1 else [])           # rank 1 also holds a "mu"
+    try:
+        agree_on_layout(mine)
+        raised = False
+    except RuntimeError:
+        raised = True
+    sizes = [torch.zeros(4 + rank)]                                  # same count, different element counts
+    try:
+        agree_on_layout(sizes)
+        raised2 = False
+    except RuntimeError:
+        raised2 = True
+    dist.barrier()                                                   # nobody is stuck in a collective
+    q.put((rank, raised, raised2))
+    dist.destroy_process_group()
+
+
+def test_replica_tensor_lists_that_differ_raise_on_every_rank_instead_of_deadlocking():
+    """sync_replicas / check_replicas agree on the tensor list first: a rank that holds mu next to one that does
+    not, or tensors of different sizes, raises on EVERY rank; a per-tensor broadcast would hang instead."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_layout, args=(r, 2, port, q)) for r in range(2)]
+    [pr.start() for pr in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [pr.join(60) for pr in procs]
+    assert all(pr.exitcode == 0 for pr in procs)
+    assert res == [(0, True, True), (1, True, True)]

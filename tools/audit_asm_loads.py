@@ -1,4 +1,4 @@
-"""Audit of the compiled kernels (qfa_amd/csrc: `make asm asmgx asm32` -> /tmp/qfa_*.s): register prefetches are issued by
+"""Audit of the compiled kernels (qfa_amd/csrc/build/*-gfx950.s, written by the compile that produced the shipped objects: -save-temps): register prefetches are issued by
 asm statements that hipcc does not track, so nothing but program order protects their destination registers.  For every
 such load (between ;;#ASMSTART / ;;#ASMEND) of every kernel check that no instruction reads or writes its destination
 registers before the next `s_waitcnt vmcnt(...)`; in k_grads_x and k_predict_x also require zero scratch (spills of
@@ -7,7 +7,7 @@ middle of the counted queue).  The scan is linear in program order (the code beh
 with nothing pending; a counted wait is taken to retire every asm load before it): a build-time tripwire beside the
 dynamic check, tests/test_tracked_loads.py.  Exit code 1 on a violation.
 
-    tools/audit_asm_loads.py [file.s ...]          (default /tmp/qfa_gx.s)"""
+    tools/audit_asm_loads.py [file.s ...]          (run by `make`: the library does not link unless it passes)"""
 import re, sys
 paths = sys.argv[1:] or ["/tmp/qfa_gx.s"]
 src = "\n".join(open(p).read() for p in paths)

@@ -8,4 +8,4 @@ if [ ! -f /tmp/qfa_k32_variant.o ] || [ $R/qfa_amd/csrc/qfa_step_kernels.h -nt /
   /opt/rocm/bin/hipcc $B -c $R/qfa_amd/csrc/qfa_k32.hip -o /tmp/qfa_k32_variant.o || exit 1
 fi
 # the XDL pass 2 / writer translation unit is taken from the tree's last build (tools/build_gx_variant.sh varies that one)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $out.capi.o /tmp/qfa_k32_variant.o $R/qfa_amd/csrc/qfa_gx.o -o $out
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $out.capi.o /tmp/qfa_k32_variant.o $R/qfa_amd/csrc/build/qfa_gx.o -o $out
