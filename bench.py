@@ -287,8 +287,11 @@ def main():
     for i, s0 in enumerate(range(0, B, slab)):
         n = min(slab, B - s0)
         parts.append(synthetic.make_batch_torch(params, mu, wav, nb, n, 20220700 + cfg_index + 1000 * rank + 17 * i,
-                                                dev, masks=masks))
+                                                dev, masks=masks, return_zq=True))
     batch = tuple(torch.cat([p[j] for p in parts]) for j in range(4))
+    # the factored-z input form of the same batch (include/qfa_hip.h: 1 + zabs = zq1 x pix_ratio, QFA/dataloader.py:102)
+    zfac = ((1.0 + torch.cat([p[4] for p in parts])).contiguous(),
+            torch.tensor((wav[:nb] / synthetic.LYA).astype(np.float32), device=dev))
     del parts
     torch.cuda.empty_cache()
 
@@ -359,6 +362,35 @@ def main():
                      "after_seconds_of_load": time.perf_counter() - t_s,
                      "stage_ms": {"pf_image": float(sst[0]), "pass1_moments": float(sst[1]), "solve": float(sst[2]),
                                   "pass2_grads": float(sst[3])}}
+    # ---- the same step fed the factored-z input form (what DeviceDataloader batches carry): zabs is not read
+    fz = None
+    if nb > 0:
+        for _ in range(2):
+            model.step(opt, batch[0], batch[1], None, batch[3], zfac=zfac)
+        fev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+        for es in fev:
+            for e in es:
+                e.record()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            model.step(opt, batch[0], batch[1], None, batch[3], events=fev[i], zfac=zfac)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([dtf], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtf = float(t.item())
+        fst = np.array([[es[j].elapsed_time(es[j + 1]) for j in range(4)] for es in fev]).mean(axis=0)
+        fz = {"ms_per_step": dtf / args.steps * 1e3, "value": world * B * args.steps / dtf,
+              "alg_bytes_per_spectrum": npix * 9 + 8,
+              "stage_ms": {"pf_image": float(fst[0]), "pass1_moments": float(fst[1]), "solve": float(fst[2]),
+                           "pass2_grads": float(fst[3])},
+              "note": "qfa_batch_t::zq1 / pix_ratio instead of zabs (B, Nb): 4 Nb bytes per spectrum and pass less, two "
+                      "transcendentals per blue element instead of five; same results to float32 rounding "
+                      "(tests/test_hip_parity.py::test_factored_z_input_form_matches_zabs_form_and_oracle)"}
     f1, f2 = alg_flops(npix, nh)
     by = alg_bytes(npix, nb)
     rate = world * B * args.steps / dt
@@ -444,6 +476,8 @@ def main():
                                           + (f" and {traffic_step / (step_ms * 1e-3) / (PEAK_HBM_GBS * 1e9) * 100:.0f}% in measured bytes" if traffic_step else "")},
         "loss": float(losses[-1].item()),
     }
+    if fz is not None:
+        out["factored_z"] = fz
     if sustained is not None:
         out["sustained_ms_per_step"] = sustained["ms_per_step"]
         out["sustained"] = sustained

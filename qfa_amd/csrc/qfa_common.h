@@ -39,9 +39,10 @@ struct Cfg {
     static constexpr int NCPL = FW + PW + 4;
     static constexpr int TILE_PF = 16 * NCPL;           // floats per 16-pixel tile (contiguous)
     // PFT image (pass 2), tile-major: tile t = [row c][16 px]; rows [0,KP) = F^T, [KP,KP+KK2) =
-    // pair products, then Psi, omega, zero padding to a multiple of 4 rows.
+    // pair products, then Psi, omega, the per-pixel factors ti, pwi, l2i of the factored-z input form (ZP of this
+    // header; zeros otherwise), zero padding to a multiple of 4 rows.
     static constexpr int PFT_PSI = KP + KK2;
-    static constexpr int NR = (KP + KK2 + 2 + 3) / 4 * 4;
+    static constexpr int NR = (KP + KK2 + 5 + 3) / 4 * 4;    // (+ ti, pwi, l2i of the factored-z form behind Psi, omega)
     // N_h > 8: stage 3 of k_grads runs on the XDL pipe; its A operand (F of the tile as three bf16 pieces in the lane
     // order of the MFMA: KP = 16 v_mfma_f32_16x16x16_bf16 [piece][g][px][a = 4g + j], 3 x 512 bytes; KP = 32
     // v_mfma_f32_16x16x32_bf16 [piece][g][px][a = 8g + j], 3 x 1 KiB) is appended to the tile, and both parts are
@@ -126,6 +127,7 @@ __device__ __forceinline__ void scal64_commit(Scal64 *q, double a, double b, dou
 struct DevConsts {
     float tau0, c0, beta;
     float t_amp, t_lscale, t_expo, t_off;   // tau(z) = t_amp * 2^(t_expo (log2(1+z) + t_lscale)) + t_off
+    float offp, k1, omc0;                   // -log2(e) t_off,  -log2(e) tau0,  1 - c0   (factored-z form)
 };
 
 #ifdef QFA_PRECISE_MATH   // accuracy experiments only: libm-grade exp2/log2 and IEEE division
@@ -154,6 +156,49 @@ __device__ __forceinline__ BlueTerms blue_terms(float z, const DevConsts &k) {
     float re = 1.0f - k.c0 - fast_exp(-k.tau0 * t.pw);                            // utils.py:91
     t.zd = re * re;
     return t;
+}
+
+// ---- factored-z input form (include/qfa_hip.h, qfa_batch_t::zq1 / pix_ratio): 1 + z = zq1[s] pix_ratio[i], so
+//   log2(1+z) = l2s + l2i,   (1+z)^beta = pws pwi,   A = exp(-tau(z)) = 2^(ts ti + offp)
+// with per-spectrum factors ZS[s] = {ts, pws, l2s, 0} and per-pixel factors ZP[i] = {ti, pwi, l2i, 0}, both computed once
+// per call in float64 (k_zfac_spec / k_zfac_pix below) and rounded once: two hardware transcendentals per blue element
+// (2^x for A and for the omega term) instead of five, and none of them a logarithm (v_log_f32 is biased by -0.5 ulp,
+// tools/ubench/trans_bias.hip: the zabs form carries a coherent +5e-8 bias in A that the scalar gradients see).
+struct ZFac {
+    float ts, pw, l2;
+};
+__device__ __forceinline__ ZFac zfac_load(const float4 *__restrict__ ZS, int s, bool valid) {
+    ZFac z{0.f, 0.f, 0.f};
+    if (valid) {
+        const float4 q = ZS[s];
+        z.ts = q.x; z.pw = q.y; z.l2 = q.z;
+    }
+    return z;
+}
+__device__ __forceinline__ BlueTerms blue_terms_zf(const ZFac &zs, float ti, float pwi, float l2i, const DevConsts &k) {
+    BlueTerms t;
+    t.l2 = zs.l2 + l2i;
+    t.pw = zs.pw * pwi;                                                           // (1+z)^beta, utils.py:73
+    t.A = fast_exp2(fmaf(zs.ts, ti, k.offp));                                     // QFA/model.py:125
+    const float re = k.omc0 - fast_exp2(k.k1 * t.pw);                             // utils.py:91
+    t.zd = re * re;
+    return t;
+}
+// ZS[s] from zq1[s] = 1 + z_qso;  ZP[i] from pix_ratio[i] = wav_i / 1215.67 (blue pixels)
+static __global__ void k_zfac_spec(const float *__restrict__ zq1, qfa_params_t p, qfa_tau_t tau, int B,
+                                   float4 *__restrict__ ZS) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    const double l2s = log2((double)zq1[s]);
+    const double ts = -1.4426950408889634 * (double)tau.amp * exp2((double)tau.expo * (l2s + log2((double)tau.scale)));
+    ZS[s] = float4{(float)ts, (float)exp2((double)*p.beta * l2s), (float)l2s, 0.f};
+}
+static __global__ void k_zfac_pix(const float *__restrict__ pix_ratio, qfa_params_t p, qfa_tau_t tau, int Nb,
+                                  float4 *__restrict__ ZP) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nb) return;
+    const double l2i = log2((double)pix_ratio[i]);
+    ZP[i] = float4{(float)exp2((double)tau.expo * l2i), (float)exp2((double)*p.beta * l2i), (float)l2i, 0.f};
 }
 
 #ifndef QFA_ABL
@@ -322,5 +367,8 @@ __device__ __forceinline__ DevConsts load_consts(const qfa_params_t &p, const qf
     k.t_amp = (float)((double)tau.amp * exp2((double)tau.expo * (l2s - (double)k.t_lscale)));
     k.t_expo = tau.expo;
     k.t_off = tau.offset;
+    k.offp = -QFA_LOG2E * k.t_off;
+    k.k1 = -QFA_LOG2E * k.tau0;
+    k.omc0 = 1.0f - k.c0;
     return k;
 }

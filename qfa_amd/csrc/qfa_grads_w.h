@@ -62,11 +62,10 @@ static_assert(GWT<16>::AUX_PAR + 5 * 64 <= GWT<16>::AUX_B, "aux block");
 // k_prep_pgw : F, Psi, omega (+ the per-pixel factors of the factored-z form) -> the pass-2 image, one block per 32-pixel tile
 //   half h:  [K-step ks][piece][lane (g, lo)][8 k] bf16 : B[k = 32 ks + 8 g + j][px = 2 lo + h]   (as k_prep_pgx)
 //            aux: F[lo][a] float32 (row stride FROW), Psi[lo], omega[lo], ti[lo], pwi[lo], l2i[lo] of the pixels 2 lo + h
-// pix_ratio != NULL (factored form, include/qfa_hip.h): 1 + z = zq1[s] pix_ratio[i]; with l2i = log2(pix_ratio[i])
-//   ti = 2^(expo l2i),  pwi = 2^(beta l2i)   (float64 here, rounded once)
+// ZP != NULL (factored-z form): the per-pixel factors {ti, pwi, l2i} of qfa_common.h
 // ------------------------------------------------------------------------------------------------
 template <int KP>
-__global__ __launch_bounds__(256) void k_prep_pgw(qfa_params_t p, qfa_tau_t tau, const float *__restrict__ pix_ratio,
+__global__ __launch_bounds__(256) void k_prep_pgw(qfa_params_t p, const float4 *__restrict__ ZP,
                                                   int Npix, int Nb, int Nh, unsigned char *__restrict__ PGW) {
     using GW = GWT<KP>;
     const float *__restrict__ F = p.F;
@@ -106,7 +105,6 @@ __global__ __launch_bounds__(256) void k_prep_pgw(qfa_params_t p, qfa_tau_t tau,
         *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
         *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
     }
-    const float beta = *p.beta;
     for (int i = threadIdx.x; i < 2 * (GW::AUX_B / 4); i += 256) {
         const int h = i / (GW::AUX_B / 4), j = i % (GW::AUX_B / 4);
         float *aux = reinterpret_cast<float *>(tile + h * GW::HALF_B + GW::S1_HALF);
@@ -118,25 +116,13 @@ __global__ __launch_bounds__(256) void k_prep_pgw(qfa_params_t p, qfa_tau_t tau,
             const int q = (j - 16 * GW::FROW) >> 4, lo = (j - 16 * GW::FROW) & 15, px = p0 + 2 * lo + h;
             if (q == 0) v = px < Npix ? p.Psi[px] : 0.f;
             else if (q == 1) v = px < Nb ? p.omega[px] : 0.f;
-            else if (pix_ratio && px < Nb) {
-                const double l2i = log2((double)pix_ratio[px]);
-                v = q == 2 ? (float)exp2((double)tau.expo * l2i) : (q == 3 ? (float)exp2((double)beta * l2i) : (float)l2i);
+            else if (ZP && px < Nb) {
+                const float4 zq = ZP[px];
+                v = q == 2 ? zq.x : (q == 3 ? zq.y : zq.z);
             }
         }
         aux[j] = v;
     }
-}
-
-// per-spectrum factors of the factored-z form: ZS[s] = {ts, pws, l2s, 0}: with l2s = log2(zq1[s]) (float64, rounded once)
-//   ts = -log2(e) amp 2^(expo (l2s + log2 scale)),  pws = 2^(beta l2s)
-// so that  A = exp(-tau) = 2^(ts ti - log2(e) off),  (1 + z)^beta = pws pwi,  log2(1 + z) = l2s + l2i.
-static __global__ void k_zfac_spec(const float *__restrict__ zq1, qfa_params_t p, qfa_tau_t tau, int B,
-                                   float4 *__restrict__ ZS) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= B) return;
-    const double l2s = log2((double)zq1[s]);
-    const double ts = -1.4426950408889634 * (double)tau.amp * exp2((double)tau.expo * (l2s + log2((double)tau.scale)));
-    ZS[s] = float4{(float)ts, (float)exp2((double)*p.beta * l2s), (float)l2s, 0.f};
 }
 
 // dynamic operand of stage 3: four float32 values (the lane's spectra 4 g + r) as the three K = 32 operands
@@ -189,7 +175,6 @@ __global__ __launch_bounds__(256, 1) void k_grads_w(qfa_params_t p, qfa_batch_t 
     const int n = t1 - t0;
     const int nbt = (Nb + 31) >> 5;                          // tiles that contain blue pixels
     const DevConsts k = load_consts(p, tau);
-    const float k_offp = -QFA_LOG2E * k.t_off, k_k1 = -k.tau0 * QFA_LOG2E, k_omc0 = 1.0f - k.c0;
 
     const bool det = slab != nullptr;
     float *accF = det ? slab + (size_t)blk * (size_t)slab_stride : accum;
@@ -505,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void k_grads_w(qfa_params_t p, qfa_batch_t 
                 if (ZF) {
                     l2 = zs_l2[r] + l2i;
                     pw = zs_pw[r] * pwi;
-                    Ab = fast_exp2(fmaf(zs_ts[r], ti, k_offp));                                   // QFA/model.py:125
+                    Ab = fast_exp2(fmaf(zs_ts[r], ti, k.offp));                                   // QFA/model.py:125
                 } else {
                     l2 = fast_log2(1.0f + cur.z[r][h]);
                     pw = fast_exp2(k.beta * l2);
@@ -513,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void k_grads_w(qfa_params_t p, qfa_batch_t 
                     Ab = fast_exp2(-tauv * QFA_LOG2E);
                 }
                 if (HASA) Ab = abase[(unsigned)min(4 * g + r, last_row) * (unsigned)Nb + (unsigned)min(px, Nb - 1)];
-                const float re = k_omc0 - fast_exp2(k_k1 * pw);                                   // QFA/utils.py:91
+                const float re = k.omc0 - fast_exp2(k.k1 * pw);                                   // QFA/utils.py:91
                 const float Av = blue ? Ab : 1.f;
                 const float zd = blue ? re * re : 0.f;
                 const float A2 = Av * Av;

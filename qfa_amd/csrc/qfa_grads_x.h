@@ -74,7 +74,8 @@ struct GXT {                                             // KP = 16 (N_h = 9..16
     static constexpr int L_PSUM = L_PART + 2 * NG * PARTF * 4;       // [2][NG][4 sums][32 px] float (summed over the wave)
     static constexpr int L_SCAL = L_PSUM + 2 * NG * 512;             // [NG waves][3 sums][64 lanes] double (role A)
     static constexpr int L_STG = L_SCAL + NG * 3 * 64 * 8;           // [NG waves][2 tile parity][STG_B]
-    static constexpr int L_TOTAL = L_STG + NG * 2 * STG_B;
+    static constexpr int L_ZS = L_STG + NG * 2 * STG_B;              // [NG waves][16 spectra] float4: factored-z per-spectrum factors
+    static constexpr int L_TOTAL = L_ZS + NG * 256;
 };
 static_assert(GXT<16>::L_TOTAL <= 160 * 1024 && GXT<8>::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
 __device__ __forceinline__ f32x16 xdl32(const u32x4 &a, const u32x4 &b, f32x16 c) {     // 32x32x16
@@ -113,8 +114,8 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 &h, u32x4 &m, 
 // ------------------------------------------------------------------------------------------------
 template <int KP>
 __global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, const float *__restrict__ Psi,
-                                                  const float *__restrict__ omega, int Npix, int Nb, int Nh,
-                                                  unsigned char *__restrict__ PGX) {
+                                                  const float *__restrict__ omega, const float4 *__restrict__ ZP,
+                                                  int Npix, int Nb, int Nh, unsigned char *__restrict__ PGX) {
     using GX = GXT<KP>;
     unsigned char *tile = PGX + (size_t)blockIdx.x * GX::TILE_B;
     const int p0 = 32 * blockIdx.x;
@@ -160,6 +161,10 @@ __global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, c
         float v = 0.f;
         if (j < 16) v = px < Npix ? Psi[px] : 0.f;
         else if (j < 32) v = px < Nb ? omega[px] : 0.f;
+        else if (j < 80 && ZP && px < Nb) {                 // factored-z form: ti | pwi | l2i of the half's pixels
+            const float4 q = ZP[px];
+            v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
+        }
         po[j] = v;
     }
     if (threadIdx.x < 64) {
@@ -201,11 +206,12 @@ __device__ unsigned long long qfa_gx_stamps[2 * 32];
 #else
 #define GXS(i) {}
 #endif
-template <int KP, bool HASA, int TERMS>
+template <int KP, bool HASA, int TERMS, bool ZF>
 __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix, int Nb,
                                                     int Nh, int ntiles, WorkPlan wp,
                                                     const unsigned char *__restrict__ PGX,
-                                                    const float *__restrict__ SOL, float *__restrict__ accum,
+                                                    const float *__restrict__ SOL, const float4 *__restrict__ ZS,
+                                                    float *__restrict__ accum,
                                                     float *__restrict__ slab, double *__restrict__ slabS,
                                                     int slab_stride, Scal64 *__restrict__ sc64) {
     using C = Cfg<KP>;
@@ -299,8 +305,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         const float *dbase = uniform_ptr(bt.delta + (size_t)(active ? s0 : 0) * Npix);
         const float *ebase = uniform_ptr(bt.error + (size_t)(active ? s0 : 0) * Npix);
         const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)(active ? s0 : 0) * Npix);
-        const float *zbase = uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
+        const float *zbase = ZF ? dbase : uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
         const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
+        // factored-z form: the per-spectrum factors of the wave's 16 spectra in LDS (this role has no registers to spare)
+        float4 *zsl = reinterpret_cast<float4 *>(lds + GX::L_ZS + w * 256);
+        if (ZF && lane < 16) zsl[lane] = (active && s0 + lane < B) ? ZS[s0 + lane] : float4{0.f, 0.f, 0.f, 0.f};
         // scalar-gradient sums: float32 inside a tile, float64 across tiles -- the float64 running sums live in LDS
         // (three doubles per lane), not in six registers
         double *scal = reinterpret_cast<double *>(lds + GX::L_SCAL) + (size_t)w * 3 * 64 + lane;
@@ -322,8 +331,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         auto stage_tile = [&](int tg, int par) -> int {
             if (QFA_GX_ABL & 1) return 8;
             if (QFA_GX_ABL & 8) tg = t0;
-            const bool zblue = tg < nbt;                                                      // wave-uniform
-            const bool fastp = 32 * tg + 31 < Npix, fastz = !zblue || 32 * tg + 31 < Nb;
+            const bool zblue = !ZF && tg < nbt;                                               // wave-uniform
+            const bool fastp = 32 * tg + 31 < Npix, fastz = ZF || !zblue || 32 * tg + 31 < Nb;
             const float *zb = (zblue && !(QFA_GX_ABL & 16)) ? zbase : dbase;
             const int zlen = (zblue && !(QFA_GX_ABL & 16)) ? Nb : Npix;
             const unsigned dst = wave_uniform(lds_addr(stg + par * GX::STG_B));
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     const unsigned o = row * (unsigned)Npix + (unsigned)min(px, Npix - 1);
                     sf[0 * (GX::STG_ARR / 4) + q * 32 + pxl] = dbase[o];
                     sf[1 * (GX::STG_ARR / 4) + q * 32 + pxl] = ebase[o];
-                    sf[2 * (GX::STG_ARR / 4) + q * 32 + pxl] = zb[row * (unsigned)zlen + (unsigned)min(px, zlen - 1)];
+                    if (!ZF) sf[2 * (GX::STG_ARR / 4) + q * 32 + pxl] = zb[row * (unsigned)zlen + (unsigned)min(px, zlen - 1)];
                     mb[q * 32 + pxl] = px < Npix ? mbase[o] : (unsigned char)0;
                 }
                 (void)dst; (void)fastz;
@@ -355,10 +364,10 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     const unsigned o = row * (unsigned)Npix + 32u * (unsigned)tg + pc;
                     glds16a(dbase, 4u * o, dst + 0 * GX::STG_ARR + i * 1024);
                     glds16a(ebase, 4u * o, dst + 1 * GX::STG_ARR + i * 1024);
-                    if (fastz) glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * GX::STG_ARR + i * 1024);
+                    if (!ZF && fastz) glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * GX::STG_ARR + i * 1024);
                     glds4a(mbase, o, dst + GX::STG_MASK + i * 256);
                 }
-                if (fastz) return 8;
+                if (fastz) return ZF ? 6 : 8;
             }
             // 4-byte pieces, 64 lanes = two rows per instruction, the pixel index clamped per lane
 #pragma unroll
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 const int q = 2 * i + (lane >> 5);
                 const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
                 const int pxl = lane & 31;
-                glds4a(zb, 4u * (row * (unsigned)zlen + (unsigned)min(32 * tg + pxl, zlen - 1)), dst + 2 * GX::STG_ARR + i * 256);
+                if (!ZF) glds4a(zb, 4u * (row * (unsigned)zlen + (unsigned)min(32 * tg + pxl, zlen - 1)), dst + 2 * GX::STG_ARR + i * 256);
                 if (!fastp) {
                     const unsigned o = row * (unsigned)Npix + (unsigned)min(32 * tg + pxl, Npix - 1);
                     glds4a(dbase, 4u * o, dst + 0 * GX::STG_ARR + i * 256);
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 const int slot = 4 * g + (r ^ (g & 1));
                 cur.d[r] = *reinterpret_cast<const f32x2 *>(sb + 0 * GX::STG_ARR + slot * 128);
                 f32x2 e2 = *reinterpret_cast<const f32x2 *>(sb + 1 * GX::STG_ARR + slot * 128);
-                cur.z[r] = *reinterpret_cast<const f32x2 *>(sb + 2 * GX::STG_ARR + slot * 128);
+                if (!ZF) cur.z[r] = *reinterpret_cast<const f32x2 *>(sb + 2 * GX::STG_ARR + slot * 128);
                 const unsigned mk = *reinterpret_cast<const unsigned short *>(mb + slot * 32);
                 e2[0] = (mk & 0xffu) ? fabsf(e2[0]) : -1.f;          // (sign bit, not value: sigma = +0 stays unmasked)
                 e2[1] = (mk & 0xff00u) ? fabsf(e2[1]) : -1.f;
@@ -436,6 +445,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             mid();
             const float *po = reinterpret_cast<const float *>(img + GX::S1_HALF);
             const float Psi = po[lo], om = po[16 + lo];
+            float ti = 0.f, pwi = 0.f, l2i = 0.f;
+            if (BLUE && ZF) { ti = po[32 + lo]; pwi = po[48 + lo]; l2i = po[64 + lo]; }
             const int px = 32 * tg + 2 * lo + h;
             const bool inb = px < Npix;
             const bool blue = px < Nb;
@@ -448,12 +459,21 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 float dd = wv_ ? cur.d[r][h] : 0.f;
                 const float sg = cur.sg[r][h];
                 if (BLUE) {
-                    const float l2 = fast_log2(1.0f + cur.z[r][h]);
-                    const float pw = fast_exp2(k.beta * l2);
-                    const float tauv = k.t_amp * fast_exp2(k.t_expo * (l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
-                    float Ab = fast_exp2(-tauv * QFA_LOG2E);                                          // QFA/model.py:125
+                    float l2, pw, Ab, re;
+                    if (ZF) {                                                                         // qfa_common.h, ZFac
+                        const float4 zq = zsl[4 * g + r];
+                        l2 = zq.z + l2i;
+                        pw = zq.y * pwi;
+                        Ab = fast_exp2(fmaf(zq.x, ti, k.offp));                                       // QFA/model.py:125
+                        re = k.omc0 - fast_exp2(k.k1 * pw);                                           // QFA/utils.py:91
+                    } else {
+                        l2 = fast_log2(1.0f + cur.z[r][h]);
+                        pw = fast_exp2(k.beta * l2);
+                        const float tauv = k.t_amp * fast_exp2(k.t_expo * (l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
+                        Ab = fast_exp2(-tauv * QFA_LOG2E);                                            // QFA/model.py:125
+                        re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);                       // QFA/utils.py:91
+                    }
                     if (HASA) Ab = abase[offB_of(r) + (unsigned)min(px, Nb - 1)];                     // custom tau callable
-                    const float re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);               // QFA/utils.py:91
                     const float Av = blue ? Ab : 1.f;
                     const float zd = blue ? re * re : 0.f;
                     const float A2 = Av * Av;
@@ -541,6 +561,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                         // everything but the requests of tile c + 1 has landed after this
                         if (QFA_GX_ABL & 1) {}
                         else if (c + 1 < n && cnt_other == 8) dma_wait<8>();
+                        else if (c + 1 < n && cnt_other == 6) dma_wait<6>();
                         else if (c + 1 < n && cnt_other == 14) dma_wait<14>();
                         else dma_wait<0>();
                         if (tg < nbt) { GXS(5) } else { GXS(21) }

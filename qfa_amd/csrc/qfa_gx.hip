@@ -14,46 +14,50 @@ size_t qfa_gx_image_bytes(int KP, int ntiles32) {            // the larger of th
 // pass 2, one-wave-per-SIMD form (qfa_grads_w.h)
 template <int KP>
 static void gw_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                      int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, float4 *ZS, float *accum,
-                      float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st) {
-    const bool zf = b.zq1 && b.pix_ratio && Nb > 0;
-    k_prep_pgw<KP><<<ntiles32, 256, 0, st>>>(p, tau, zf ? b.pix_ratio : nullptr, Npix, Nb, Nh, PGW);
-    if (zf) k_zfac_spec<<<(B + 255) / 256, 256, 0, st>>>(b.zq1, p, tau, B, ZS);
+                      int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, const float4 *ZS,
+                      const float4 *ZP, float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64,
+                      hipStream_t st) {
+    k_prep_pgw<KP><<<ntiles32, 256, 0, st>>>(p, ZP, Npix, Nb, Nh, PGW);
     auto go = [&](auto hasa, auto zfac) {
         k_grads_w<KP, decltype(hasa)::value, decltype(zfac)::value><<<wp.items(), 256, 0, st>>>(
             p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, ZS, accum, slab, slabS, slab_stride, sc64);
     };
     if (b.A_blue) go(std::true_type{}, std::false_type{});
-    else if (zf) go(std::false_type{}, std::true_type{});
+    else if (ZS) go(std::false_type{}, std::true_type{});
     else go(std::false_type{}, std::false_type{});
 }
 void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, float *ZS, float *accum, float *slab,
-                   double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st) {
-    if (KP == 8) gw_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, reinterpret_cast<float4 *>(ZS), accum, slab, slabS, slab_stride, sc64, st);
-    else gw_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, reinterpret_cast<float4 *>(ZS), accum, slab, slabS, slab_stride, sc64, st);
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, const float *ZS, const float *ZP,
+                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st) {
+    const float4 *zs = reinterpret_cast<const float4 *>(ZS), *zp = reinterpret_cast<const float4 *>(ZP);
+    if (KP == 8) gw_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, zs, zp, accum, slab, slabS, slab_stride, sc64, st);
+    else gw_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, zs, zp, accum, slab, slabS, slab_stride, sc64, st);
 }
 
+// pass 2, two-role form (qfa_grads_x.h)
 template <int KP>
 static void gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                      int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
-                      double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st) {
-    k_prep_pgx<KP><<<ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, PGX);
-    auto go = [&](auto hasa, auto terms) {
-        k_grads_x<KP, decltype(hasa)::value, decltype(terms)::value><<<wp.items(), 512, 0, st>>>(
-            p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, sc64);
+                      int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, const float4 *ZS,
+                      const float4 *ZP, float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64,
+                      unsigned flags, hipStream_t st) {
+    k_prep_pgx<KP><<<ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, ZP, Npix, Nb, Nh, PGX);
+    auto go = [&](auto hasa, auto terms, auto zf) {
+        k_grads_x<KP, decltype(hasa)::value, decltype(terms)::value, decltype(zf)::value><<<wp.items(), 512, 0, st>>>(
+            p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, ZS, accum, slab, slabS, slab_stride, sc64);
     };
     using T6 = std::integral_constant<int, 6>;
     using T3 = std::integral_constant<int, 3>;
     const bool fast = (flags & QFA_F_S3_FAST) != 0;
-    if (b.A_blue) { if (fast) go(std::true_type{}, T3{}); else go(std::true_type{}, T6{}); }
-    else { if (fast) go(std::false_type{}, T3{}); else go(std::false_type{}, T6{}); }
+    if (b.A_blue) { if (fast) go(std::true_type{}, T3{}, std::false_type{}); else go(std::true_type{}, T6{}, std::false_type{}); }
+    else if (ZS) { if (fast) go(std::false_type{}, T3{}, std::true_type{}); else go(std::false_type{}, T6{}, std::true_type{}); }
+    else { if (fast) go(std::false_type{}, T3{}, std::false_type{}); else go(std::false_type{}, T6{}, std::false_type{}); }
 }
 void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
-                   double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st) {
-    if (KP == 8) gx_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, sc64, flags, st);
-    else gx_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, accum, slab, slabS, slab_stride, sc64, flags, st);
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, const float *ZS, const float *ZP,
+                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st) {
+    const float4 *zs = reinterpret_cast<const float4 *>(ZS), *zp = reinterpret_cast<const float4 *>(ZP);
+    if (KP == 8) gx_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, zs, zp, accum, slab, slabS, slab_stride, sc64, flags, st);
+    else gx_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, zs, zp, accum, slab, slabS, slab_stride, sc64, flags, st);
 }
 
 size_t qfa_px_image_bytes(int KP, int ntiles32) {

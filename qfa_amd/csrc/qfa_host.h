@@ -10,13 +10,13 @@
 // pass 2 for N_h <= 16 with every contraction on the XDL pipe (qfa_grads_x.h: KP = 8 or 16, built in qfa_gx.hip)
 size_t qfa_gx_image_bytes(int KP, int ntiles32);
 void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, float *accum, float *slab,
-                   double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st);
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, const float *ZS, const float *ZP,
+                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st);
 
 // the one-wave-per-SIMD form of the all-XDL pass 2 (qfa_grads_w.h, built in qfa_gx.hip): QFA_F_PASS2_WFORM
 void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, float *ZS, float *accum, float *slab,
-                   double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st);
+                   int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, const float *ZS, const float *ZP,
+                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st);
 
 // posterior writer for N_h <= 16 on the XDL pipe (qfa_predict_x.h, built in qfa_gx.hip)
 size_t qfa_px_image_bytes(int KP, int ntiles32);
@@ -94,7 +94,7 @@ struct Layout {
     int spb1;                                          // spectra per block of pass 1's plan (128 for the 8-wave k_moments_x)
     WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
     WorkPlan wpp;                                      // posterior writer on the XDL pipe (k_predict_x, N_h <= 16)
-    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, oZS, total;   // float offsets
+    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, oZS, oZP, total;   // float offsets
     int bg_stride;                                     // beta / gamma hand-over of pass 2 at N_h = 17..32 ([2][Bpad][NpixPad])
 };
 
@@ -139,7 +139,8 @@ Layout make_layout_t(int B, int Npix) {
     L.oSOL = take((size_t)L.Bpad * C::NSOL);
     L.oNLL = take((size_t)L.Bpad);
     L.oNBL = take((size_t)L.Bpad);
-    L.oZS = take(4 * (size_t)L.Bpad);                   // per-spectrum factors of the factored-z input form (float4 each)
+    L.oZS = take(4 * (size_t)L.Bpad);                   // factored-z input form: per-spectrum factors ZS (float4 each)
+    L.oZP = take(4 * (size_t)L.NpixPad);                //                        per-pixel factors ZP (blue pixels)
     L.oRED = take(2 * 2 * NRED + 2 + sizeof(Scal64) / 4);   // k_reduce_nll: 2 x NRED doubles + the ticket counter; then the
                                                             // float64 scalar-gradient sums of pass 2 (Scal64)
     L.oBG = 0;
@@ -203,10 +204,10 @@ inline int hip_status(hipStream_t st = nullptr, unsigned flags = 0) {
 }
 
 template <int KP>
-void launch_prep(const qfa_params_t &p, int Npix, int Nb, int Nh, const Layout &L, float *PF, float *PFT,
+void launch_prep(const qfa_params_t &p, const float4 *ZP, int Npix, int Nb, int Nh, const Layout &L, float *PF, float *PFT,
                  hipStream_t st) {
     dim3 blk(64, 4);
-    k_prep_pf<KP><<<(L.NpixPad + 3) / 4, blk, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, L.NpixPad, PF, PFT);
+    k_prep_pf<KP><<<(L.NpixPad + 3) / 4, blk, 0, st>>>(p.F, p.Psi, p.omega, ZP, Npix, Nb, Nh, L.NpixPad, PF, PFT);
 }
 
 // MOM[seg 0] += MOM[seg 1..] for the rows of the segmented blocks of pass 1
@@ -222,17 +223,35 @@ void sum_segments(float *MOM, const Layout &L, int B, hipStream_t st) {
         reinterpret_cast<const float4 *>(MOM + (size_t)L.Bpad * Cfg<KP>::NMOM), w.nseg, n4);
 }
 
+// Factored-z input form (qfa_batch_t::zq1 / pix_ratio; qfa_common.h ZFac): the per-spectrum and per-pixel factor tables
+// of this call, or NULL pointers when the batch carries zabs only.
+struct ZTables {
+    const float4 *ZS, *ZP;
+};
+inline ZTables launch_zfac(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Nb, const Layout &L,
+                           float *ws, hipStream_t st) {
+    if (!(b.zq1 && b.pix_ratio) || Nb <= 0) return ZTables{nullptr, nullptr};
+    float4 *ZS = reinterpret_cast<float4 *>(ws + L.oZS), *ZP = reinterpret_cast<float4 *>(ws + L.oZP);
+    k_zfac_spec<<<(B + 255) / 256, 256, 0, st>>>(b.zq1, p, tau, B, ZS);
+    k_zfac_pix<<<(Nb + 255) / 256, 256, 0, st>>>(b.pix_ratio, p, tau, Nb, ZP);
+    return ZTables{ZS, ZP};
+}
+
 // pass 1: N_h <= 16 on the XDL pipe (split-bf16 operands, 32-pixel tiles), wider models on the f32 MFMA
 template <int KP, bool PREDICT>
 void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, const float *mu, int B, int Npix,
-                   int Nb, int Nh, const Layout &L, float *ws, hipStream_t st) {
+                   int Nb, int Nh, const Layout &L, const ZTables &zt, float *ws, hipStream_t st) {
     float *MOM = ws + L.oMOM;
     if constexpr (KP <= 16 || QFA_P1_XDL32) {
         unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
-        k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, Npix, Nb, Nh, PFX);
+        k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, Npix, Nb, Nh, PFX);
         constexpr int NW = KP <= 16 ? QFA_P1_NW : 4;      // (L.spb1 = 16 NW spectra per block)
-        k_moments_x<KP, PREDICT, NW><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, MOM);
+        if (zt.ZS)
+            k_moments_x<KP, PREDICT, NW, true><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, zt.ZS, MOM);
+        else
+            k_moments_x<KP, PREDICT, NW, false><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, nullptr, MOM);
     } else {
+        static_assert(KP <= 16 || QFA_P1_XDL32, "k_moments (float32 MFMA pass 1) has no factored-z form");
         k_moments<KP, PREDICT><<<L.wp1.items(), 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.wp1, ws + L.oPF, MOM);
     }
 }
@@ -291,10 +310,11 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     bool pass2_xdl = false;
     if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP, flags);
     mark(0);
+    const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
     // the float32 images PF / PFT serve k_moments (N_h > 16) and k_grads: not needed when both passes run on the XDL pipe
-    if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
+    if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, zt.ZP, Npix, Nb, Nh, L, PF, PFT, st);
     mark(1);
-    launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, ws, st);
+    launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, zt, ws, st);
     mark(2);
     sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
@@ -308,10 +328,12 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     if (pass2_xdl) {
         if (!(flags & QFA_F_PASS2_WFORM))
             qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
-                          accum, slab, slabS, (int)D.stride, sc64, flags, st);
+                          reinterpret_cast<const float *>(zt.ZS), reinterpret_cast<const float *>(zt.ZP), accum, slab, slabS,
+                          (int)D.stride, sc64, flags, st);
         else
             qfa_gw_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
-                          ws + L.oZS, accum, slab, slabS, (int)D.stride, sc64, st);
+                          reinterpret_cast<const float *>(zt.ZS), reinterpret_cast<const float *>(zt.ZP), accum, slab, slabS,
+                          (int)D.stride, sc64, st);
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
         return hip_status(st, flags);
@@ -320,11 +342,13 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         // stages 1 and 2 for every (spectrum, pixel) on the XDL pipe, beta / gamma through HBM, then stage 3 per 16 columns
         float *BG = ws + L.oBG, *GG = BG + (size_t)round_up(B, 64) * L.bg_stride;
         unsigned char *IMG = reinterpret_cast<unsigned char *>(ws + L.oPGX);
-        k_prep_s12<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, Npix, Nb, Nh, IMG);
+        k_prep_s12<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, zt.ZP, Npix, Nb, Nh, IMG);
         if (b.A_blue)
-            k_s12_x<KP, true><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride, sc64);
+            k_s12_x<KP, true, false><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride, sc64, nullptr);
+        else if (zt.ZS)
+            k_s12_x<KP, false, true><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride, sc64, zt.ZS);
         else
-            k_s12_x<KP, false><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride, sc64);
+            k_s12_x<KP, false, false><<<L.wp2x.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, IMG, SOL, BG, GG, L.bg_stride, accum, slab, slabS, (int)D.stride, sc64, nullptr);
         for (int bh = 0; 16 * bh < Nh; ++bh) {
             if (flags & QFA_F_S3_FAST)
                 k_grads_s3<KP, 3><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, bh, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
@@ -335,22 +359,24 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         mark(4);
         return hip_status(st, flags);
     }
+    auto grads = [&](int bh, float *BG, float *GG) {       // the float32-MFMA form: custom tau table / factored z / zabs
+        if (b.A_blue)
+            k_grads<KP, true, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64, nullptr, BG, GG, L.bg_stride);
+        else if (zt.ZS)
+            k_grads<KP, false, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64, zt.ZS, BG, GG, L.bg_stride);
+        else
+            k_grads<KP, false, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64, nullptr, BG, GG, L.bg_stride);
+    };
     if constexpr (KP == 32) {
         // columns 0..15 by k_grads, which also stores beta and gamma; columns 16..31 by the stage-3-only kernel
         float *BG = Nh > 16 ? ws + L.oBG : nullptr, *GG = Nh > 16 ? BG + (size_t)round_up(B, 64) * L.bg_stride : nullptr;
-        if (b.A_blue)
-            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, 0, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64, BG, GG, L.bg_stride);
-        else
-            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, 0, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64, BG, GG, L.bg_stride);
+        grads(0, BG, GG);
         if (Nh > 16)
             k_grads_s3<KP, 4><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, 1, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
     } else {
     for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
         if (16 * bh >= Nh) break;
-        if (b.A_blue)
-            k_grads<KP, true><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64);
-        else
-            k_grads<KP, false><<<L.wp2.items(), 256, 0, st>>>(p, b, tau, B, Npix, Nb, Nh, L.ntiles, L.wp2, bh, PFT, SOL, accum, slab, slabS, (int)D.stride, sc64);
+        grads(bh, nullptr, nullptr);
     }
     }
     if (slab) launch_reduce_slab(slab, D, B, L.wp2.items() * 4, accum, st);
@@ -372,9 +398,10 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
         writer_xdl = !(flags & QFA_F_PREDICT_F32);               // (the float32-MFMA writer: A/B timing, cross-check)
     }
     mark(0);
+    const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
     // (PF / PFT: k_predict_out, and k_moments where pass 1 is not on the XDL pipe)
-    if (!writer_xdl || (KP > 16 && !QFA_P1_XDL32)) launch_prep<KP>(p, Npix, Nb, Nh, L, PF, PFT, st);
-    launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, ws, st);
+    if (!writer_xdl || (KP > 16 && !QFA_P1_XDL32)) launch_prep<KP>(p, nullptr, Npix, Nb, Nh, L, PF, PFT, st);
+    launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, zt, ws, st);
     mark(1);
     sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
@@ -383,7 +410,7 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     if constexpr (KP > 16 && QFA_P2_S12 != 0) {
         if (writer_xdl) {              // the image of k_s12_x with mu in the place of Psi (qfa_s12_x.h)
             unsigned char *IMG = reinterpret_cast<unsigned char *>(ws + L.oPGX);
-            k_prep_s12<KP><<<L.ntiles32, 256, 0, st>>>(p.F, mu, p.omega, Npix, Nb, Nh, IMG);
+            k_prep_s12<KP><<<L.ntiles32, 256, 0, st>>>(p.F, mu, p.omega, nullptr, Npix, Nb, Nh, IMG);
             k_predict_x32<KP><<<L.wp2x.items(), 256, 0, st>>>(B, Npix, L.ntiles32, L.wp2x, IMG, SOL, cont, unc);
         }
     }

@@ -50,8 +50,8 @@ struct S12 {
 // ------------------------------------------------------------------------------------------------
 template <int KP>
 __global__ __launch_bounds__(256) void k_prep_s12(const float *__restrict__ F, const float *__restrict__ Psi,
-                                                  const float *__restrict__ omega, int Npix, int Nb, int Nh,
-                                                  unsigned char *__restrict__ IMG) {
+                                                  const float *__restrict__ omega, const float4 *__restrict__ ZP,
+                                                  int Npix, int Nb, int Nh, unsigned char *__restrict__ IMG) {
     using X = S12<KP>;
     unsigned char *tile = IMG + (size_t)blockIdx.x * X::TILE_B;
     const int p0 = 32 * blockIdx.x;
@@ -102,6 +102,10 @@ __global__ __launch_bounds__(256) void k_prep_s12(const float *__restrict__ F, c
         float v = 0.f;
         if (j < 16) v = px < Npix ? Psi[px] : 0.f;
         else if (j < 32) v = px < Nb ? omega[px] : 0.f;
+        else if (j < 80 && ZP && px < Nb) {                 // factored-z form: ti | pwi | l2i of the half's pixels
+            const float4 q = ZP[px];
+            v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
+        }
         po[j] = v;
     }
 }
@@ -110,13 +114,13 @@ __global__ __launch_bounds__(256) void k_prep_s12(const float *__restrict__ F, c
 // k_s12_x.  One work item = (block of 64 spectra, range of 32-pixel tiles).  slab != NULL: deterministic mode (the
 // per-pixel sums go to row blk of the slab by plain stores, the scalar sums to slabS[item][wave][3]).
 // ------------------------------------------------------------------------------------------------
-template <int KP, bool HASA>
+template <int KP, bool HASA, bool ZF>
 __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix, int Nb,
                                                   int Nh, int ntiles, WorkPlan wp, const unsigned char *__restrict__ IMG,
                                                   const float *__restrict__ SOL, float *__restrict__ BG,
                                                   float *__restrict__ GG, int bg_stride, float *__restrict__ accum,
                                                   float *__restrict__ slab, double *__restrict__ slabS, int slab_stride,
-                                                  Scal64 *__restrict__ sc64) {
+                                                  Scal64 *__restrict__ sc64, const float4 *__restrict__ ZS) {
     using C = Cfg<KP>;
     using X = S12<KP>;
     constexpr int RING = 3;                                    // quarters in LDS: two of DMA distance (the image streams
@@ -187,11 +191,11 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
     const float *dbase = uniform_ptr(bt.delta + (size_t)(active ? s0 : 0) * Npix);
     const float *ebase = uniform_ptr(bt.error + (size_t)(active ? s0 : 0) * Npix);
     const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)(active ? s0 : 0) * Npix);
-    const float *zbase = uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
+    const float *zbase = ZF ? dbase : uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
     auto stage_tile = [&](int tg, int par) -> int {
         if (QFA_S12_ABL & 2) return 8;
         if (QFA_S12_ABL & 8) tg = t0;                 // timing only: the staging always re-reads the item's first tile (cache hits)
-        const bool zblue = tg < nbt;                                                      // wave-uniform
+        const bool zblue = !ZF && tg < nbt;                                               // wave-uniform
         const bool fast = (32 * tg + 31 < Npix) && (!zblue || 32 * tg + 31 < Nb) && !QFA_TRACKED_LOADS;
         const float *zb = zblue ? zbase : dbase;
         const int zlen = zblue ? Nb : Npix;
@@ -206,10 +210,10 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
                 const unsigned o = row * (unsigned)Npix + 32u * (unsigned)tg + pc;
                 glds16a(dbase, 4u * o, dst + 0 * X::STG_ARR + i * 1024);
                 glds16a(ebase, 4u * o, dst + 1 * X::STG_ARR + i * 1024);
-                glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * X::STG_ARR + i * 1024);
+                if (!ZF) glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * X::STG_ARR + i * 1024);
                 glds4a(mbase, o, dst + X::STG_MASK + i * 256);
             }
-            return 8;
+            return ZF ? 6 : 8;
         }
         float *sf = reinterpret_cast<float *>(buf);
         unsigned char *mb = buf + X::STG_MASK;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
             const unsigned o = row * (unsigned)Npix + (unsigned)min(px, Npix - 1);
             sf[0 * (X::STG_ARR / 4) + q * 32 + pxl] = dbase[o];
             sf[1 * (X::STG_ARR / 4) + q * 32 + pxl] = ebase[o];
-            sf[2 * (X::STG_ARR / 4) + q * 32 + pxl] = zb[row * (unsigned)zlen + (unsigned)min(px, zlen - 1)];
+            if (!ZF) sf[2 * (X::STG_ARR / 4) + q * 32 + pxl] = zb[row * (unsigned)zlen + (unsigned)min(px, zlen - 1)];
             mb[q * 32 + pxl] = px < Npix ? mbase[o] : (unsigned char)0;
         }
         return 0;
@@ -234,7 +238,8 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
             const int slot = 4 * g + (r ^ (g & 1));
             const s12_f32x2 d2 = *reinterpret_cast<const s12_f32x2 *>(sb + 0 * X::STG_ARR + slot * 128);
             const s12_f32x2 e2 = *reinterpret_cast<const s12_f32x2 *>(sb + 1 * X::STG_ARR + slot * 128);
-            const s12_f32x2 z2 = *reinterpret_cast<const s12_f32x2 *>(sb + 2 * X::STG_ARR + slot * 128);
+            s12_f32x2 z2 = {0.f, 0.f};
+            if (!ZF) z2 = *reinterpret_cast<const s12_f32x2 *>(sb + 2 * X::STG_ARR + slot * 128);
             const unsigned mk = *reinterpret_cast<const unsigned short *>(mb + slot * 32);
             cur.d[r][0] = d2[0]; cur.d[r][1] = d2[1];
             cur.sg[r][0] = (mk & 0xffu) ? fabsf(e2[0]) : -1.f;        // (sign bit = masked; only sigma^2 is used)
@@ -261,7 +266,10 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
 
     double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;
     f32x4 afy, aq;
-    float PsiH = 0.f, omH = 0.f;
+    float PsiH = 0.f, omH = 0.f, tiH = 0.f, pwiH = 0.f, l2iH = 0.f;
+    ZFac zs[4];                                   // factored-z form: per-spectrum factors of the lane's four spectra
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[r] = zfac_load(ZS, s0 + 4 * g + r, ZF && sv[r]);
 
     // the K-steps of quarter j of a half: B pieces of K-step ks + 1 are read while the six MFMAs of ks run
     auto quarter = [&](auto jtag, const unsigned char *img) {
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
             const float *po = reinterpret_cast<const float *>(img + X::Q_B);
             PsiH = po[lo];
             omH = po[16 + lo];
+            if (ZF) { tiH = po[32 + lo]; pwiH = po[48 + lo]; l2iH = po[64 + lo]; }
         }
         u32x4 bq[2][3];
 #pragma unroll
@@ -314,12 +323,20 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
             const bool wv_ = inb & sv[r] & (__float_as_int(sg) >= 0);
             const float dd = wv_ ? cur.d[r][h] : 0.f;
             if (BLUE) {
-                const float l2 = fast_log2(1.0f + cur.z[r][h]);
-                const float pw = fast_exp2(k.beta * l2);
-                const float tauv = k.t_amp * fast_exp2(k.t_expo * (l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
-                float Ab = fast_exp2(-tauv * QFA_LOG2E);                                          // QFA/model.py:125
+                float l2, pw, Ab, re;
+                if (ZF) {                                                                         // qfa_common.h, ZFac
+                    l2 = zs[r].l2 + l2iH;
+                    pw = zs[r].pw * pwiH;
+                    Ab = fast_exp2(fmaf(zs[r].ts, tiH, k.offp));                                  // QFA/model.py:125
+                    re = k.omc0 - fast_exp2(k.k1 * pw);                                           // QFA/utils.py:91
+                } else {
+                    l2 = fast_log2(1.0f + cur.z[r][h]);
+                    pw = fast_exp2(k.beta * l2);
+                    const float tauv = k.t_amp * fast_exp2(k.t_expo * (l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
+                    Ab = fast_exp2(-tauv * QFA_LOG2E);                                            // QFA/model.py:125
+                    re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);                       // QFA/utils.py:91
+                }
                 if (HASA) Ab = bt.A_blue[(size_t)(active ? min(s0 + 4 * g + r, B - 1) : 0) * Nb + min(px, Nb - 1)];
-                const float re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);               // QFA/utils.py:91
                 const float Av = blue ? Ab : 1.f;
                 const float zd = blue ? re * re : 0.f;
                 const float A2 = Av * Av;

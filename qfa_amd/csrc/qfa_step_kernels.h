@@ -23,8 +23,8 @@
 // ------------------------------------------------------------------------------------------------
 template <int KP>
 __global__ void k_prep_pf(const float *__restrict__ F, const float *__restrict__ Psi,
-                          const float *__restrict__ omega, int Npix, int Nb, int Nh, int NpixPad,
-                          float *__restrict__ PF, float *__restrict__ PFT) {
+                          const float *__restrict__ omega, const float4 *__restrict__ ZP, int Npix, int Nb, int Nh,
+                          int NpixPad, float *__restrict__ PF, float *__restrict__ PFT) {
     using C = Cfg<KP>;
     const int i = blockIdx.x * blockDim.y + threadIdx.y;   // pixel row
     if (i >= NpixPad) return;
@@ -55,8 +55,15 @@ __global__ void k_prep_pf(const float *__restrict__ F, const float *__restrict__
         PF[(size_t)i * C::NCPL + c] = v;
         if (rt >= 0) pft[rt * 16] = v;
     }
-    // zero padding rows of the PFT tile
-    for (int r = C::PFT_PSI + 2 + threadIdx.x; r < C::NR; r += blockDim.x) pft[r * 16] = 0.f;
+    // the per-pixel factors of the factored-z form, then zero padding rows of the PFT tile
+    for (int r = C::PFT_PSI + 2 + threadIdx.x; r < C::NR; r += blockDim.x) {
+        float v = 0.f;
+        if (ZP && i < Nb && r < C::PFT_PSI + 5) {
+            const float4 q = ZP[i];
+            v = r == C::PFT_PSI + 2 ? q.x : (r == C::PFT_PSI + 3 ? q.y : q.z);
+        }
+        pft[r * 16] = v;
+    }
     if constexpr (C::XS3 && KP == 32) {
         // F of this pixel as bf16 pieces, A operand of stage 3 (K = a = 32): [piece][g][px][a = 8g + j], 16 bytes per (g, px)
         if (threadIdx.x < 4) {
@@ -629,14 +636,17 @@ struct SpecRegs2 {
 #ifndef QFA_G8_OCC
 #define QFA_G8_OCC 2      // workgroups per CU the N_h <= 8 instantiation is compiled for
 #endif
-template <int KP, bool HASA>
+struct PixPar {                  // per-pixel parameters of the lane's pixel: Psi, omega and (factored-z form) ti, pwi, l2i
+    float Psi, om, ti, pwi, l2i;
+};
+template <int KP, bool HASA, bool ZF>
 __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void k_grads(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B,
                                                               int Npix, int Nb, int Nh, int ntiles, WorkPlan wp,
                                                               int bhalf, const float *__restrict__ PFT,
                                                               const float *__restrict__ SOL,
                                                               float *__restrict__ accum, float *__restrict__ slab,
                                                               double *__restrict__ slabS, int slab_stride,
-                                                              Scal64 *__restrict__ sc64,
+                                                              Scal64 *__restrict__ sc64, const float4 *__restrict__ ZS,
                                                               float *__restrict__ BG = nullptr,
                                                               float *__restrict__ GG = nullptr, int bg_stride = 0) {
     // BG != NULL (KP = 32): beta = wD A^2 and gamma = A u of every (spectrum, pixel) are also stored, [Bpad][bg_stride]
@@ -772,8 +782,11 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
     const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
     const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
     const uint8_t *mbase = bt.mask + (size_t)(active ? s0 : 0) * Npix;
-    const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
+    const float *zbase = ZF ? nullptr : bt.zabs + (size_t)(active ? s0 : 0) * Nb;
     const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
+    ZFac zs[4];                                   // factored-z form: per-spectrum factors of the lane's four spectra
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[r] = zfac_load(ZS, s0 + 4 * g + r, ZF && sv[r]);
     const float4 *PFT4 = reinterpret_cast<const float4 *>(PFT);
     using TC = TileCopy<XS3 ? NM4 : NF4>;       // (XDL stage 3: the F pieces at the end of the tile are not staged)
     float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f}, tvx[TC::NX];
@@ -812,7 +825,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
                 rg.sg[r] = ebase[o];
                 rg.m[r] = mbase[o];
             }
-            if (BLUE) {
+            if (BLUE && !ZF) {
                 const unsigned pz = (unsigned)min(16 * tg + lo, Nb - 1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rg.z[r] = zbase[(unsigned)offB[r] + pz];
@@ -821,7 +834,16 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
 
         // ---- stage 1 of one tile: [f^T y | f^T C^-1 f] for the lane's four elements, plus Psi/omega
         // (plain form, used once to prime the pipeline)
-        auto stage1 = [&](const float *tile, f32x4 &afy, f32x4 &aq, float &Psi, float &om) {
+        auto read_pix = [&](const float *tile, PixPar &pp) {
+            pp.Psi = tile[C::PFT_PSI * 16 + lo];
+            pp.om = tile[(C::PFT_PSI + 1) * 16 + lo];
+            if (BLUE && ZF) {
+                pp.ti = tile[(C::PFT_PSI + 2) * 16 + lo];
+                pp.pwi = tile[(C::PFT_PSI + 3) * 16 + lo];
+                pp.l2i = tile[(C::PFT_PSI + 4) * 16 + lo];
+            }
+        };
+        auto stage1 = [&](const float *tile, f32x4 &afy, f32x4 &aq, PixPar &pp) {
             constexpr int NK1 = KF + KQ;
             const float *tb_ = tile + g * 16 + lo;
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
@@ -835,8 +857,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
             }
             afy = a0;
             aq = a1 + a2;
-            Psi = tile[C::PFT_PSI * 16 + lo];
-            om = tile[(C::PFT_PSI + 1) * 16 + lo];
+            read_pix(tile, pp);
         };
 
         // ---- region 1 of the software pipeline: stage 2 of tile `tg` (VALU: u, diag(Sigma^-1), dG, the
@@ -845,8 +866,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
         // the next tile are issued (their B operands were read from LDS six slots earlier), and
         // sched_barrier(0) pins that order, so a single wave keeps the matrix pipe and the VALU busy
         // at the same time (an MFMA occupies the pipe for 32 cycles = 6-8 VALU issues).
-        auto region1 = [&](int tg, const SpecRegs2 &cur, const f32x4 &afy, const f32x4 &aq, float Psi, float om,
-                           const float *tileN, f32x4 &afyN, f32x4 &aqN, float &PsiN, float &omN,
+        auto region1 = [&](int tg, const SpecRegs2 &cur, const f32x4 &afy, const f32x4 &aq, const PixPar &pp,
+                           const float *tileN, f32x4 &afyN, f32x4 &aqN, PixPar &ppN,
                            float (&betaR)[4], float (&gamR)[4], float *part) {
             constexpr int NK1 = KF + KQ, AHEAD = 6;
             const float *tbN = tileN + g * 16 + lo;
@@ -873,9 +894,9 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
             };
 #pragma unroll
             for (int t = 0; t < AHEAD; ++t) rd(t);
-            PsiN = tileN[C::PFT_PSI * 16 + lo];
-            omN = tileN[(C::PFT_PSI + 1) * 16 + lo];
+            read_pix(tileN, ppN);
             __builtin_amdgcn_sched_barrier(0);
+            const float Psi = pp.Psi, om = pp.om;
 
             const int px = 16 * tg + lo;
             const bool inb = px < Npix;
@@ -895,18 +916,29 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
                 if (BLUE) {
 #pragma unroll
                     for (int r = rp; r < rp + 2; ++r) {           // chunk 0
-                        l2[r] = fast_log2(1.0f + cur.z[r]);
-                        x1[r] = k.t_expo * (l2[r] + k.t_lscale);
-                        x2[r] = k.beta * l2[r];
-                        pin(x1[r], x2[r]);
+                        if (ZF) {                                 // factored-z form (qfa_common.h, ZFac): no logarithm
+                            l2[r] = zs[r].l2 + pp.l2i;
+                            pw[r] = zs[r].pw * pp.pwi;
+                            pin(l2[r], pw[r]);
+                        } else {
+                            l2[r] = fast_log2(1.0f + cur.z[r]);
+                            x1[r] = k.t_expo * (l2[r] + k.t_lscale);
+                            x2[r] = k.beta * l2[r];
+                            pin(x1[r], x2[r]);
+                        }
                     }
                     slots(2);
 #pragma unroll
                     for (int r = rp; r < rp + 2; ++r) {           // chunk 1
-                        pw[r] = fast_exp2(x2[r]);
-                        const float tauv = k.t_amp * fast_exp2(x1[r]) + k.t_off;       // QFA/utils.py:105-141
-                        y1[r] = -tauv * QFA_LOG2E;
-                        y2[r] = -k.tau0 * pw[r] * QFA_LOG2E;
+                        if (ZF) {
+                            y1[r] = fmaf(zs[r].ts, pp.ti, k.offp);
+                            y2[r] = k.k1 * pw[r];
+                        } else {
+                            pw[r] = fast_exp2(x2[r]);
+                            const float tauv = k.t_amp * fast_exp2(x1[r]) + k.t_off;       // QFA/utils.py:105-141
+                            y1[r] = -tauv * QFA_LOG2E;
+                            y2[r] = -k.tau0 * pw[r] * QFA_LOG2E;
+                        }
                         pin(y1[r], y2[r]);
                     }
                     slots(2);
@@ -1118,7 +1150,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
         //            region 2 = stage 3 of tile c (68 MFMAs);
         // so the matrix pipe has work from a neighbouring tile while the VALU does the per-pixel math.
         f32x4 afy, aq;
-        float Psi = 0.f, om = 0.f;
+        PixPar pxp{0.f, 0.f, 0.f, 0.f, 0.f};
         auto step = [&](int c, const SpecRegs2 &cur, SpecRegs2 &nxt) {
             const bool more = c + 1 < n;
             const int tg = tile_of(c);
@@ -1128,7 +1160,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
 #endif
             QFA_STAMP(q0)
             f32x4 afyN = {0.f, 0.f, 0.f, 0.f}, aqN = {0.f, 0.f, 0.f, 0.f};
-            float PsiN = 0.f, omN = 0.f;
+            PixPar pxpN{0.f, 0.f, 0.f, 0.f, 0.f};
             float betaR[4] = {0.f, 0.f, 0.f, 0.f}, gamR[4] = {0.f, 0.f, 0.f, 0.f};
             ZV Fgh = {}, Fgm = {};
             if constexpr (XS3 && !XDMA) {      // KP = 32: the lane's F pieces of this tile straight from the tile image (L2)
@@ -1146,7 +1178,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
                 nxt = cur;
 #endif
                 QFA_STAMP(q1)
-                region1(tg, cur, afy, aq, Psi, om, tilebuf(cn1), afyN, aqN, PsiN, omN, betaR, gamR,
+                region1(tg, cur, afy, aq, pxp, tilebuf(cn1), afyN, aqN, pxpN, betaR, gamR,
                         ldspart[pbuf][wv]);
                 __builtin_amdgcn_sched_barrier(0);
                 QFA_STAMP(q2)
@@ -1169,7 +1201,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
                 asm volatile("" ::"v"(betaR[0]), "v"(betaR[1]), "v"(betaR[2]), "v"(betaR[3]), "v"(gamR[0]), "v"(gamR[1]),
                              "v"(gamR[2]), "v"(gamR[3]));
 #endif
-                afy = afyN; aq = aqN; Psi = PsiN; om = omN;
+                afy = afyN; aq = aqN; pxp = pxpN;
                 QFA_STAMP(q3)
 #if QFA_ABL == 7
                 st_t[(BLUE ? 0 : 8) + 0] += q1 - q0; st_t[(BLUE ? 0 : 8) + 1] += q2 - q1; st_t[(BLUE ? 0 : 8) + 2] += q3 - q2;
@@ -1201,7 +1233,7 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
         }
         if (active) load_spec(tile_of(0), ra);
         __syncthreads();
-        if (active) stage1(tilebuf(0), afy, aq, Psi, om);
+        if (active) stage1(tilebuf(0), afy, aq, pxp);
         for (int c = 0; c < n; c += 2) {
             step(c, ra, rb);
             if (c + 1 < n) step(c + 1, rb, ra);

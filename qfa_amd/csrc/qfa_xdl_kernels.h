@@ -30,8 +30,9 @@ struct XCfg {
     static constexpr int nct(int j) { return j == 0 ? CT1 : NCT - CT1; }
     static constexpr int pstr(int j) { return nct(j) * 1024; }   // bytes of one piece of sub-image j: 32 px x bf16 per column
     static constexpr int PSTR = pstr(0);
-    static constexpr int OFF_PSI = 3 * PSTR;                  // in sub-image 0: float32 Psi[32], omega[32], mu[32] (prediction)
-    static constexpr int SUB0_B = (3 * PSTR + 384 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
+    static constexpr int OFF_PSI = 3 * PSTR;                  // in sub-image 0: float32 Psi[32], omega[32], mu[32] (prediction),
+                                                              // ti[32], pwi[32] (factored-z form: ZP of qfa_common.h)
+    static constexpr int SUB0_B = (3 * PSTR + 640 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
     static constexpr int SUB1_B = NSW > 1 ? 3 * pstr(1) : 0;
     static constexpr int sub_off(int j) { return j == 0 ? 0 : SUB0_B; }
     static constexpr int sub_bytes(int j) { return j == 0 ? SUB0_B : SUB1_B; }
@@ -127,7 +128,7 @@ __device__ __forceinline__ void step_barrier() {        // LDS writes of this st
 template <int KP>
 __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, const float *__restrict__ Psi,
                                                   const float *__restrict__ omega, const float *__restrict__ mu,
-                                                  int Npix, int Nb, int Nh,
+                                                  const float4 *__restrict__ ZP, int Npix, int Nb, int Nh,
                                                   unsigned char *__restrict__ PFX) {
     using C = Cfg<KP>;
     using X = XCfg<KP>;
@@ -172,6 +173,8 @@ __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, c
         if (idx < 32) v = i < Npix ? Psi[i] : 0.f;
         else if (idx < 64) v = i < Nb ? omega[i] : 0.f;
         else if (idx < 96) v = (mu && i < Npix) ? mu[i] : 0.f;      // mean continuum (prediction: delta = flux - mu A)
+        else if (idx < 128) v = (ZP && i < Nb) ? ZP[i].x : 0.f;     // factored-z form: ti
+        else if (idx < 160) v = (ZP && i < Nb) ? ZP[i].y : 0.f;     //                  pwi
         po[idx] = v;
     }
 }
@@ -206,10 +209,10 @@ __device__ __forceinline__ void aload8(u32x2 &dst, const void *sbase, unsigned v
 __device__ __forceinline__ void aload4(float &dst, const void *sbase, unsigned voff) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
-template <bool BLUE>
+template <bool WITHZ>
 __device__ __forceinline__ void land(SpecRegsX &r) {
     asm volatile("" : "+v"(r.d0), "+v"(r.d1), "+v"(r.s0), "+v"(r.s1), "+v"(r.m));
-    if (BLUE) asm volatile("" : "+v"(r.z0), "+v"(r.z1));
+    if (WITHZ) asm volatile("" : "+v"(r.z0), "+v"(r.z1));
 }
 
 #ifndef QFA_P1_EARLY_DMA
@@ -229,11 +232,11 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
     c = xdl(ah, bm, c);
     return xdl(ah, bh, c);
 }
-template <int KP, bool PREDICT, int NW>
+template <int KP, bool PREDICT, int NW, bool ZF>      // ZF: factored-z input form (ZS = per-spectrum factors; zabs is not read)
 __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                       const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
                                                       int ntiles, WorkPlan wp, const unsigned char *__restrict__ PFX,
-                                                      float *__restrict__ MOM) {
+                                                      const float4 *__restrict__ ZS, float *__restrict__ MOM) {
     using C = Cfg<KP>;
     using X = XCfg<KP>;
     static_assert(NW == 4 || (NW == 8 && X::NSW == 1), "8 waves: the two-group form of N_h <= 16");
@@ -254,9 +257,10 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
     const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
     const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
     const uint8_t *mbase = bt.mask + (size_t)(active ? s0 : 0) * Npix;
-    const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
+    const float *zbase = ZF ? nullptr : bt.zabs + (size_t)(active ? s0 : 0) * Nb;
     const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
     const int offN = srow * Npix, offB = srow * Nb;
+    const ZFac zs = zfac_load(ZS, s0 + sl, ZF && svalid);
     // per-lane byte offsets of the fast-path loads (base = the wave's row block + 32 * tile, in SGPRs)
     const unsigned voffN = (unsigned)(offN + 8 * g) * 4u, voffB = (unsigned)(offB + 8 * g) * 4u,
                    voffM = (unsigned)(offN + 8 * g);
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 // vmcnt(0) in front of the fast path's next loads into the same registers
                 asm volatile("" : "+v"(r.d0), "+v"(r.d1), "+v"(r.s0), "+v"(r.s1));
             }
-            if (BLUE) {
+            if (BLUE && !ZF) {
                 if (!QFA_TRACKED_LOADS && pb + 7 < Nb) {
                     aload16<0>(r.z0, zbase + 32 * tg, voffB);
                     aload16<16>(r.z1, zbase + 32 * tg, voffB);
@@ -335,7 +339,13 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         // ---- phase 1 of a tile: per-element weights on the VALU (QFA/model.py:125-131), split into bf16 pieces
         auto weights = [&](int tg, const SpecRegsX &cur, const unsigned char *tile, Pieces &w) {
             const float *pp = reinterpret_cast<const float *>(tile + X::OFF_PSI) + 8 * g;
-            float psi[8], om[8], muv[8];
+            float psi[8], om[8], muv[8], ti[8], pwi[8];
+            if (BLUE && ZF) {
+                const float4 a = *reinterpret_cast<const float4 *>(pp + 96), b = *reinterpret_cast<const float4 *>(pp + 100),
+                             c = *reinterpret_cast<const float4 *>(pp + 128), d = *reinterpret_cast<const float4 *>(pp + 132);
+                ti[0] = a.x; ti[1] = a.y; ti[2] = a.z; ti[3] = a.w; ti[4] = b.x; ti[5] = b.y; ti[6] = b.z; ti[7] = b.w;
+                pwi[0] = c.x; pwi[1] = c.y; pwi[2] = c.z; pwi[3] = c.w; pwi[4] = d.x; pwi[5] = d.y; pwi[6] = d.z; pwi[7] = d.w;
+            }
             if (PREDICT) {          // from the tile image: a global load here would sit in the counted vmcnt queue
                 const float4 a = *reinterpret_cast<const float4 *>(pp + 64), b = *reinterpret_cast<const float4 *>(pp + 68);
                 muv[0] = a.x; muv[1] = a.y; muv[2] = a.z; muv[3] = a.w;
@@ -368,7 +378,8 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                     float D, wD;
                     if (BLUE) {
                         const bool blue = px < Nb;
-                        const BlueTerms t = blue_terms(e < 4 ? cur.z0[e & 3] : cur.z1[e & 3], k);
+                        const BlueTerms t = ZF ? blue_terms_zf(zs, ti[e], pwi[e], 0.f, k)
+                                               : blue_terms(e < 4 ? cur.z0[e & 3] : cur.z1[e & 3], k);
                         float Ab = t.A;
                         if (abase) Ab = abase[offB + min(px, Nb - 1)];        // custom tau callable (rare path)
                         const float A = blue ? Ab : 1.f;
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             Pieces w;
             if (QFA_P1_EARLY_DMA && c + 1 < n && !(QFA_P1_ABL & 8)) stage(ta + c + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            land<BLUE>(cur);
+            land<BLUE && !ZF>(cur);
             if (QFA_P1_ABL & 4) {            // timing only: no weights (pieces straight from the spectra registers)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             } else if (active) mfmas(lds[buf], w, std::integral_constant<int, 0>{});
             // retire everything up to and including the DMA: it was issued before the 5 (red: 2 delta, 2 sigma,
             // 1 mask) / 7 (blue: + 2 zabs) spectra loads of this step (the ragged-end path issues more, smaller ones)
-            if (reload) dma_wait<BLUE ? 7 : 5>();
+            if (reload) dma_wait<(BLUE && !ZF) ? 7 : 5>();
             else dma_wait<0>();
             wg_barrier();
             asm volatile("" ::: "memory");
@@ -481,7 +492,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         // everything: the spectra requested in sweep 0 have had a whole tile step (~3 us at N_h = 32) by then.
         auto step2 = [&](int c, SpecRegsX &cur) {
             Pieces w;
-            land<BLUE>(cur);
+            land<BLUE && !ZF>(cur);
             if (active) weights(ta + c, cur, lds[0], w);
             __builtin_amdgcn_sched_barrier(0);
             stage_sub(ta + c, std::integral_constant<int, X::NSW - 1>{}, 1);
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             if (reload) load_spec(ta + c + 2, cur);
             __builtin_amdgcn_sched_barrier(0);
             if (active) mfmas(lds[0], w, std::integral_constant<int, 0>{});
-            if (reload) dma_wait<BLUE ? 7 : 5>();
+            if (reload) dma_wait<(BLUE && !ZF) ? 7 : 5>();
             else dma_wait<0>();
             wg_barrier();
             asm volatile("" ::: "memory");
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             const int slot = c % 3, nslot = (c + 1) % 3, pslot = (c + 2) % 3;
             if (c + 1 < n) stage(ta + c + 1, nslot);
             __builtin_amdgcn_sched_barrier(0);
-            land<BLUE>(cur);
+            land<BLUE && !ZF>(cur);
             const bool reload = active & (c + 2 < n);
             // (one weights site and one set of piece registers for both groups)
             if (grpB && active && c > 0) mfmas(lds[pslot], wB, std::integral_constant<int, 0>{});
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             if (reload) load_spec(ta + c + 2, cur);
             __builtin_amdgcn_sched_barrier(0);
             if (!grpB && active) mfmas(lds[slot], wB, std::integral_constant<int, 0>{});
-            if (reload) dma_wait<BLUE ? 7 : 5>();
+            if (reload) dma_wait<(BLUE && !ZF) ? 7 : 5>();
             else dma_wait<0>();
             wg_barrier();
             asm volatile("" ::: "memory");

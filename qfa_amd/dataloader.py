@@ -78,6 +78,11 @@ class DeviceDataloader(object):
         self.pathlist = paths if paths is not None else np.arange(lo, hi)
         self._zq_dev = torch.as_tensor(self.zqso, device=self.device)
         self._wav_dev = torch.as_tensor(self.wav_grid, device=self.device)
+        # factored-z input form (include/qfa_hip.h): 1 + zabs[s][i] = (1 + z_qso[s]) wav_i / 1215.67 (reference
+        # QFA/dataloader.py:102), so the kernels can take the two factors instead of reading the (B, Nb) array
+        self._zq1_dev = (1.0 + self._zq_dev).to(f32)
+        self._pix_ratio = torch.as_tensor((self.wav_grid[:self.Nb] / LYA).astype(np.float32), device=self.device)
+        self.factored_z = True                                  # attach the factors to the zabs tensor of every batch
         self._plan = ShardPlan(n_global, self.batch_size, self.rank, self.world, seed, shuffle) if self.world > 1 else None
         self._epoch = -1
         self._steps = None                                      # DP: list of local row arrays of the current epoch
@@ -160,6 +165,10 @@ class DeviceDataloader(object):
             C.c_void_p(self._mu_dev.data_ptr()), self._which, n, self.Npix, self.Nb, C.c_void_p(delta.data_ptr()),
             C.c_void_p(err.data_ptr()), C.c_void_p(zabs.data_ptr()) if self.Nb > 0 else None,
             C.c_void_p(mask.data_ptr()), _lib.current_stream(self.device)), "qfa_build_batch_f32")
+        if self.factored_z and out is None and self.Nb > 0:
+            # QFA.forward / step / predict look for this attribute on the zabs tensor they are handed (the 4-tuple of the
+            # reference's next_batch contract stays what it is; a sliced or copied zabs simply loses the attribute)
+            zabs.zfac = (self._zq1_dev[idx.long()], self._pix_ratio)
         return delta, err, zabs, mask
 
     def have_next_batch(self):

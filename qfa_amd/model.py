@@ -84,6 +84,9 @@ class QFA(object):
         self.deterministic = False
         # kernel-form switches of the *_ex_f32 entry points (_lib.F_*; 0 = defaults): A/B timing, cross-checks in tests/
         self.flags = 0
+        # use the factored-z input form when a batch carries it (DeviceDataloader batches, or zfac=...): same results to
+        # float32 rounding, 4 Nb bytes per spectrum and pass less HBM traffic, three transcendentals per blue element less
+        self.use_factored_z = True
 
     # ------------------------------------------------------------------ parameters
     def random_init_func(self) -> None:
@@ -151,22 +154,39 @@ class QFA(object):
             setattr(ps, k, _lib.require_device_tensor(t, f32, k).value)
         return ps
 
-    def _batch_struct(self, delta, error, zabs, mask):
+    def _batch_struct(self, delta, error, zabs, mask, zfac=None):
+        """``zfac`` = (zq1 (B,), pix_ratio (Nb,)) float32 device tensors: the factored-z input form of include/qfa_hip.h
+        (1 + zabs[s][i] = zq1[s] pix_ratio[i], reference QFA/dataloader.py:102).  Default: the ``zfac`` attribute a
+        DeviceDataloader attaches to the zabs tensors it builds; None = the kernels read zabs."""
+        if zfac is None:
+            zfac = getattr(zabs, "zfac", None)
         if mask.dtype != torch.bool:
             raise _lib.QFAHipError(f"mask: dtype {mask.dtype}, expected torch.bool (reference model.py:124)")
         bs = _lib.Batch()
         delta = delta if (delta.dtype == f32 and delta.is_contiguous()) else delta.to(f32).contiguous()
         error = error if (error.dtype == f32 and error.is_contiguous()) else error.to(f32).contiguous()
-        zabs = zabs if (zabs.dtype == f32 and zabs.is_contiguous()) else zabs.to(f32).contiguous()
+        if zabs is not None:
+            zabs = zabs if (zabs.dtype == f32 and zabs.is_contiguous()) else zabs.to(f32).contiguous()
         mask = mask if mask.is_contiguous() else mask.contiguous()
         keep = [delta, error, zabs, mask]
         bs.delta = _lib.require_device_tensor(delta, f32, "delta").value
         bs.error = _lib.require_device_tensor(error, f32, "error").value
-        bs.zabs = _lib.require_device_tensor(zabs, f32, "zabs").value if self.Nb > 0 else None
+        bs.zabs = _lib.require_device_tensor(zabs, f32, "zabs").value if (self.Nb > 0 and zabs is not None) else None
         bs.mask = _lib.require_device_tensor(mask, torch.bool, "mask").value
         bs.A_blue = None
         bs.zq1 = None
         bs.pix_ratio = None
+        if zfac is not None and self.Nb > 0 and self._tau_callable is None and self.use_factored_z:
+            zq1, ratio = zfac
+            if tuple(zq1.shape) != (delta.shape[0],) or tuple(ratio.shape) != (self.Nb,):
+                raise _lib.QFAHipError(f"zfac shapes {tuple(zq1.shape)}, {tuple(ratio.shape)}: expected ({delta.shape[0]},), ({self.Nb},)")
+            zq1 = zq1 if (zq1.dtype == f32 and zq1.is_contiguous()) else zq1.to(f32).contiguous()
+            ratio = ratio if (ratio.dtype == f32 and ratio.is_contiguous()) else ratio.to(f32).contiguous()
+            keep += [zq1, ratio]
+            bs.zq1 = _lib.require_device_tensor(zq1, f32, "zq1").value
+            bs.pix_ratio = _lib.require_device_tensor(ratio, f32, "pix_ratio").value
+        elif zabs is None and self.Nb > 0:
+            raise _lib.QFAHipError("zabs is None and no usable zfac = (zq1, pix_ratio) was given")
         if self._tau_callable is not None and self.Nb > 0:
             a = torch.exp(-1. * self._tau_callable(zabs)).to(f32).contiguous()   # user code (model.py:125)
             keep.append(a)
@@ -194,6 +214,8 @@ class QFA(object):
 
     def _check_batch_shapes(self, delta, error, zabs, mask):
         B = delta.shape[0]
+        if zabs is None:
+            zabs = delta.new_empty((B, self.Nb))            # (factored-z form: shape check of the rest only)
         if tuple(delta.shape) != (B, self.Npix) or tuple(error.shape) != (B, self.Npix) \
                 or tuple(mask.shape) != (B, self.Npix) or tuple(zabs.shape) != (B, self.Nb):
             raise _lib.QFAHipError(
@@ -250,13 +272,13 @@ class QFA(object):
                                    "sync_replicas(optimizer) after random_init_func / load_* on every rank")
         self._dp_checked = True
 
-    def accumulate(self, delta, error, zabs, mask, accum=None, nll=None, events=None):
+    def accumulate(self, delta, error, zabs, mask, accum=None, nll=None, events=None, zfac=None):
         """Raw sums of one (shard of a) batch into the packed buffer; no normalisation.
         ``events``: optional list of 5 recorded torch.cuda.Event(enable_timing=True) that the library
         re-records at {start, PF image, pass 1, solve, pass 2} on the current stream (bench.py)."""
         B = self._check_batch_shapes(delta, error, zabs, mask)
         ps = self._params_struct()
-        bs, keep = self._batch_struct(delta, error, zabs, mask)
+        bs, keep = self._batch_struct(delta, error, zabs, mask, zfac)
         ws = self._workspace(B)
         acc = self._accum() if accum is None else accum
         evs = None
@@ -295,14 +317,14 @@ class QFA(object):
 
     # ------------------------------------------------------------------ reference surface
     def forward(self, delta: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor,
-                events=None):
+                events=None, zfac=None):
         """Batch loss (1,1) and count-normalised gradient dict (reference QFA/model.py:74-105)."""
         if delta.shape[0] == 0:
             if not self._dp:
                 raise _lib.QFAHipError("forward: empty batch")
             acc = self._accum()                         # an exhausted rank adds zeros to the global sums and counts
         else:
-            acc = self.accumulate(delta, error, zabs, mask, events=events)
+            acc = self.accumulate(delta, error, zabs, mask, events=events, zfac=zfac)
         if self._dp:
             from .distributed import all_reduce_accum
             all_reduce_accum(acc, self._dp_group)
@@ -315,7 +337,7 @@ class QFA(object):
         return self._finalize(acc, False)
 
     def predict(self, flux: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor, events=None,
-                out=None):
+                out=None, zfac=None):
         """Batched posterior prediction: ll (B,), hmean (B,Nh), hcov (B,Nh,Nh), cont (B,Npix),
         unc (B,Npix) (reference QFA/model.py:160-180 applied to every row).  ``events``: optional list of 4 recorded
         torch.cuda.Event(enable_timing=True), re-recorded at {start, images + pass 1, solve, continuum writer};
@@ -324,7 +346,7 @@ class QFA(object):
             raise _lib.QFAHipError("predict needs model.mu (load_from_npz or train first)")
         B = self._check_batch_shapes(flux, error, zabs, mask)
         ps = self._params_struct()
-        bs, keep = self._batch_struct(flux, error, zabs, mask)
+        bs, keep = self._batch_struct(flux, error, zabs, mask, zfac)
         mu = self.mu.to(device=self.device, dtype=f32).contiguous()
         ws = self._workspace(B)
         dev = self.device
@@ -408,10 +430,10 @@ class QFA(object):
         ll, hmean, hcov, cont, unc = self.predict(flux[None, :], error[None, :], zabs[None, :], mask[None, :])
         return ll.reshape(1, 1), hmean.reshape(self.Nh, 1), hcov[0], cont[0], unc[0]
 
-    def step(self, optimizer, delta, error, zabs, mask, events=None):
+    def step(self, optimizer, delta, error, zabs, mask, events=None, zfac=None):
         """forward -> Adam.update -> clip, all on device, no host sync (model.py:212-214, 316).
         Returns the (1,1) loss tensor."""
-        loss, grads = self.forward(delta, error, zabs, mask, events=events)
+        loss, grads = self.forward(delta, error, zabs, mask, events=events, zfac=zfac)
         new = optimizer.update(self.parameters, grads, clip=self._clip_table())
         for k in PARAM_KEYS:
             setattr(self, k, new[k])

@@ -110,10 +110,10 @@ def make_batch_numpy(params, mu, wav, nb, batch, seed, masks=True, red_only=(), 
     }
 
 
-def make_batch_torch(params, mu, wav, nb, batch, seed, device, masks=True):
+def make_batch_torch(params, mu, wav, nb, batch, seed, device, masks=True, return_zq=False):
     """On-device generator for benchmark-sized batches (same model, torch RNG).
 
-    Returns (delta, error, zabs, mask) float32/bool tensors on ``device``.
+    Returns (delta, error, zabs, mask) float32/bool tensors on ``device``; with ``return_zq`` also z_qso (batch,).
     """
     import torch
     g = torch.Generator(device=device)
@@ -156,4 +156,6 @@ def make_batch_torch(params, mu, wav, nb, batch, seed, device, masks=True):
         flux = torch.where(mask, flux, torch.full_like(flux, -999.0))
         sigma = torch.where(mask, sigma, torch.full_like(sigma, -999.0))
     delta = flux - mu_t[None, :] * A
+    if return_zq:
+        return delta.contiguous(), sigma.contiguous(), zabs.contiguous(), mask.contiguous(), zq
     return delta.contiguous(), sigma.contiguous(), zabs.contiguous(), mask.contiguous()

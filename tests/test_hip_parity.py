@@ -687,3 +687,49 @@ def test_g13_desi_model(dev):
     for k in ("tau0", "c0", "beta"):
         assert abs(gr[k].item() - float(g[f"g_{k}"])) / abs(float(g[f"g_{k}"])) < 3e-4, k
     assert (gr["F"].cpu().numpy()[~b["mask"][1]] == 0).all()
+
+
+@pytest.mark.parametrize("npix,nh,B,flags", [
+    (200, 16, 70, 0), (97, 9, 33, 0), (1000, 12, 130, 0), (640, 16, 48, _lib.F_PASS2_F32),
+    (640, 16, 48, _lib.F_PASS2_XDL | _lib.F_PASS2_WFORM),                       # k_grads<16> / k_grads_w
+    (1913, 8, 130, 0), (97, 5, 33, 0), (450, 1, 65, 0), (200, 8, 70, _lib.F_PASS2_XDL),      # k_grads<8> / k_grads_x<8>
+    (450, 32, 70, 0), (1000, 20, 130, 0), (31, 17, 5, 0)])                      # k_moments_x<32>, k_s12_x
+def test_factored_z_input_form_matches_zabs_form_and_oracle(dev, npix, nh, B, flags):
+    """ABI v2: qfa_batch_t::zq1 / pix_ratio (1 + zabs[s][i] = zq1[s] pix_ratio[i], reference QFA/dataloader.py:102) through
+    every pass-1 / pass-2 form and the predict call: against the zabs form section by section (same arithmetic up to the
+    rounding of the factors) and against the float64 oracle evaluated on zabs.  zabs = None is accepted with the factors."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    from tools import parity_sections as PS
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=npix + nh)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=7 * npix + nh)
+    m = make_model(dev, p, mu)
+    m.flags = flags
+    bt = batch_t(b, dev)
+    zfac = (torch.tensor(1.0 + b["zqso"].astype(np.float64), device=dev).float(),
+            torch.tensor((wav[:nb] / synthetic.LYA).astype(np.float32), device=dev))
+    nll_z, nll_f = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    acc_z = m.accumulate(*bt, nll=nll_z).clone()
+    acc_f = m.accumulate(bt[0], bt[1], None, bt[3], nll=nll_f, zfac=zfac).clone()
+    assert torch.allclose(nll_z, nll_f, rtol=5e-6, atol=0)
+    for name, sl in PS.sections(m).items():
+        a, r = acc_f[sl].double().cpu().numpy(), acc_z[sl].double().cpu().numpy()
+        if name in ("cnt", "n_blue", "n_spectra"):
+            assert np.array_equal(a, r), name
+        elif a.size == 1:
+            assert abs(a[0] - r[0]) <= 2e-4 * abs(r[0]) + 1e-6, (name, a, r)
+        else:
+            assert rel_l2(a, r) < 2e-5, (name, rel_l2(a, r))
+    loss, g = m._finalize(acc_f, True)
+    ol, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
+    assert abs(loss.item() - ol) <= TOL_NLL * abs(ol)
+    for k in KEYS:
+        ok = ~np.isnan(np.asarray(og[k], dtype=np.float64))
+        assert rel_l2(g[k].cpu().numpy()[ok], np.asarray(og[k])[ok]) < (2e-4 if nh > 16 and k == "F" else TOL_G[k]), k
+    pz = [x.cpu().numpy() for x in m.predict(*batch_t(b, dev, "flux"))]
+    ft = batch_t(b, dev, "flux")
+    pf = [x.cpu().numpy() for x in m.predict(ft[0], ft[1], None, ft[3], zfac=zfac)]
+    for a, r, tol in zip(pf, pz, (5e-6, 2e-5, 2e-5, 2e-6, 5e-6)):
+        assert np.max(np.abs(a - r)) <= tol * np.max(np.abs(r)), tol

@@ -20,14 +20,15 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TRACKED = os.path.join(REPO, "qfa_amd", "libqfa_tracked.so")
 
 
-def run(lib, out, npix, nh, B):
+def run(lib, out, npix, nh, B, form="zabs"):
     env = dict(os.environ)
     if lib:
         env["QFA_HIP_LIB"] = lib
     else:
         env.pop("QFA_HIP_LIB", None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "dump_hot_path.py"), out, str(npix), str(nh), str(B),
-                        "deterministic"], env=env, capture_output=True, text=True, timeout=280)
+                        "deterministic"] + (["zfac"] if form == "zfac" else []), env=env, capture_output=True, text=True,
+                       timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(out)
 
@@ -38,9 +39,10 @@ def run(lib, out, npix, nh, B):
                                        (1100, 24, 300),       # N_h = 24: k_moments_x<32> (two column sweeps per tile),
                                                               # k_s12_x, k_grads_s3, k_predict_x32 (tracked qfa_k32 object)
                                        (2050, 32, 1000)])     # N_h = 32, several work items per block, ragged last tile
-def test_tracked_build_is_bit_identical(tmp_path, npix, nh, B):
+@pytest.mark.parametrize("form", ["zabs", "zfac"])          # zfac: the factored-z input form (other request counts)
+def test_tracked_build_is_bit_identical(tmp_path, npix, nh, B, form):
     assert os.path.exists(TRACKED), "libqfa_tracked.so missing: __graft_entry__.build() / make -C qfa_amd/csrc tracked"
-    a = run(None, str(tmp_path / "shipped.npz"), npix, nh, B)
-    b = run(TRACKED, str(tmp_path / "tracked.npz"), npix, nh, B)
+    a = run(None, str(tmp_path / "shipped.npz"), npix, nh, B, form)
+    b = run(TRACKED, str(tmp_path / "tracked.npz"), npix, nh, B, form)
     for k in a.files:
         assert np.array_equal(a[k], b[k], equal_nan=True), (k, float(np.nanmax(np.abs(a[k] - b[k]))))
