@@ -59,6 +59,7 @@ struct GXT {                                             // KP = 16 (N_h = 9..16
     static constexpr int TILE_B = OFF_FP + 3 * 1024;     // 41 / 23 KiB per 32-pixel tile in global memory
     static constexpr int NCH_HALF = HALF_B / 1024;       // one-KiB DMA pieces per half (+ 3 for the F pieces with h = 1)
     static constexpr int GROW = 16;                      // floats per row of the transposed gamma slot
+    static constexpr int FROW = KP + 4;                  // W form: floats per pixel row of the F block (conflict-free b128 reads)
     static constexpr int NG = 4;                         // groups of 16 spectra per workgroup
     static constexpr int SPB = 16 * NG;                  // spectra per workgroup
     static constexpr int STG_ARR = 16 * 128;             // staging: one array of one tile, [16 rows][32 px] float
@@ -78,6 +79,7 @@ struct GXT {                                             // KP = 16 (N_h = 9..16
     static constexpr int L_TOTAL = L_ZS + NG * 256;
 };
 static_assert(GXT<16>::L_TOTAL <= 160 * 1024 && GXT<8>::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
+static_assert(32 * GXT<16>::FROW * 4 <= 3072, "F block of the W form fits the F slot");
 __device__ __forceinline__ f32x16 xdl32(const u32x4 &a, const u32x4 &b, f32x16 c) {     // 32x32x16
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
                                                    0);
@@ -115,7 +117,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 &h, u32x4 &m, 
 template <int KP>
 __global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, const float *__restrict__ Psi,
                                                   const float *__restrict__ omega, const float4 *__restrict__ ZP,
-                                                  int Npix, int Nb, int Nh, unsigned char *__restrict__ PGX) {
+                                                  int Npix, int Nb, int Nh, int wform, unsigned char *__restrict__ PGX) {
     using GX = GXT<KP>;
     unsigned char *tile = PGX + (size_t)blockIdx.x * GX::TILE_B;
     const int p0 = 32 * blockIdx.x;
@@ -167,7 +169,13 @@ __global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, c
         }
         po[j] = v;
     }
-    if (threadIdx.x < 64) {
+    if (wform) {       // stage 3 in its W form (role B, TERMS = 6): F of the tile as float32 rows [pixel 0..31][FROW]
+        float *fr = reinterpret_cast<float *>(tile + GX::OFF_FP);
+        for (int i = threadIdx.x; i < 32 * GX::FROW; i += 256) {
+            const int px = i / GX::FROW, a = i % GX::FROW;
+            fr[i] = a < KP ? f[px][a] : 0.f;
+        }
+    } else if (threadIdx.x < 64) {
         const int lane = threadIdx.x, r = lane & 31, h2 = lane >> 5;
         float v[8];
 #pragma unroll
@@ -412,19 +420,19 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             }
         };
 
-        // one 16-pixel half of a tile: stage 1 (36 MFMAs on the ring slot of this half), the wait for this tile's spectra
-        // (first half only), stage 2 of the lane's four elements of this half
+        // one 16-pixel half of a tile: stage 1 (36 MFMAs on the ring slot of this half; the per-pixel parameters of the half
+        // are read with it), then stage 2 of the lane's four elements.  (A form that issued stage 1 of half t + 1 beside stage 2
+        // of half t inside the wave -- sched_group_barrier interleave, image requested two half-steps ahead -- was built and
+        // measured in round 3: same results, 2.67 against 2.62 ms at c3: the SIMD issues about one instruction per 4.8 cycles
+        // over BOTH waves, so ordering the streams inside a wave buys nothing; profiles/r3_ablation_pass2.txt.)
+        struct PixA {
+            float Psi, om, ti, pwi, l2i;
+        };
         float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
-        auto halfA = [&](auto blue_tag, int tg, int h, const SpecA &cur, int par, auto &&mid) {
-            constexpr bool BLUE = decltype(blue_tag)::value;
-            const unsigned char *img = lds + GX::L_IMG + h * GX::HALF_B;
-            float *bslot = reinterpret_cast<float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
-            float *gslot = reinterpret_cast<float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
-            float *psum = reinterpret_cast<float *>(lds + GX::L_PSUM + (par * GX::NG + w) * 512);
+        auto stage1A = [&](int slot, f32x4 &ofy, f32x4 &oq, PixA &pp) {
+            const unsigned char *img = lds + GX::L_IMG + slot * GX::HALF_B;
             const unsigned char *bp = img + lane * 16;
             f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
-            // B pieces of K-step ks + 1 are read while the six MFMAs of K-step ks run; the fences keep the compiler
-            // from reading further ahead (every K-step in flight costs 12 registers)
             u32x4 bq[2][3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
@@ -435,18 +443,25 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     for (int pc = 0; pc < 3; ++pc)
                         bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
                 if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
                 else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
-                __builtin_amdgcn_sched_barrier(0);
             }
-            GXS((BLUE ? 0 : 16) + 8 * h + 1)
-            mid();
             const float *po = reinterpret_cast<const float *>(img + GX::S1_HALF);
-            const float Psi = po[lo], om = po[16 + lo];
-            float ti = 0.f, pwi = 0.f, l2i = 0.f;
-            if (BLUE && ZF) { ti = po[32 + lo]; pwi = po[48 + lo]; l2i = po[64 + lo]; }
+            pp.Psi = po[lo]; pp.om = po[16 + lo];
+            pp.ti = pp.pwi = pp.l2i = 0.f;
+            if (ZF) { pp.ti = po[32 + lo]; pp.pwi = po[48 + lo]; pp.l2i = po[64 + lo]; }
+            ofy = afy;
+            oq = aq;
+        };
+        auto stage2A = [&](auto blue_tag, int tg, int h, const SpecA &cur, int par, const f32x4 &afy, const f32x4 &aq,
+                           const PixA &pp) {
+            constexpr bool BLUE = decltype(blue_tag)::value;
+            float *bslot = reinterpret_cast<float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
+            float *gslot = reinterpret_cast<float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
+            float *psum = reinterpret_cast<float *>(lds + GX::L_PSUM + (par * GX::NG + w) * 512);
+            const float Psi = pp.Psi, om = pp.om;
+            const float ti = pp.ti, pwi = pp.pwi, l2i = pp.l2i;
             const int px = 32 * tg + 2 * lo + h;
             const bool inb = px < Npix;
             const bool blue = px < Nb;
@@ -508,12 +523,19 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 if (r & 1) __builtin_amdgcn_sched_barrier(0);      // two elements at a time: bounds the live temporaries
             }
             GXS((BLUE ? 0 : 16) + 8 * h + 2)
+            if constexpr (TERMS == 6) {
+                // W form of stage 3 (role B below): beta and gamma of the lane's four spectra stay in THIS lane's layout --
+                // [half h][lane][4 floats], one 16-byte store each
+                *reinterpret_cast<float4 *>(bslot + (h * 64 + lane) * 4) = float4{betaR[0], betaR[1], betaR[2], betaR[3]};
+                *reinterpret_cast<float4 *>(gslot + (h * 64 + lane) * 4) = float4{gamR[0], gamR[1], gamR[2], gamR[3]};
+            } else {
             // beta[s = 4g + r][pxl = 2 lo + h]
 #pragma unroll
             for (int r = 0; r < 4; ++r) bslot[(4 * g + r) * 32 + 2 * lo + h] = betaR[r];
             // gamma transposed: row rho = 16 h + lo, columns s = 4g .. 4g + 3 (one 16-byte store)
             *reinterpret_cast<float4 *>(gslot + (16 * h + lo) * GX::GROW + 4 * g) =
                 float4{gamR[0], gamR[1], gamR[2], gamR[3]};
+            }
             // per-pixel sums over the wave's 16 spectra (lanes lo + 16 g'): two cross-lane adds, one store per pixel
             // (v_permlane16_swap / v_permlane32_swap: three exchanges and three adds leave quantity g's sum over the
             // four 16-lane rows in row g)
@@ -544,40 +566,39 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         }
         step_barrier();                      // (role B's wait in front of this barrier covers the first image half)
         SpecA cur;
+        f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+        PixA pxp{0.f, 0.f, 0.f, 0.f, 0.f};
         auto tileA = [&](int c, int &cnt_cur, int cnt_other) {
             const bool work = c < n && active;
             const int tg = work ? tile_of(c) : 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (work) {
-                    // Behind stage 1 of the first half (which needs no spectra): the wait for this tile's staged spectra,
-                    // their copy into registers, then the requests for tile c + 2 into the buffer just read.  (At the start
-                    // of a half-step role B's image DMA and flushes fill the CU's address queue and a wave that issues
-                    // behind them stalls until they have drained.  The wait itself is ~200 cycles here against 460 - 1 480
-                    // at the start of the step, but the step does not get shorter: whatever comes first behind the barrier
-                    // absorbs the stall -- measured 2.29 - 2.30 ms either way.)
-                    auto mid = [&]() {
+                    auto spectra = [&]() {
                         if (h != 0) return;
-                        // everything but the requests of tile c + 1 has landed after this
+                        // this tile's staged spectra: everything but the requests of tile c + 1 has landed after the wait;
+                        // copy out, then the requests for tile c + 2 into the buffer just read
                         if (QFA_GX_ABL & 1) {}
                         else if (c + 1 < n && cnt_other == 8) dma_wait<8>();
                         else if (c + 1 < n && cnt_other == 6) dma_wait<6>();
                         else if (c + 1 < n && cnt_other == 14) dma_wait<14>();
                         else dma_wait<0>();
-                        if (tg < nbt) { GXS(5) } else { GXS(21) }
                         take_tile(c & 1, cur);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging buffer read: it may be overwritten now
                         __builtin_amdgcn_sched_barrier(0);
                         cnt_cur = 0;
-                        if (tg < nbt) { GXS(0) } else { GXS(16) }
                         if (c + 2 < n) cnt_cur = stage_tile(tile_of(c + 2), c & 1);
+                        __builtin_amdgcn_sched_barrier(0);
                     };
-                    if (tg < nbt) halfA(std::true_type{}, tg, h, cur, c & 1, mid);
-                    else halfA(std::false_type{}, tg, h, cur, c & 1, mid);
+                    {
+                        stage1A(h, afy, aq, pxp);
+                        __builtin_amdgcn_sched_barrier(0);
+                        spectra();                             // (behind stage 1 of the first half, which needs no spectra)
+                        if (tg < nbt) stage2A(std::true_type{}, tg, h, cur, c & 1, afy, aq, pxp);
+                        else stage2A(std::false_type{}, tg, h, cur, c & 1, afy, aq, pxp);
+                    }
                 }
                 step_barrier();
-                if (work) { if (tg < nbt) { GXS(8 * h + 4) } else { GXS(16 + 8 * h + 4) } }
-                else GXS(31)
             }
         };
         for (int c = 0; c < n + 2; c += 2) {
@@ -614,14 +635,53 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         }
     } else if (QFA_GX_ROLE != 1) {
         // ================================================================ role B: image DMA, flushes, stage 3
+        constexpr bool WB = TERMS == 6;        // stage 3 in its W form (float32 grade); TERMS == 3: the G form (QFA_F_S3_FAST)
+        // ---- W form (qfa_grads_w.h has the derivation): accF[px][b] = sum_a F[px][a] W[px][a][b], W = sum_s Z_s[a][b] beta[s][px]
+        // as a K = spectrum GEMM per column tile a: A = static Z pieces (row m = b = lane & 15; k = 8 g + j <-> spectrum
+        // 4 g + (j & 3), piece slot j >> 2), B = the lane's own four beta values as {h|l}, {m|m}, {h|h}: three INDEPENDENT
+        // short chains per column tile instead of six dependent 32x32x16 MFMAs per spectrum pair -- role B alone ran 2.75 ms
+        // at c3 in the six-product G form (latency of the dependent chain), against 1.1 ms with three.
+        const int loB = lane & 15, gB = lane >> 4;
+        u32x4 ZA1[WB ? KP : 1], ZA2[WB ? KP : 1], PA1 = {0u, 0u, 0u, 0u}, PA2 = {0u, 0u, 0u, 0u};
+        if constexpr (WB) {
+            const float *solr[4];
+            bool vr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sidx = s0 + 4 * gB + r;
+                vr[r] = active && sidx < B && loB < Nh && loB < KP;
+                solr[r] = SOL + (size_t)(vr[r] ? sidx : 0) * C::NSOL;
+            }
+#pragma unroll
+            for (int a = 0; a < KP; ++a) {
+                float x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = vr[r] ? solr[r][C::SOL_Z + a * KP + (loB & (KP - 1))] : 0.f;
+                unsigned h01, m01, l01, h23, m23, l23;
+                split2(x[0], x[1], h01, m01, l01);
+                split2(x[2], x[3], h23, m23, l23);
+                ZA1[a] = u32x4{l01, l23, h01, h23};
+                ZA2[a] = u32x4{h01, h23, m01, m23};
+            }
+            float x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = vr[r] ? solr[r][C::SOL_P + (loB & (KP - 1))] : 0.f;
+            unsigned h01, m01, l01, h23, m23, l23;
+            split2(x[0], x[1], h01, m01, l01);
+            split2(x[2], x[3], h23, m23, l23);
+            PA1 = u32x4{l01, l23, h01, h23};
+            PA2 = u32x4{h01, h23, m01, m23};
+        }
+        // ---- G form (TERMS == 3)
         // One stage-3 MFMA (32 px x 32 columns x K = 16) covers the columns of 32 / KP spectra: a pair at KP = 16, four
         // spectra at KP = 8 (where only k < 8 carries data).  Column col = (spectrum sc = col / KP, b = col % KP).
         constexpr int SPM = 32 / KP, NMG = 16 / SPM;       // spectra per MFMA, MFMA groups per wave (8 pairs / 4 fours)
         const int col = lane & 31, h2 = lane >> 5, b = lane & (KP - 1), sc = col / KP, sp = (lane >> 4) & 1;
         const int tidB = tid & 255;                        // 0..255 over the four role-B waves
         // B operands: Z of group m: B[k = a = 8 h2 + j][col = (sc, b)] = Z_{SPM m + sc}[a][b]
-        u32x4 Zh[NMG], Zm[NMG], Zl[NMG], Ph, Pm, Pl;
-        {
+        constexpr int NMGA = WB ? 1 : NMG;
+        u32x4 Zh[NMGA], Zm[NMGA], Zl[NMGA], Ph = {0u, 0u, 0u, 0u}, Pm = Ph, Pl = Ph;
+        if constexpr (!WB) {
 #pragma unroll
             for (int m = 0; m < NMG; ++m) {
                 const int s = s0 + SPM * m + sc;
@@ -644,21 +704,25 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         }
         // LDS-DMA of half-step t = 2 c + h: the stage-1 image + Psi/omega of that half into ring slot h, and with the
         // second half the F pieces of the tile into the F ring; wave w moves the 1-KiB pieces w, w + 4, ...
-        auto get_half = [&](int t) {
+        // (role A runs stage 1 of half t + 1 during half-step t: the image of half t + 2 is requested at the start of
+        // half-step t into the slot half t was read from in half-step t - 1; the F block of tile c with its second half-step)
+        auto get_img = [&](int t) {
             if ((QFA_GX_ABL & 4) && t > 1) return;
             const int c = t >> 1, h = t & 1;
             const unsigned char *sbase = uniform_ptr(PGX + (size_t)tile_of(c) * GX::TILE_B);
             unsigned char *img = lds + GX::L_IMG + h * GX::HALF_B;
-            unsigned char *fp = lds + GX::L_FP + (c & 1) * 3072;
 #pragma unroll
-            for (int i = 0; i < (GX::NCH_HALF + 3 + GX::NG - 1) / GX::NG; ++i) {
+            for (int i = 0; i < (GX::NCH_HALF + GX::NG - 1) / GX::NG; ++i) {
                 const int ch = w + GX::NG * i;
                 if (ch < GX::NCH_HALF)
                     glds16a(sbase + h * GX::HALF_B + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(img + ch * 1024)));
-                else if (h == 1 && ch < GX::NCH_HALF + 3)
-                    glds16a(sbase + GX::OFF_FP + (ch - GX::NCH_HALF) * 1024, (unsigned)lane * 16u,
-                            wave_uniform(lds_addr(fp + (ch - GX::NCH_HALF) * 1024)));
             }
+        };
+        auto get_F = [&](int c) {
+            if ((QFA_GX_ABL & 4) && c > 0) return;
+            const unsigned char *sbase = uniform_ptr(PGX + (size_t)tile_of(c) * GX::TILE_B);
+            unsigned char *fp = lds + GX::L_FP + (c & 1) * 3072;
+            if (w < 3) glds16a(sbase + GX::OFF_FP + w * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(fp + w * 1024)));
         };
         // Every lane of a flushing wave issues its request: the number of requests per wave is then a constant, which
         // the counted wait below needs.  Default mode (float atomics): a lane outside the arrays adds 0 to an element
@@ -721,6 +785,55 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         auto tileB = [&](int c, auto part_tag) {
             constexpr int PART = decltype(part_tag)::value;
             const int par = c & 1;
+            if constexpr (WB) {
+                // half PART of tile c: beta / gamma of the lane's four spectra (pixel 2 lo + PART) as role A left them
+                const float *bsl = reinterpret_cast<const float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
+                const float *gsl = reinterpret_cast<const float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
+                const float4 b4 = *reinterpret_cast<const float4 *>(bsl + (PART * 64 + lane) * 4);
+                const float4 g4 = *reinterpret_cast<const float4 *>(gsl + (PART * 64 + lane) * 4);
+                const float *frow = reinterpret_cast<const float *>(lds + GX::L_FP + (c & 1) * 3072) + (2 * loB + PART) * GX::FROW;
+                float fa[KP];
+#pragma unroll
+                for (int a4 = 0; a4 < KP / 4; ++a4) {
+                    const float4 f4 = *reinterpret_cast<const float4 *>(frow + 4 * a4);
+                    fa[4 * a4] = f4.x; fa[4 * a4 + 1] = f4.y; fa[4 * a4 + 2] = f4.z; fa[4 * a4 + 3] = f4.w;
+                }
+                unsigned h01, m01, l01, h23, m23, l23;
+                split2(b4.x, b4.y, h01, m01, l01);
+                split2(b4.z, b4.w, h23, m23, l23);
+                const u32x4 bhl = {h01, h23, l01, l23}, bmm = {m01, m23, m01, m23}, bhh = {h01, h23, h01, h23};
+                split2(g4.x, g4.y, h01, m01, l01);
+                split2(g4.z, g4.w, h23, m23, l23);
+                const u32x4 ghl = {h01, h23, l01, l23}, gmm = {m01, m23, m01, m23}, ghh = {h01, h23, h01, h23};
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = xdl(PA2, ghh, xdl(PA2, gmm, xdl(PA1, ghl, zero)));       // sum_s p_s[b] gamma[s][px]
+                // column tiles in chunks of four: twelve MFMAs in flight (independent chains of three), the FMAs of a chunk
+                // behind the MFMAs of the next
+                f32x4 Wc[2][4];
+#pragma unroll
+                for (int ch = 0; ch <= KP / 4; ++ch) {
+                    if (ch < KP / 4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int a = 4 * ch + j;
+                            Wc[ch & 1][j] = xdl(ZA2[a], bhh, xdl(ZA2[a], bmm, xdl(ZA1[a], bhl, zero)));
+                        }
+                    }
+                    if (ch > 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int a = 4 * (ch - 1) + j;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa[a], Wc[(ch - 1) & 1][j][r], acc[r]);
+                        }
+                    }
+                }
+                // the lane holds accF[px = 2 lo + PART][b = 4 g + r] of its group: one 16-byte store into the group's slot
+                float *part = reinterpret_cast<float *>(lds + GX::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
+                if (KP == 16 || gB < KP / 4)
+                    *reinterpret_cast<float4 *>(part + (2 * loB + PART) * KP + 4 * gB) = float4{acc[0], acc[1], acc[2], acc[3]};
+                return;
+            }
             const unsigned char *fp = lds + GX::L_FP + (c & 1) * 3072 + lane * 16;
             const float *bslot = reinterpret_cast<const float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
             const float *gslot = reinterpret_cast<const float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
@@ -775,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #if QFA_GX_BPRIO && QFA_GX_BPRIO < 4
         __builtin_amdgcn_s_setprio(QFA_GX_BPRIO);
 #endif
-        if (n > 0) get_half(0);
+        if (n > 0) get_img(0);
         dma_wait<0>();
         step_barrier();
         for (int c = 0; c < n + 2; ++c) {
@@ -789,7 +902,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 const int t = 2 * c + h;
                 // The image DMA first, the flushes behind it, and a wait that leaves exactly the flushes in flight: they
                 // are device-scope atomics with a long round trip, and have until the end of the NEXT half-step.
-                if (t + 1 < 2 * n) get_half(t + 1);
+                if (t + 1 < 2 * n) get_img(t + 1);
+                if (h == 1 && c < n) get_F(c);
                 // requests of this wave's flushes (wave-uniform): F 2 (one as a 16-byte store, waves 0 and 1), P 1
                 const bool wP = wide ? tidB >= 128 : tidB < 128, wF = !wide || tidB < NWIDE;
                 const int nreq = (h == 0 && c >= 1 && c <= n && wP ? 1 : 0) +
