@@ -400,7 +400,7 @@ def main():
     if nh > 16:
         p2_name = "k_s12_x+2*k_grads_s3"      # pass 2 at N_h = 17..32: three launches, timed together by the stage events
     else:                                     # the same rule as pass2_use_xdl (qfa_host.h)
-        xdl_form = False if (fl & 0x1) else (True if (fl & 0x2) else nh > 8)
+        xdl_form = False if (fl & 0x1) else (True if (fl & 0x2) else (nh > 8 or B >= 96 * torch.cuda.get_device_properties(dev).multi_processor_count))
         p2_name = ("k_grads_w" if (fl & 0x10) else "k_grads_x") if xdl_form else "k_grads"
     dominant = p2_name if ms_p2 >= ms_p1 else "k_moments_x"
     dom_ms, dom_flops = (ms_p2, f2) if dominant == p2_name else (ms_p1, f1)

@@ -179,18 +179,18 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
     return 0;
 }
 
-// Which form of pass 2 runs at N_h <= 16 (KP = 8 or 16): the all-XDL form (k_grads_x) or the float32-MFMA form
-// (k_grads, the only one for N_h = 17..32).  Default, from measurements on MI355X (profiles/r2_ablation_k_grads_x.txt):
-//   KP = 16: k_grads_x -- 2.4-2.6 ms at c3 against 3.2, and no slower at any batch size down to 64 spectra;
-//   KP = 8 : k_grads   -- k_grads_x<8> is correct (same tests) but slower there (0.22 against 0.17 ms at c2, 2.3 against
-//            1.8 ms at 160 000 x 2000): its tile step is bound by the VALU work of stage 2 and the hand-overs, which
-//            do not shrink with N_h, while k_grads runs two workgroups per CU.
+// Which form of pass 2 runs at N_h <= 16 (KP = 8 or 16): the all-XDL two-role form (k_grads_x) or the float32-MFMA form
+// (k_grads, the only one for N_h = 17..32).  Default, from measurements on MI355X (profiles/r3_ablation_pass2.txt):
+//   KP = 16: k_grads_x -- 2.5 - 2.6 ms at c3 against 3.2, and no slower at any batch size down to 64 spectra;
+//   KP = 8 : k_grads_x once the batch fills the chip (one workgroup of 64 spectra per CU, >= 1.5 rounds): 1.51 against 2.11 ms
+//            at the DESI shape (40 000 x 9243), 0.040 / 0.044 at the reference's default batch of 500; k_grads (two
+//            workgroups per CU) below that: 0.174 against 0.197 ms at c2 (10 000 x 2000).
 // QFA_F_PASS2_F32 / QFA_F_PASS2_XDL in the call's `flags` force one form (A/B timing and the cross-check of the two
 // forms in tests/).
-inline bool pass2_use_xdl(int KP, unsigned flags) {
+inline bool pass2_use_xdl(int KP, int B, unsigned flags) {
     if (flags & QFA_F_PASS2_F32) return false;
     if (flags & QFA_F_PASS2_XDL) return true;
-    return KP == 16;
+    return KP == 16 || B >= 96 * cu_count();
 }
 
 // launch errors of the calls just made; with QFA_F_SYNC also the asynchronous ones (the stream is drained first)
@@ -308,7 +308,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         if (events && events[i]) (void)hipEventRecord((hipEvent_t)events[i], st);
     };
     bool pass2_xdl = false;
-    if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP, flags);
+    if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP, B, flags);
     mark(0);
     const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
     // the float32 images PF / PFT serve k_moments (N_h > 16) and k_grads: not needed when both passes run on the XDL pipe
