@@ -425,7 +425,12 @@ def main():
             tj = json.load(open(tfile))
             if tj.get("B") == B:
                 traffic = tj.get(dominant.replace("k_moments_x", "k_moments") + "_hbm_bytes_per_launch")
-                traffic_step = sum(v for kk, v in tj.items() if kk.endswith("_hbm_bytes_per_launch"))
+                p2key = {"k_grads_w": "k_grads_x"}.get(p2_name, p2_name)
+                parts = [tj.get(kk + "_hbm_bytes_per_launch") for kk in ("k_moments", "k_solve", p2key)]
+                traffic_step = sum(parts) if all(x is not None for x in parts) else None
+                if fz is not None and all((kk + "_hbm_bytes_per_launch") in tj for kk in ("k_moments_x_zfac", "k_grads_x_zfac", "k_solve")):
+                    fz["measured_hbm_bytes_per_step"] = sum(tj[kk + "_hbm_bytes_per_launch"] for kk in ("k_moments_x_zfac", "k_grads_x_zfac", "k_solve"))
+                    fz["traffic_ratio"] = fz["measured_hbm_bytes_per_step"] / (fz["alg_bytes_per_spectrum"] * B)
         except Exception:
             traffic = None
     if xdl_flops:

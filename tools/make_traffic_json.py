@@ -6,14 +6,20 @@ summary, cfg, B, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 cur, vals = None, {}
 for line in open(summary):
     if not line.startswith(" "):
-        cur = line.strip().split("<")[0]
+        name = line.strip()
+        cur = name.split("<")[0]
+        # the factored-z instantiations (last template argument `true` of k_grads_x / k_moments_x) are kept apart
+        if cur in ("k_grads_x", "k_moments_x") and name.rstrip(">").endswith("true"):
+            cur += "_zfac"
+        if cur == "k_moments_x" and ", true, 4" in name:      # the prediction instantiation of pass 1
+            cur = "k_moments_x_predict"
         vals.setdefault(cur, {})
     else:
         m = re.match(r"\s+(\S+)\s+mean/dispatch\s+(\S+)", line)
         if m: vals[cur][m.group(1)] = float(m.group(2))
 res = {"config": cfg, "B": B, "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ*); "
        "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; check: TCC_EA0_RDREQ_128B*128"}
-for k in ("k_grads", "k_grads_x", "k_moments", "k_solve"):
+for k in ("k_grads", "k_grads_x", "k_moments", "k_solve", "k_grads_x_zfac", "k_moments_x_zfac"):
     v = vals.get(k, {})
     if k == "k_moments" and "k_moments_x" in vals:      # pass 1 on the XDL pipe (N_h <= 16)
         v = vals["k_moments_x"]
