@@ -63,22 +63,35 @@ struct GXT {                                             // KP = 16 (N_h = 9..16
     static constexpr int NG = 4;                         // groups of 16 spectra per workgroup
     static constexpr int SPB = 16 * NG;                  // spectra per workgroup
     static constexpr int STG_ARR = 16 * 128;             // staging: one array of one tile, [16 rows][32 px] float
-    static constexpr int STG_MASK = 3 * STG_ARR;         // mask bytes [16 rows][32 px]
-    static constexpr int STG_B = 3 * STG_ARR + 512;      // delta | sigma | zabs | mask (6.5 KiB per wave and tile)
     static constexpr int PARTF = 32 * KP;                // floats of one group's stage-3 sums of a tile: [32 px][KP b]
-    // LDS (bytes), per workgroup
-    static constexpr int L_IMG = 0;                                  // [2 halves][HALF_B]
-    static constexpr int L_FP = L_IMG + 2 * HALF_B;                  // [2 tile parity][3 KiB]
+};
+// LDS of k_grads_x (bytes per workgroup).  ZF (factored-z input form): no zabs staging (two arrays instead of three: 139 KiB).
+// QFA_GX_RING3=1 spends the freed space on a THIRD image slot (image of half t + 2 requested during half-step t, role B's wait
+// in front of a barrier leaves a whole half-step's requests in flight): built, bit-identical results, and SLOWER -- 2.70 against
+// 2.60 ms at c3 on one box, twice (profiles/r3_ablation_pass2.txt) -- so two slots stay the default.
+template <int KP, bool ZF>
+struct GXL : GXT<KP> {
+    using G = GXT<KP>;
+    static constexpr int NG = G::NG;
+#ifndef QFA_GX_RING3
+#define QFA_GX_RING3 0        // 1: three image slots in the factored-z form (measured slower)
+#endif
+    static constexpr int RING = (ZF && QFA_GX_RING3) ? 3 : 2;   // image slots (halves)
+    static constexpr int NARR = ZF ? 2 : 3;              // staged float arrays: delta, sigma (, zabs)
+    static constexpr int STG_MASK = NARR * G::STG_ARR;   // mask bytes [16 rows][32 px]
+    static constexpr int STG_B = NARR * G::STG_ARR + 512;  // 6.5 / 4.5 KiB per wave and tile
+    static constexpr int L_IMG = 0;                                  // [RING halves][HALF_B]
+    static constexpr int L_FP = L_IMG + RING * G::HALF_B;            // [2 tile parity][3 KiB]
     static constexpr int L_BETA = L_FP + 2 * 3072;                   // [2 tile parity][NG][16 s][32 px] float
     static constexpr int L_GAM = L_BETA + 2 * NG * 2048;             // [2][NG][32 rows][GROW] float
-    static constexpr int L_PART = L_GAM + 2 * NG * 32 * GROW * 4;    // [2][NG][32 px][KP b] float
-    static constexpr int L_PSUM = L_PART + 2 * NG * PARTF * 4;       // [2][NG][4 sums][32 px] float (summed over the wave)
+    static constexpr int L_PART = L_GAM + 2 * NG * 32 * G::GROW * 4; // [2][NG][32 px][KP b] float
+    static constexpr int L_PSUM = L_PART + 2 * NG * G::PARTF * 4;    // [2][NG][4 sums][32 px] float (summed over the wave)
     static constexpr int L_SCAL = L_PSUM + 2 * NG * 512;             // [NG waves][3 sums][64 lanes] double (role A)
     static constexpr int L_STG = L_SCAL + NG * 3 * 64 * 8;           // [NG waves][2 tile parity][STG_B]
     static constexpr int L_ZS = L_STG + NG * 2 * STG_B;              // [NG waves][16 spectra] float4: factored-z per-spectrum factors
     static constexpr int L_TOTAL = L_ZS + NG * 256;
 };
-static_assert(GXT<16>::L_TOTAL <= 160 * 1024 && GXT<8>::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
+static_assert(GXL<16, false>::L_TOTAL <= 160 * 1024 && GXL<16, true>::L_TOTAL <= 160 * 1024 && GXL<8, true>::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
 static_assert(32 * GXT<16>::FROW * 4 <= 3072, "F block of the W form fits the F slot");
 __device__ __forceinline__ f32x16 xdl32(const u32x4 &a, const u32x4 &b, f32x16 c) {     // 32x32x16
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -224,7 +237,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                                                     int slab_stride, Scal64 *__restrict__ sc64) {
     using C = Cfg<KP>;
     using GX = GXT<KP>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[GX::L_TOTAL];
+    using L = GXL<KP, ZF>;              // LDS layout (the factored-z form has a third image slot)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[L::L_TOTAL];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv8 = wave_uniform(tid >> 6);               // 0..7
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
     float *accS = accum + (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
 
     // zero the slots that inactive groups never write
-    for (int i = tid; i < (GX::L_SCAL - GX::L_BETA) / 4; i += 512) reinterpret_cast<float *>(lds + GX::L_BETA)[i] = 0.f;
+    for (int i = tid; i < (L::L_SCAL - L::L_BETA) / 4; i += 512) reinterpret_cast<float *>(lds + L::L_BETA)[i] = 0.f;
 
     // de-phase the tile order between workgroups (concurrent flushes then hit different rows; the workgroups running
     // together still share a window of the image in L2)
@@ -316,11 +330,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         const float *zbase = ZF ? dbase : uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
         const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
         // factored-z form: the per-spectrum factors of the wave's 16 spectra in LDS (this role has no registers to spare)
-        float4 *zsl = reinterpret_cast<float4 *>(lds + GX::L_ZS + w * 256);
+        float4 *zsl = reinterpret_cast<float4 *>(lds + L::L_ZS + w * 256);
         if (ZF && lane < 16) zsl[lane] = (active && s0 + lane < B) ? ZS[s0 + lane] : float4{0.f, 0.f, 0.f, 0.f};
         // scalar-gradient sums: float32 inside a tile, float64 across tiles -- the float64 running sums live in LDS
         // (three doubles per lane), not in six registers
-        double *scal = reinterpret_cast<double *>(lds + GX::L_SCAL) + (size_t)w * 3 * 64 + lane;
+        double *scal = reinterpret_cast<double *>(lds + L::L_SCAL) + (size_t)w * 3 * 64 + lane;
         scal[0] = 0.0; scal[64] = 0.0; scal[128] = 0.0;
 
         // ---- spectra of one tile for this wave: LDS-DMA of the 128-byte row segments of delta, sigma, zabs and of the
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         //    0   the ragged last tile of the pixel axis: everything as clamped 4-byte pieces, masks through registers.
         // The third array is staged for EVERY tile so that the counts are fixed: red tiles re-request their delta rows
         // there (hits in the vector cache, values unused).  No request reads past the end of a row.
-        unsigned char *stg = lds + GX::L_STG + w * 2 * GX::STG_B;
+        unsigned char *stg = lds + L::L_STG + w * 2 * L::STG_B;
         auto stage_tile = [&](int tg, int par) -> int {
             if (QFA_GX_ABL & 1) return 8;
             if (QFA_GX_ABL & 8) tg = t0;
@@ -343,11 +357,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             const bool fastp = 32 * tg + 31 < Npix, fastz = ZF || !zblue || 32 * tg + 31 < Nb;
             const float *zb = (zblue && !(QFA_GX_ABL & 16)) ? zbase : dbase;
             const int zlen = (zblue && !(QFA_GX_ABL & 16)) ? Nb : Npix;
-            const unsigned dst = wave_uniform(lds_addr(stg + par * GX::STG_B));
+            const unsigned dst = wave_uniform(lds_addr(stg + par * L::STG_B));
 #if QFA_TRACKED_LOADS
             {   // test build: ordinary loads and LDS stores for all four arrays (two rows per pass), no counted wait
-                float *sf = reinterpret_cast<float *>(stg + par * GX::STG_B);
-                unsigned char *mb = stg + par * GX::STG_B + GX::STG_MASK;
+                float *sf = reinterpret_cast<float *>(stg + par * L::STG_B);
+                unsigned char *mb = stg + par * L::STG_B + L::STG_MASK;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int q = 2 * i + (lane >> 5), pxl = lane & 31;
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     glds16a(dbase, 4u * o, dst + 0 * GX::STG_ARR + i * 1024);
                     glds16a(ebase, 4u * o, dst + 1 * GX::STG_ARR + i * 1024);
                     if (!ZF && fastz) glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * GX::STG_ARR + i * 1024);
-                    glds4a(mbase, o, dst + GX::STG_MASK + i * 256);
+                    glds4a(mbase, o, dst + L::STG_MASK + i * 256);
                 }
                 if (fastz) return ZF ? 6 : 8;
             }
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             }
             if (fastp) return 14;
             // masks of the ragged tile: ordinary loads (hipcc waits for them by itself) and byte stores
-            unsigned char *mb = stg + par * GX::STG_B + GX::STG_MASK;
+            unsigned char *mb = stg + par * L::STG_B + L::STG_MASK;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int q = 2 * i + (lane >> 5);
@@ -405,8 +419,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         // copy the lane's 4 spectra x 2 pixels of the staged tile into registers; the mask goes into the sign of sigma
         // (only sigma^2 is ever used: sign bit set means "masked" from here on)
         auto take_tile = [&](int par, SpecA &cur) {
-            const unsigned char *sb = stg + par * GX::STG_B + 8 * lo;
-            const unsigned char *mb = stg + par * GX::STG_B + GX::STG_MASK + 2 * lo;
+            const unsigned char *sb = stg + par * L::STG_B + 8 * lo;
+            const unsigned char *mb = stg + par * L::STG_B + L::STG_MASK + 2 * lo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int slot = 4 * g + (r ^ (g & 1));
@@ -430,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         };
         float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
         auto stage1A = [&](int slot, f32x4 &ofy, f32x4 &oq, PixA &pp) {
-            const unsigned char *img = lds + GX::L_IMG + slot * GX::HALF_B;
+            const unsigned char *img = lds + L::L_IMG + slot * GX::HALF_B;
             const unsigned char *bp = img + lane * 16;
             f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
             u32x4 bq[2][3];
@@ -457,9 +471,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         auto stage2A = [&](auto blue_tag, int tg, int h, const SpecA &cur, int par, const f32x4 &afy, const f32x4 &aq,
                            const PixA &pp) {
             constexpr bool BLUE = decltype(blue_tag)::value;
-            float *bslot = reinterpret_cast<float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
-            float *gslot = reinterpret_cast<float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
-            float *psum = reinterpret_cast<float *>(lds + GX::L_PSUM + (par * GX::NG + w) * 512);
+            float *bslot = reinterpret_cast<float *>(lds + L::L_BETA + (par * GX::NG + w) * 2048);
+            float *gslot = reinterpret_cast<float *>(lds + L::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
+            float *psum = reinterpret_cast<float *>(lds + L::L_PSUM + (par * GX::NG + w) * 512);
             const float Psi = pp.Psi, om = pp.om;
             const float ti = pp.ti, pwi = pp.pwi, l2i = pp.l2i;
             const int px = 32 * tg + 2 * lo + h;
@@ -591,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     {
-                        stage1A(h, afy, aq, pxp);
+                        stage1A((2 * c + h) % L::RING, afy, aq, pxp);
                         __builtin_amdgcn_sched_barrier(0);
                         spectra();                             // (behind stage 1 of the first half, which needs no spectra)
                         if (tg < nbt) stage2A(std::true_type{}, tg, h, cur, c & 1, afy, aq, pxp);
@@ -704,13 +718,13 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         }
         // LDS-DMA of half-step t = 2 c + h: the stage-1 image + Psi/omega of that half into ring slot h, and with the
         // second half the F pieces of the tile into the F ring; wave w moves the 1-KiB pieces w, w + 4, ...
-        // (role A runs stage 1 of half t + 1 during half-step t: the image of half t + 2 is requested at the start of
-        // half-step t into the slot half t was read from in half-step t - 1; the F block of tile c with its second half-step)
+        // (the image of half t + AHEAD is requested at the start of half-step t; the F block of tile c with its first half-step:
+        // stage 3 of tile c reads it during tile c + 1)
         auto get_img = [&](int t) {
             if ((QFA_GX_ABL & 4) && t > 1) return;
             const int c = t >> 1, h = t & 1;
             const unsigned char *sbase = uniform_ptr(PGX + (size_t)tile_of(c) * GX::TILE_B);
-            unsigned char *img = lds + GX::L_IMG + h * GX::HALF_B;
+            unsigned char *img = lds + L::L_IMG + (t % L::RING) * GX::HALF_B;
 #pragma unroll
             for (int i = 0; i < (GX::NCH_HALF + GX::NG - 1) / GX::NG; ++i) {
                 const int ch = w + GX::NG * i;
@@ -721,7 +735,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         auto get_F = [&](int c) {
             if ((QFA_GX_ABL & 4) && c > 0) return;
             const unsigned char *sbase = uniform_ptr(PGX + (size_t)tile_of(c) * GX::TILE_B);
-            unsigned char *fp = lds + GX::L_FP + (c & 1) * 3072;
+            unsigned char *fp = lds + L::L_FP + (c & 1) * 3072;
             if (w < 3) glds16a(sbase + GX::OFF_FP + w * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(fp + w * 1024)));
         };
         // Every lane of a flushing wave issues its request: the number of requests per wave is then a constant, which
@@ -737,7 +751,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         constexpr int NWIDE = 8 * KP;                      // threads of the 16-byte form: 128 (waves 0, 1) / 64 (wave 0)
         auto flush_F = [&](int tg, int par) {
             if (QFA_GX_ABL & 2) return;
-            const float *pp = reinterpret_cast<const float *>(lds + GX::L_PART + par * GX::NG * GX::PARTF * 4);
+            const float *pp = reinterpret_cast<const float *>(lds + L::L_PART + par * GX::NG * GX::PARTF * 4);
             if (wide) {
                 if (tidB >= NWIDE) return;                                            // wave-uniform
                 const int pxl = tidB / (KP / 4), b4 = 4 * (tidB % (KP / 4));
@@ -768,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             if (QFA_GX_ABL & 2) return;
             if (wide ? tidB < 128 : tidB >= 128) return;                              // wave-uniform (waves 2, 3 / 0, 1)
             const int which = (tidB >> 5) & 3, pxl = tidB & 31;
-            const float *q = reinterpret_cast<const float *>(lds + GX::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
+            const float *q = reinterpret_cast<const float *>(lds + L::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
             float v = (QFA_GX_ABL & 64) ? 1.f : (q[0] + q[128]) + (q[256] + q[384]);
             if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); return; }
             const int px = 32 * tg + pxl;
@@ -787,11 +801,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             const int par = c & 1;
             if constexpr (WB) {
                 // half PART of tile c: beta / gamma of the lane's four spectra (pixel 2 lo + PART) as role A left them
-                const float *bsl = reinterpret_cast<const float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
-                const float *gsl = reinterpret_cast<const float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
+                const float *bsl = reinterpret_cast<const float *>(lds + L::L_BETA + (par * GX::NG + w) * 2048);
+                const float *gsl = reinterpret_cast<const float *>(lds + L::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
                 const float4 b4 = *reinterpret_cast<const float4 *>(bsl + (PART * 64 + lane) * 4);
                 const float4 g4 = *reinterpret_cast<const float4 *>(gsl + (PART * 64 + lane) * 4);
-                const float *frow = reinterpret_cast<const float *>(lds + GX::L_FP + (c & 1) * 3072) + (2 * loB + PART) * GX::FROW;
+                const float *frow = reinterpret_cast<const float *>(lds + L::L_FP + (c & 1) * 3072) + (2 * loB + PART) * GX::FROW;
                 float fa[KP];
 #pragma unroll
                 for (int a4 = 0; a4 < KP / 4; ++a4) {
@@ -829,15 +843,15 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     }
                 }
                 // the lane holds accF[px = 2 lo + PART][b = 4 g + r] of its group: one 16-byte store into the group's slot
-                float *part = reinterpret_cast<float *>(lds + GX::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
+                float *part = reinterpret_cast<float *>(lds + L::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
                 if (KP == 16 || gB < KP / 4)
                     *reinterpret_cast<float4 *>(part + (2 * loB + PART) * KP + 4 * gB) = float4{acc[0], acc[1], acc[2], acc[3]};
                 return;
             }
-            const unsigned char *fp = lds + GX::L_FP + (c & 1) * 3072 + lane * 16;
-            const float *bslot = reinterpret_cast<const float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
-            const float *gslot = reinterpret_cast<const float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
-            float *part = reinterpret_cast<float *>(lds + GX::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
+            const unsigned char *fp = lds + L::L_FP + (c & 1) * 3072 + lane * 16;
+            const float *bslot = reinterpret_cast<const float *>(lds + L::L_BETA + (par * GX::NG + w) * 2048);
+            const float *gslot = reinterpret_cast<const float *>(lds + L::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
+            float *part = reinterpret_cast<float *>(lds + L::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
             const u32x4 Fh = *reinterpret_cast<const u32x4 *>(fp), Fm = *reinterpret_cast<const u32x4 *>(fp + 1024),
                         Fl = *reinterpret_cast<const u32x4 *>(fp + 2048);
             f32x16 zero;
@@ -888,9 +902,15 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #if QFA_GX_BPRIO && QFA_GX_BPRIO < 4
         __builtin_amdgcn_s_setprio(QFA_GX_BPRIO);
 #endif
-        if (n > 0) get_img(0);
+        constexpr int AHEAD = L::RING - 1;                 // half-steps between the request of an image half and its first read
+        if (n > 0) {
+            get_img(0);
+            if (AHEAD == 2) get_img(1);
+        }
         dma_wait<0>();
         step_barrier();
+        // requests of this wave for one image half / one F block (the counted wait leaves a whole half-step's requests in flight)
+        const int n_img = (GX::NCH_HALF - w + GX::NG - 1) / GX::NG, n_fp = w < 3 ? 1 : 0;
         for (int c = 0; c < n + 2; ++c) {
 #if QFA_GX_BPRIO == 4
             // this role is the slower one while role A works on a red tile, and the faster one on a blue tile
@@ -902,8 +922,10 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 const int t = 2 * c + h;
                 // The image DMA first, the flushes behind it, and a wait that leaves exactly the flushes in flight: they
                 // are device-scope atomics with a long round trip, and have until the end of the NEXT half-step.
-                if (t + 1 < 2 * n) get_img(t + 1);
-                if (h == 1 && c < n) get_F(c);
+                int n_dma = 0;                             // image / F requests issued in THIS half-step
+                if (t + AHEAD < 2 * n) { get_img(t + AHEAD); n_dma += n_img; }
+                if (h == 0 && c < n) { get_F(c); n_dma += n_fp; }      // (first read in half-step 2 c + 2: landed behind the wait of 2 c + 1)
+                if (QFA_GX_ABL & 4) n_dma = 0;
                 // requests of this wave's flushes (wave-uniform): F 2 (one as a 16-byte store, waves 0 and 1), P 1
                 const bool wP = wide ? tidB >= 128 : tidB < 128, wF = !wide || tidB < NWIDE;
                 const int nreq = (h == 0 && c >= 1 && c <= n && wP ? 1 : 0) +
@@ -919,6 +941,12 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 }
                 GXS(8 * h + 1)
                 if (QFA_GX_ABL & 2) dma_wait<0>();
+                else if (AHEAD == 2) {
+                    // three image slots: what this half-step requested (image of half t + 2, F block, flushes) may stay in
+                    // flight; everything older -- the image of half t + 1, the F block requested one half-step earlier --
+                    // has landed behind this wait
+                    dma_wait_n(n_dma + nreq);
+                }
                 else if (nreq == 3) dma_wait<3>();
                 else if (nreq == 2) dma_wait<2>();
                 else if (nreq == 1) dma_wait<1>();
