@@ -40,7 +40,7 @@
 // and behind them the flush atomics, which a counted vmcnt in front of the barrier leaves in flight for one more
 // half-step.  Nothing on the hot path loads into registers through asm (an earlier form did, and hipcc moved copies
 // of such registers in front of the wait; tools/audit_asm_loads.py still checks the compiled code for that), and
-// `make check-gx` fails on any scratch use (spilled loop-carried registers came
+// `make` fails on any scratch use (audit of the shipped objects' assembly) (spilled loop-carried registers came
 // back wrong from run to run in an earlier build -- tools/diag_slab.py).
 #pragma once
 #include "qfa_common.h"

@@ -1,5 +1,5 @@
 """The two build-time audits of the generated assembly (tools/audit_mfma_overlap.py, tools/audit_asm_loads.py; run by
-`make check` / __graft_entry__.build()) on hand-written snippets: each must flag the pattern it exists for and pass
+`make` -- the library does not link unless both pass -- and so by __graft_entry__.build()) on hand-written snippets: each must flag the pattern it exists for and pass
 the harmless neighbours."""
 import os
 import subprocess

@@ -1,7 +1,7 @@
 """Instruction mix per kernel from the hipcc -S output (tools; not product code)."""
 import re, sys
 from collections import Counter
-path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/qfa_kernels.s"
+path = sys.argv[1] if len(sys.argv) > 1 else "qfa_amd/csrc/build/qfa_capi-hip-amdgcn-amd-amdhsa-gfx950.s"
 pat = sys.argv[2] if len(sys.argv) > 2 else "k_"
 name = None
 c = Counter()

@@ -9,7 +9,7 @@ dynamic check, tests/test_tracked_loads.py.  Exit code 1 on a violation.
 
     tools/audit_asm_loads.py [file.s ...]          (run by `make`: the library does not link unless it passes)"""
 import re, sys
-paths = sys.argv[1:] or ["/tmp/qfa_gx.s"]
+paths = sys.argv[1:] or ["qfa_amd/csrc/build/qfa_gx-hip-amdgcn-amd-amdhsa-gfx950.s"]
 src = "\n".join(open(p).read() for p in paths)
 NO_SCRATCH = ("_Z9k_grads_x", "_Z11k_predict_x")
 bad = 0
