@@ -285,6 +285,67 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #ifndef QFA_GX_ROLE
 #define QFA_GX_ROLE 0      // register-pressure experiments: 1 = role A only, 2 = role B only
 #endif
+#ifndef QFA_GX_FLUSH_A
+#define QFA_GX_FLUSH_A 0      // which role issues the flushes: 0 = role B; 1 = role A -- measured in round 3 because role B ALONE
+#endif                        // runs 2.53 ms (2.13 without its flushes) and role A alone 1.6: same results, 3.2 against 2.7 ms
+    const int tidR = tid & 255;                            // 0..255 over the four waves of a role
+    // Every lane of a flushing wave issues its request: the number of requests per wave is then a constant, which
+    // the counted wait below needs.  Default mode (float atomics): a lane outside the arrays adds 0 to an element
+    // inside them, a different one for each lane (195 000 tile-steps adding to ONE spare address took 50 ms).
+    // Deterministic mode (plain stores into the block's slab row, every element written exactly once): such a lane
+    // stores into the 64 spare floats at the end of the row.
+    float *sink = accF + (slab_stride - 64) + lane;
+    // tile tg leaves the workgroup: the flushing role sums the four groups' partials (fixed order) and adds them to the packed
+    // buffer.  Default: 256 threads, 32 KP / 256 outputs each (a wave's 64 lanes cover 256 contiguous bytes at
+    // N_h = KP).  Deterministic with N_h a multiple of 4: the first 8 KP threads, one 16-byte store each.
+    const bool wide = det && (Nh & 3) == 0;
+    constexpr int NWIDE = 8 * KP;                      // threads of the 16-byte form: 128 (waves 0, 1) / 64 (wave 0)
+    auto flush_F = [&](int tg, int par) -> int {          // returns the number of requests this wave issued
+        if (QFA_GX_ABL & 2) return 0;
+        const float *pp = reinterpret_cast<const float *>(lds + L::L_PART + par * GX::NG * GX::PARTF * 4);
+        if (wide) {
+            if (tidR >= NWIDE) return 0;                                          // wave-uniform
+            const int pxl = tidR / (KP / 4), b4 = 4 * (tidR % (KP / 4));
+            const int px = 32 * tg + pxl;
+            const float4 *q4 = reinterpret_cast<const float4 *>(pp + pxl * KP + b4);
+            const float4 v0 = q4[0], v1 = q4[GX::PARTF / 4], v2 = q4[2 * GX::PARTF / 4], v3 = q4[3 * GX::PARTF / 4];
+            const float4 v = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
+                              (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w)};
+            const bool ok = (b4 < Nh) & (px < Npix);
+            if (ok) *reinterpret_cast<float4 *>(accF + (size_t)px * Nh + b4) = v;
+            else *sink = v.x;
+            return 1;
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < GX::PARTF / 256; ++k4) {
+            const int o = tidR + 256 * k4;
+            float v = (QFA_GX_ABL & 64) ? 1.f : (pp[o] + pp[GX::PARTF + o]) + (pp[2 * GX::PARTF + o] + pp[3 * GX::PARTF + o]);
+            const int px = 32 * tg + o / KP, bb = o % KP;
+            const bool ok = (bb < Nh) & (px < Npix);
+            if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); continue; }
+            if (det) *(ok ? accF + (size_t)px * Nh + bb : sink) = v;
+            else atomicAdd(accF + (size_t)min(px, Npix - 1) * Nh + bb % Nh, ok ? v : 0.f);
+        }
+        return (QFA_GX_ABL & 32) ? 0 : GX::PARTF / 256;
+    };
+    // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = t >> 5, pxl = t & 31) of 128 -- waves
+    // 0 and 1, or waves 2 and 3 when the F sums go out as 16-byte stores (one request per wave and tile then)
+    auto flush_P = [&](int tg, int par) -> int {
+        if (QFA_GX_ABL & 2) return 0;
+        if (wide ? tidR < 128 : tidR >= 128) return 0;                            // wave-uniform (waves 2, 3 / 0, 1)
+        const int which = (tidR >> 5) & 3, pxl = tidR & 31;
+        const float *q = reinterpret_cast<const float *>(lds + L::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
+        float v = (QFA_GX_ABL & 64) ? 1.f : (q[0] + q[128]) + (q[256] + q[384]);
+        if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); return 0; }
+        const int px = 32 * tg + pxl;
+        const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
+        // (default mode: a red pixel's lane of the gOmega group adds 0 to the pixel's count instead)
+        const int pxc = min(px, Npix - 1);
+        const int offc = (which == 2 && pxc >= Nb) ? 2 * Npix + Nb + pxc : which * Npix - (which == 3 ? Npix - Nb : 0) + pxc;
+        if (det) *(ok ? accA + offc : sink) = v;
+        else atomicAdd(accA + offc, ok ? v : 0.f);
+        return 1;
+    };
     if (roleA && QFA_GX_ROLE != 2) {
         // ================================================================ role A: stage 1 + stage 2
         const int lo = lane & 15, g = lane >> 4;
@@ -573,16 +634,28 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 
         // Tile c is staged in buffer c & 1, which is refilled for tile c + 2 during step c (after the copy-out at the
         // start of the step): the requests have more than a step and a half to land.
-        int cnt_a = 0, cnt_b = 0;            // requests in flight for buffer 0 / 1 (0: not issued by a counted path)
+        // This wave's vector-memory queue holds, in issue order, the staging requests of the tiles and (QFA_GX_FLUSH_A) the
+        // flush requests of every second half-step.  `issued` counts them all; mark[p] is its value right behind the requests
+        // that filled staging buffer p, so that "everything up to the staging of tile c has landed" is a counted wait that
+        // leaves issued - mark[c & 1] requests in flight.  A staging call that went through ordinary loads (the ragged last
+        // tile) makes the next wait a wait for everything.
+        int issued = 0, mark[2] = {0, 0};
+        bool uncounted = false;
+        auto stage_counted = [&](int tg, int par) {
+            const int k_ = stage_tile(tg, par);
+            if (k_ == 0) uncounted = true;
+            issued += k_;
+            mark[par] = issued;
+        };
         if (n > 0 && active) {
-            cnt_a = stage_tile(tile_of(0), 0);
-            if (n > 1) cnt_b = stage_tile(tile_of(1), 1);
+            stage_counted(tile_of(0), 0);
+            if (n > 1) stage_counted(tile_of(1), 1);
         }
         step_barrier();                      // (role B's wait in front of this barrier covers the first image half)
         SpecA cur;
         f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
         PixA pxp{0.f, 0.f, 0.f, 0.f, 0.f};
-        auto tileA = [&](int c, int &cnt_cur, int cnt_other) {
+        auto tileA = [&](int c) {
             const bool work = c < n && active;
             const int tg = work ? tile_of(c) : 0;
 #pragma unroll
@@ -590,18 +663,15 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 if (work) {
                     auto spectra = [&]() {
                         if (h != 0) return;
-                        // this tile's staged spectra: everything but the requests of tile c + 1 has landed after the wait;
-                        // copy out, then the requests for tile c + 2 into the buffer just read
+                        // this tile's staged spectra: everything up to its staging requests has landed behind the wait; copy
+                        // out, then the requests for tile c + 2 into the buffer just read
                         if (QFA_GX_ABL & 1) {}
-                        else if (c + 1 < n && cnt_other == 8) dma_wait<8>();
-                        else if (c + 1 < n && cnt_other == 6) dma_wait<6>();
-                        else if (c + 1 < n && cnt_other == 14) dma_wait<14>();
-                        else dma_wait<0>();
+                        else if (uncounted) { dma_wait<0>(); uncounted = false; }
+                        else dma_wait_n(issued - mark[c & 1]);
                         take_tile(c & 1, cur);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging buffer read: it may be overwritten now
                         __builtin_amdgcn_sched_barrier(0);
-                        cnt_cur = 0;
-                        if (c + 2 < n) cnt_cur = stage_tile(tile_of(c + 2), c & 1);
+                        if (c + 2 < n) stage_counted(tile_of(c + 2), c & 1);
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     {
@@ -612,13 +682,17 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                         else stage2A(std::false_type{}, tg, h, cur, c & 1, afy, aq, pxp);
                     }
                 }
+                if (QFA_GX_FLUSH_A && h == 1) {
+                    // the flushes of the tiles that left the pipeline (every wave of the role, active or not): the per-pixel
+                    // sums of tile c - 1 (this role wrote them during tile c - 1), the F sums of tile c - 2 (role B finished
+                    // them during tile c - 1).  Fire and forget: they only count in the waits above.
+                    if (c >= 1 && c <= n) issued += flush_P(tile_of(c - 1), (c - 1) & 1);
+                    if (c >= 2) issued += flush_F(tile_of(c - 2), c & 1);
+                }
                 step_barrier();
             }
         };
-        for (int c = 0; c < n + 2; c += 2) {
-            tileA(c, cnt_a, cnt_b);
-            if (c + 1 < n + 2) tileA(c + 1, cnt_b, cnt_a);
-        }
+        for (int c = 0; c < n + 2; ++c) tileA(c);
 #if QFA_GX_STAMPS
         if (blockIdx.x == 300 && w == 0 && lane == 0) {
             st_[30] = n;
@@ -691,7 +765,6 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         // spectra at KP = 8 (where only k < 8 carries data).  Column col = (spectrum sc = col / KP, b = col % KP).
         constexpr int SPM = 32 / KP, NMG = 16 / SPM;       // spectra per MFMA, MFMA groups per wave (8 pairs / 4 fours)
         const int col = lane & 31, h2 = lane >> 5, b = lane & (KP - 1), sc = col / KP, sp = (lane >> 4) & 1;
-        const int tidB = tid & 255;                        // 0..255 over the four role-B waves
         // B operands: Z of group m: B[k = a = 8 h2 + j][col = (sc, b)] = Z_{SPM m + sc}[a][b]
         constexpr int NMGA = WB ? 1 : NMG;
         u32x4 Zh[NMGA], Zm[NMGA], Zl[NMGA], Ph = {0u, 0u, 0u, 0u}, Pm = Ph, Pl = Ph;
@@ -737,61 +810,6 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             const unsigned char *sbase = uniform_ptr(PGX + (size_t)tile_of(c) * GX::TILE_B);
             unsigned char *fp = lds + L::L_FP + (c & 1) * 3072;
             if (w < 3) glds16a(sbase + GX::OFF_FP + w * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(fp + w * 1024)));
-        };
-        // Every lane of a flushing wave issues its request: the number of requests per wave is then a constant, which
-        // the counted wait below needs.  Default mode (float atomics): a lane outside the arrays adds 0 to an element
-        // inside them, a different one for each lane (195 000 tile-steps adding to ONE spare address took 50 ms).
-        // Deterministic mode (plain stores into the block's slab row, every element written exactly once): such a lane
-        // stores into the 64 spare floats at the end of the row.
-        float *sink = accF + (slab_stride - 64) + lane;
-        // tile tg leaves the workgroup: role B sums the four groups' partials (fixed order) and adds them to the packed
-        // buffer.  Default: 256 threads, 32 KP / 256 outputs each (a wave's 64 lanes cover 256 contiguous bytes at
-        // N_h = KP).  Deterministic with N_h a multiple of 4: the first 8 KP threads, one 16-byte store each.
-        const bool wide = det && (Nh & 3) == 0;
-        constexpr int NWIDE = 8 * KP;                      // threads of the 16-byte form: 128 (waves 0, 1) / 64 (wave 0)
-        auto flush_F = [&](int tg, int par) {
-            if (QFA_GX_ABL & 2) return;
-            const float *pp = reinterpret_cast<const float *>(lds + L::L_PART + par * GX::NG * GX::PARTF * 4);
-            if (wide) {
-                if (tidB >= NWIDE) return;                                            // wave-uniform
-                const int pxl = tidB / (KP / 4), b4 = 4 * (tidB % (KP / 4));
-                const int px = 32 * tg + pxl;
-                const float4 *q4 = reinterpret_cast<const float4 *>(pp + pxl * KP + b4);
-                const float4 v0 = q4[0], v1 = q4[GX::PARTF / 4], v2 = q4[2 * GX::PARTF / 4], v3 = q4[3 * GX::PARTF / 4];
-                const float4 v = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
-                                  (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w)};
-                const bool ok = (b4 < Nh) & (px < Npix);
-                if (ok) *reinterpret_cast<float4 *>(accF + (size_t)px * Nh + b4) = v;
-                else *sink = v.x;
-                return;
-            }
-#pragma unroll
-            for (int k4 = 0; k4 < GX::PARTF / 256; ++k4) {
-                const int o = tidB + 256 * k4;
-                float v = (QFA_GX_ABL & 64) ? 1.f : (pp[o] + pp[GX::PARTF + o]) + (pp[2 * GX::PARTF + o] + pp[3 * GX::PARTF + o]);
-                const int px = 32 * tg + o / KP, bb = o % KP;
-                const bool ok = (bb < Nh) & (px < Npix);
-                if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); continue; }
-                if (det) *(ok ? accF + (size_t)px * Nh + bb : sink) = v;
-                else atomicAdd(accF + (size_t)min(px, Npix - 1) * Nh + bb % Nh, ok ? v : 0.f);
-            }
-        };
-        // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = t >> 5, pxl = t & 31) of 128 -- waves
-        // 0 and 1, or waves 2 and 3 when the F sums go out as 16-byte stores (one request per wave and tile then)
-        auto flush_P = [&](int tg, int par) {
-            if (QFA_GX_ABL & 2) return;
-            if (wide ? tidB < 128 : tidB >= 128) return;                              // wave-uniform (waves 2, 3 / 0, 1)
-            const int which = (tidB >> 5) & 3, pxl = tidB & 31;
-            const float *q = reinterpret_cast<const float *>(lds + L::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
-            float v = (QFA_GX_ABL & 64) ? 1.f : (q[0] + q[128]) + (q[256] + q[384]);
-            if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); return; }
-            const int px = 32 * tg + pxl;
-            const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
-            // (default mode: a red pixel's lane of the gOmega group adds 0 to the pixel's count instead)
-            const int pxc = min(px, Npix - 1);
-            const int offc = (which == 2 && pxc >= Nb) ? 2 * Npix + Nb + pxc : which * Npix - (which == 3 ? Npix - Nb : 0) + pxc;
-            if (det) *(ok ? accA + offc : sink) = v;
-            else atomicAdd(accA + offc, ok ? v : 0.f);
         };
         // stage 3 of tile c, in two parts (the two half-steps of tile c + 1; balanced, so that neither half-step waits for
         // this role): part 0 = the gamma term and the first half of the MFMA groups, part 1 = the second half, added to
@@ -926,13 +944,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 if (t + AHEAD < 2 * n) { get_img(t + AHEAD); n_dma += n_img; }
                 if (h == 0 && c < n) { get_F(c); n_dma += n_fp; }      // (first read in half-step 2 c + 2: landed behind the wait of 2 c + 1)
                 if (QFA_GX_ABL & 4) n_dma = 0;
-                // requests of this wave's flushes (wave-uniform): F 2 (one as a 16-byte store, waves 0 and 1), P 1
-                const bool wP = wide ? tidB >= 128 : tidB < 128, wF = !wide || tidB < NWIDE;
-                const int nreq = (h == 0 && c >= 1 && c <= n && wP ? 1 : 0) +
-                                 (h == 0 && c >= 2 && wF ? (wide ? 1 : GX::PARTF / 256) : 0);
-                if (h == 0) {
-                    if (c >= 1 && c <= n) flush_P(tile_of(c - 1), (c - 1) & 1);
-                    if (c >= 2) flush_F(tile_of(c - 2), c & 1);
+                // this wave's flush requests of the half-step (wave-uniform; none when role A flushes)
+                int nreq = 0;
+                if (!QFA_GX_FLUSH_A && h == 0) {
+                    if (c >= 1 && c <= n) nreq += flush_P(tile_of(c - 1), (c - 1) & 1);
+                    if (c >= 2) nreq += flush_F(tile_of(c - 2), c & 1);
                 }
                 GXS(8 * h + 0)
                 if (c >= 1 && c <= n && active) {
@@ -950,7 +966,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 else if (nreq == 3) dma_wait<3>();
                 else if (nreq == 2) dma_wait<2>();
                 else if (nreq == 1) dma_wait<1>();
-                else dma_wait<0>();
+                else dma_wait<0>();            // (role A flushes: the image DMA is all this role has in flight)
                 GXS(8 * h + 2)
                 step_barrier();
                 GXS(8 * h + 3)
