@@ -40,7 +40,7 @@
 // and behind them the flush atomics, which a counted vmcnt in front of the barrier leaves in flight for one more
 // half-step.  Nothing on the hot path loads into registers through asm (an earlier form did, and hipcc moved copies
 // of such registers in front of the wait; tools/audit_asm_loads.py still checks the compiled code for that), and
-// `make` fails on any scratch use (audit of the shipped objects' assembly) (spilled loop-carried registers came
+// `make check-gx` fails on any scratch use (spilled loop-carried registers came
 // back wrong from run to run in an earlier build -- tools/diag_slab.py).
 #pragma once
 #include "qfa_common.h"
@@ -63,35 +63,22 @@ struct GXT {                                             // KP = 16 (N_h = 9..16
     static constexpr int NG = 4;                         // groups of 16 spectra per workgroup
     static constexpr int SPB = 16 * NG;                  // spectra per workgroup
     static constexpr int STG_ARR = 16 * 128;             // staging: one array of one tile, [16 rows][32 px] float
+    static constexpr int STG_MASK = 3 * STG_ARR;         // mask bytes [16 rows][32 px]
+    static constexpr int STG_B = 3 * STG_ARR + 512;      // delta | sigma | zabs | mask (6.5 KiB per wave and tile)
     static constexpr int PARTF = 32 * KP;                // floats of one group's stage-3 sums of a tile: [32 px][KP b]
-};
-// LDS of k_grads_x (bytes per workgroup).  ZF (factored-z input form): no zabs staging (two arrays instead of three: 139 KiB).
-// QFA_GX_RING3=1 spends the freed space on a THIRD image slot (image of half t + 2 requested during half-step t, role B's wait
-// in front of a barrier leaves a whole half-step's requests in flight): built, bit-identical results, and SLOWER -- 2.70 against
-// 2.60 ms at c3 on one box, twice (profiles/r3_ablation_pass2.txt) -- so two slots stay the default.
-template <int KP, bool ZF>
-struct GXL : GXT<KP> {
-    using G = GXT<KP>;
-    static constexpr int NG = G::NG;
-#ifndef QFA_GX_RING3
-#define QFA_GX_RING3 0        // 1: three image slots in the factored-z form (measured slower)
-#endif
-    static constexpr int RING = (ZF && QFA_GX_RING3) ? 3 : 2;   // image slots (halves)
-    static constexpr int NARR = ZF ? 2 : 3;              // staged float arrays: delta, sigma (, zabs)
-    static constexpr int STG_MASK = NARR * G::STG_ARR;   // mask bytes [16 rows][32 px]
-    static constexpr int STG_B = NARR * G::STG_ARR + 512;  // 6.5 / 4.5 KiB per wave and tile
-    static constexpr int L_IMG = 0;                                  // [RING halves][HALF_B]
-    static constexpr int L_FP = L_IMG + RING * G::HALF_B;            // [2 tile parity][3 KiB]
+    // LDS (bytes), per workgroup
+    static constexpr int L_IMG = 0;                                  // [2 halves][HALF_B]
+    static constexpr int L_FP = L_IMG + 2 * HALF_B;                  // [2 tile parity][3 KiB]
     static constexpr int L_BETA = L_FP + 2 * 3072;                   // [2 tile parity][NG][16 s][32 px] float
     static constexpr int L_GAM = L_BETA + 2 * NG * 2048;             // [2][NG][32 rows][GROW] float
-    static constexpr int L_PART = L_GAM + 2 * NG * 32 * G::GROW * 4; // [2][NG][32 px][KP b] float
-    static constexpr int L_PSUM = L_PART + 2 * NG * G::PARTF * 4;    // [2][NG][4 sums][32 px] float (summed over the wave)
+    static constexpr int L_PART = L_GAM + 2 * NG * 32 * GROW * 4;    // [2][NG][32 px][KP b] float
+    static constexpr int L_PSUM = L_PART + 2 * NG * PARTF * 4;       // [2][NG][4 sums][32 px] float (summed over the wave)
     static constexpr int L_SCAL = L_PSUM + 2 * NG * 512;             // [NG waves][3 sums][64 lanes] double (role A)
     static constexpr int L_STG = L_SCAL + NG * 3 * 64 * 8;           // [NG waves][2 tile parity][STG_B]
     static constexpr int L_ZS = L_STG + NG * 2 * STG_B;              // [NG waves][16 spectra] float4: factored-z per-spectrum factors
     static constexpr int L_TOTAL = L_ZS + NG * 256;
 };
-static_assert(GXL<16, false>::L_TOTAL <= 160 * 1024 && GXL<16, true>::L_TOTAL <= 160 * 1024 && GXL<8, true>::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
+static_assert(GXT<16>::L_TOTAL <= 160 * 1024 && GXT<8>::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
 static_assert(32 * GXT<16>::FROW * 4 <= 3072, "F block of the W form fits the F slot");
 __device__ __forceinline__ f32x16 xdl32(const u32x4 &a, const u32x4 &b, f32x16 c) {     // 32x32x16
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -237,8 +224,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                                                     int slab_stride, Scal64 *__restrict__ sc64) {
     using C = Cfg<KP>;
     using GX = GXT<KP>;
-    using L = GXL<KP, ZF>;              // LDS layout (the factored-z form has a third image slot)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[L::L_TOTAL];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[GX::L_TOTAL];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv8 = wave_uniform(tid >> 6);               // 0..7
@@ -264,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
     float *accS = accum + (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
 
     // zero the slots that inactive groups never write
-    for (int i = tid; i < (L::L_SCAL - L::L_BETA) / 4; i += 512) reinterpret_cast<float *>(lds + L::L_BETA)[i] = 0.f;
+    for (int i = tid; i < (GX::L_SCAL - GX::L_BETA) / 4; i += 512) reinterpret_cast<float *>(lds + GX::L_BETA)[i] = 0.f;
 
     // de-phase the tile order between workgroups (concurrent flushes then hit different rows; the workgroups running
     // together still share a window of the image in L2)
@@ -285,67 +271,6 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #ifndef QFA_GX_ROLE
 #define QFA_GX_ROLE 0      // register-pressure experiments: 1 = role A only, 2 = role B only
 #endif
-#ifndef QFA_GX_FLUSH_A
-#define QFA_GX_FLUSH_A 0      // which role issues the flushes: 0 = role B; 1 = role A -- measured in round 3 because role B ALONE
-#endif                        // runs 2.53 ms (2.13 without its flushes) and role A alone 1.6: same results, 3.2 against 2.7 ms
-    const int tidR = tid & 255;                            // 0..255 over the four waves of a role
-    // Every lane of a flushing wave issues its request: the number of requests per wave is then a constant, which
-    // the counted wait below needs.  Default mode (float atomics): a lane outside the arrays adds 0 to an element
-    // inside them, a different one for each lane (195 000 tile-steps adding to ONE spare address took 50 ms).
-    // Deterministic mode (plain stores into the block's slab row, every element written exactly once): such a lane
-    // stores into the 64 spare floats at the end of the row.
-    float *sink = accF + (slab_stride - 64) + lane;
-    // tile tg leaves the workgroup: the flushing role sums the four groups' partials (fixed order) and adds them to the packed
-    // buffer.  Default: 256 threads, 32 KP / 256 outputs each (a wave's 64 lanes cover 256 contiguous bytes at
-    // N_h = KP).  Deterministic with N_h a multiple of 4: the first 8 KP threads, one 16-byte store each.
-    const bool wide = det && (Nh & 3) == 0;
-    constexpr int NWIDE = 8 * KP;                      // threads of the 16-byte form: 128 (waves 0, 1) / 64 (wave 0)
-    auto flush_F = [&](int tg, int par) -> int {          // returns the number of requests this wave issued
-        if (QFA_GX_ABL & 2) return 0;
-        const float *pp = reinterpret_cast<const float *>(lds + L::L_PART + par * GX::NG * GX::PARTF * 4);
-        if (wide) {
-            if (tidR >= NWIDE) return 0;                                          // wave-uniform
-            const int pxl = tidR / (KP / 4), b4 = 4 * (tidR % (KP / 4));
-            const int px = 32 * tg + pxl;
-            const float4 *q4 = reinterpret_cast<const float4 *>(pp + pxl * KP + b4);
-            const float4 v0 = q4[0], v1 = q4[GX::PARTF / 4], v2 = q4[2 * GX::PARTF / 4], v3 = q4[3 * GX::PARTF / 4];
-            const float4 v = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
-                              (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w)};
-            const bool ok = (b4 < Nh) & (px < Npix);
-            if (ok) *reinterpret_cast<float4 *>(accF + (size_t)px * Nh + b4) = v;
-            else *sink = v.x;
-            return 1;
-        }
-#pragma unroll
-        for (int k4 = 0; k4 < GX::PARTF / 256; ++k4) {
-            const int o = tidR + 256 * k4;
-            float v = (QFA_GX_ABL & 64) ? 1.f : (pp[o] + pp[GX::PARTF + o]) + (pp[2 * GX::PARTF + o] + pp[3 * GX::PARTF + o]);
-            const int px = 32 * tg + o / KP, bb = o % KP;
-            const bool ok = (bb < Nh) & (px < Npix);
-            if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); continue; }
-            if (det) *(ok ? accF + (size_t)px * Nh + bb : sink) = v;
-            else atomicAdd(accF + (size_t)min(px, Npix - 1) * Nh + bb % Nh, ok ? v : 0.f);
-        }
-        return (QFA_GX_ABL & 32) ? 0 : GX::PARTF / 256;
-    };
-    // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = t >> 5, pxl = t & 31) of 128 -- waves
-    // 0 and 1, or waves 2 and 3 when the F sums go out as 16-byte stores (one request per wave and tile then)
-    auto flush_P = [&](int tg, int par) -> int {
-        if (QFA_GX_ABL & 2) return 0;
-        if (wide ? tidR < 128 : tidR >= 128) return 0;                            // wave-uniform (waves 2, 3 / 0, 1)
-        const int which = (tidR >> 5) & 3, pxl = tidR & 31;
-        const float *q = reinterpret_cast<const float *>(lds + L::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
-        float v = (QFA_GX_ABL & 64) ? 1.f : (q[0] + q[128]) + (q[256] + q[384]);
-        if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); return 0; }
-        const int px = 32 * tg + pxl;
-        const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
-        // (default mode: a red pixel's lane of the gOmega group adds 0 to the pixel's count instead)
-        const int pxc = min(px, Npix - 1);
-        const int offc = (which == 2 && pxc >= Nb) ? 2 * Npix + Nb + pxc : which * Npix - (which == 3 ? Npix - Nb : 0) + pxc;
-        if (det) *(ok ? accA + offc : sink) = v;
-        else atomicAdd(accA + offc, ok ? v : 0.f);
-        return 1;
-    };
     if (roleA && QFA_GX_ROLE != 2) {
         // ================================================================ role A: stage 1 + stage 2
         const int lo = lane & 15, g = lane >> 4;
@@ -391,11 +316,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         const float *zbase = ZF ? dbase : uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
         const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
         // factored-z form: the per-spectrum factors of the wave's 16 spectra in LDS (this role has no registers to spare)
-        float4 *zsl = reinterpret_cast<float4 *>(lds + L::L_ZS + w * 256);
+        float4 *zsl = reinterpret_cast<float4 *>(lds + GX::L_ZS + w * 256);
         if (ZF && lane < 16) zsl[lane] = (active && s0 + lane < B) ? ZS[s0 + lane] : float4{0.f, 0.f, 0.f, 0.f};
         // scalar-gradient sums: float32 inside a tile, float64 across tiles -- the float64 running sums live in LDS
         // (three doubles per lane), not in six registers
-        double *scal = reinterpret_cast<double *>(lds + L::L_SCAL) + (size_t)w * 3 * 64 + lane;
+        double *scal = reinterpret_cast<double *>(lds + GX::L_SCAL) + (size_t)w * 3 * 64 + lane;
         scal[0] = 0.0; scal[64] = 0.0; scal[128] = 0.0;
 
         // ---- spectra of one tile for this wave: LDS-DMA of the 128-byte row segments of delta, sigma, zabs and of the
@@ -410,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         //    0   the ragged last tile of the pixel axis: everything as clamped 4-byte pieces, masks through registers.
         // The third array is staged for EVERY tile so that the counts are fixed: red tiles re-request their delta rows
         // there (hits in the vector cache, values unused).  No request reads past the end of a row.
-        unsigned char *stg = lds + L::L_STG + w * 2 * L::STG_B;
+        unsigned char *stg = lds + GX::L_STG + w * 2 * GX::STG_B;
         auto stage_tile = [&](int tg, int par) -> int {
             if (QFA_GX_ABL & 1) return 8;
             if (QFA_GX_ABL & 8) tg = t0;
@@ -418,11 +343,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             const bool fastp = 32 * tg + 31 < Npix, fastz = ZF || !zblue || 32 * tg + 31 < Nb;
             const float *zb = (zblue && !(QFA_GX_ABL & 16)) ? zbase : dbase;
             const int zlen = (zblue && !(QFA_GX_ABL & 16)) ? Nb : Npix;
-            const unsigned dst = wave_uniform(lds_addr(stg + par * L::STG_B));
+            const unsigned dst = wave_uniform(lds_addr(stg + par * GX::STG_B));
 #if QFA_TRACKED_LOADS
             {   // test build: ordinary loads and LDS stores for all four arrays (two rows per pass), no counted wait
-                float *sf = reinterpret_cast<float *>(stg + par * L::STG_B);
-                unsigned char *mb = stg + par * L::STG_B + L::STG_MASK;
+                float *sf = reinterpret_cast<float *>(stg + par * GX::STG_B);
+                unsigned char *mb = stg + par * GX::STG_B + GX::STG_MASK;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int q = 2 * i + (lane >> 5), pxl = lane & 31;
@@ -448,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     glds16a(dbase, 4u * o, dst + 0 * GX::STG_ARR + i * 1024);
                     glds16a(ebase, 4u * o, dst + 1 * GX::STG_ARR + i * 1024);
                     if (!ZF && fastz) glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * GX::STG_ARR + i * 1024);
-                    glds4a(mbase, o, dst + L::STG_MASK + i * 256);
+                    glds4a(mbase, o, dst + GX::STG_MASK + i * 256);
                 }
                 if (fastz) return ZF ? 6 : 8;
             }
@@ -467,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             }
             if (fastp) return 14;
             // masks of the ragged tile: ordinary loads (hipcc waits for them by itself) and byte stores
-            unsigned char *mb = stg + par * L::STG_B + L::STG_MASK;
+            unsigned char *mb = stg + par * GX::STG_B + GX::STG_MASK;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int q = 2 * i + (lane >> 5);
@@ -480,8 +405,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         // copy the lane's 4 spectra x 2 pixels of the staged tile into registers; the mask goes into the sign of sigma
         // (only sigma^2 is ever used: sign bit set means "masked" from here on)
         auto take_tile = [&](int par, SpecA &cur) {
-            const unsigned char *sb = stg + par * L::STG_B + 8 * lo;
-            const unsigned char *mb = stg + par * L::STG_B + L::STG_MASK + 2 * lo;
+            const unsigned char *sb = stg + par * GX::STG_B + 8 * lo;
+            const unsigned char *mb = stg + par * GX::STG_B + GX::STG_MASK + 2 * lo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int slot = 4 * g + (r ^ (g & 1));
@@ -505,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         };
         float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
         auto stage1A = [&](int slot, f32x4 &ofy, f32x4 &oq, PixA &pp) {
-            const unsigned char *img = lds + L::L_IMG + slot * GX::HALF_B;
+            const unsigned char *img = lds + GX::L_IMG + slot * GX::HALF_B;
             const unsigned char *bp = img + lane * 16;
             f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
             u32x4 bq[2][3];
@@ -532,9 +457,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         auto stage2A = [&](auto blue_tag, int tg, int h, const SpecA &cur, int par, const f32x4 &afy, const f32x4 &aq,
                            const PixA &pp) {
             constexpr bool BLUE = decltype(blue_tag)::value;
-            float *bslot = reinterpret_cast<float *>(lds + L::L_BETA + (par * GX::NG + w) * 2048);
-            float *gslot = reinterpret_cast<float *>(lds + L::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
-            float *psum = reinterpret_cast<float *>(lds + L::L_PSUM + (par * GX::NG + w) * 512);
+            float *bslot = reinterpret_cast<float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
+            float *gslot = reinterpret_cast<float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
+            float *psum = reinterpret_cast<float *>(lds + GX::L_PSUM + (par * GX::NG + w) * 512);
             const float Psi = pp.Psi, om = pp.om;
             const float ti = pp.ti, pwi = pp.pwi, l2i = pp.l2i;
             const int px = 32 * tg + 2 * lo + h;
@@ -634,28 +559,16 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 
         // Tile c is staged in buffer c & 1, which is refilled for tile c + 2 during step c (after the copy-out at the
         // start of the step): the requests have more than a step and a half to land.
-        // This wave's vector-memory queue holds, in issue order, the staging requests of the tiles and (QFA_GX_FLUSH_A) the
-        // flush requests of every second half-step.  `issued` counts them all; mark[p] is its value right behind the requests
-        // that filled staging buffer p, so that "everything up to the staging of tile c has landed" is a counted wait that
-        // leaves issued - mark[c & 1] requests in flight.  A staging call that went through ordinary loads (the ragged last
-        // tile) makes the next wait a wait for everything.
-        int issued = 0, mark[2] = {0, 0};
-        bool uncounted = false;
-        auto stage_counted = [&](int tg, int par) {
-            const int k_ = stage_tile(tg, par);
-            if (k_ == 0) uncounted = true;
-            issued += k_;
-            mark[par] = issued;
-        };
+        int cnt_a = 0, cnt_b = 0;            // requests in flight for buffer 0 / 1 (0: not issued by a counted path)
         if (n > 0 && active) {
-            stage_counted(tile_of(0), 0);
-            if (n > 1) stage_counted(tile_of(1), 1);
+            cnt_a = stage_tile(tile_of(0), 0);
+            if (n > 1) cnt_b = stage_tile(tile_of(1), 1);
         }
         step_barrier();                      // (role B's wait in front of this barrier covers the first image half)
         SpecA cur;
         f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
         PixA pxp{0.f, 0.f, 0.f, 0.f, 0.f};
-        auto tileA = [&](int c) {
+        auto tileA = [&](int c, int &cnt_cur, int cnt_other) {
             const bool work = c < n && active;
             const int tg = work ? tile_of(c) : 0;
 #pragma unroll
@@ -663,36 +576,35 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 if (work) {
                     auto spectra = [&]() {
                         if (h != 0) return;
-                        // this tile's staged spectra: everything up to its staging requests has landed behind the wait; copy
-                        // out, then the requests for tile c + 2 into the buffer just read
+                        // this tile's staged spectra: everything but the requests of tile c + 1 has landed after the wait;
+                        // copy out, then the requests for tile c + 2 into the buffer just read
                         if (QFA_GX_ABL & 1) {}
-                        else if (uncounted) { dma_wait<0>(); uncounted = false; }
-                        else dma_wait_n(issued - mark[c & 1]);
+                        else if (c + 1 < n && cnt_other == 8) dma_wait<8>();
+                        else if (c + 1 < n && cnt_other == 6) dma_wait<6>();
+                        else if (c + 1 < n && cnt_other == 14) dma_wait<14>();
+                        else dma_wait<0>();
                         take_tile(c & 1, cur);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging buffer read: it may be overwritten now
                         __builtin_amdgcn_sched_barrier(0);
-                        if (c + 2 < n) stage_counted(tile_of(c + 2), c & 1);
+                        cnt_cur = 0;
+                        if (c + 2 < n) cnt_cur = stage_tile(tile_of(c + 2), c & 1);
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     {
-                        stage1A((2 * c + h) % L::RING, afy, aq, pxp);
+                        stage1A(h, afy, aq, pxp);
                         __builtin_amdgcn_sched_barrier(0);
                         spectra();                             // (behind stage 1 of the first half, which needs no spectra)
                         if (tg < nbt) stage2A(std::true_type{}, tg, h, cur, c & 1, afy, aq, pxp);
                         else stage2A(std::false_type{}, tg, h, cur, c & 1, afy, aq, pxp);
                     }
                 }
-                if (QFA_GX_FLUSH_A && h == 1) {
-                    // the flushes of the tiles that left the pipeline (every wave of the role, active or not): the per-pixel
-                    // sums of tile c - 1 (this role wrote them during tile c - 1), the F sums of tile c - 2 (role B finished
-                    // them during tile c - 1).  Fire and forget: they only count in the waits above.
-                    if (c >= 1 && c <= n) issued += flush_P(tile_of(c - 1), (c - 1) & 1);
-                    if (c >= 2) issued += flush_F(tile_of(c - 2), c & 1);
-                }
                 step_barrier();
             }
         };
-        for (int c = 0; c < n + 2; ++c) tileA(c);
+        for (int c = 0; c < n + 2; c += 2) {
+            tileA(c, cnt_a, cnt_b);
+            if (c + 1 < n + 2) tileA(c + 1, cnt_b, cnt_a);
+        }
 #if QFA_GX_STAMPS
         if (blockIdx.x == 300 && w == 0 && lane == 0) {
             st_[30] = n;
@@ -765,6 +677,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         // spectra at KP = 8 (where only k < 8 carries data).  Column col = (spectrum sc = col / KP, b = col % KP).
         constexpr int SPM = 32 / KP, NMG = 16 / SPM;       // spectra per MFMA, MFMA groups per wave (8 pairs / 4 fours)
         const int col = lane & 31, h2 = lane >> 5, b = lane & (KP - 1), sc = col / KP, sp = (lane >> 4) & 1;
+        const int tidB = tid & 255;                        // 0..255 over the four role-B waves
         // B operands: Z of group m: B[k = a = 8 h2 + j][col = (sc, b)] = Z_{SPM m + sc}[a][b]
         constexpr int NMGA = WB ? 1 : NMG;
         u32x4 Zh[NMGA], Zm[NMGA], Zl[NMGA], Ph = {0u, 0u, 0u, 0u}, Pm = Ph, Pl = Ph;
@@ -791,13 +704,13 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         }
         // LDS-DMA of half-step t = 2 c + h: the stage-1 image + Psi/omega of that half into ring slot h, and with the
         // second half the F pieces of the tile into the F ring; wave w moves the 1-KiB pieces w, w + 4, ...
-        // (the image of half t + AHEAD is requested at the start of half-step t; the F block of tile c with its first half-step:
-        // stage 3 of tile c reads it during tile c + 1)
+        // (role A runs stage 1 of half t + 1 during half-step t: the image of half t + 2 is requested at the start of
+        // half-step t into the slot half t was read from in half-step t - 1; the F block of tile c with its second half-step)
         auto get_img = [&](int t) {
             if ((QFA_GX_ABL & 4) && t > 1) return;
             const int c = t >> 1, h = t & 1;
             const unsigned char *sbase = uniform_ptr(PGX + (size_t)tile_of(c) * GX::TILE_B);
-            unsigned char *img = lds + L::L_IMG + (t % L::RING) * GX::HALF_B;
+            unsigned char *img = lds + GX::L_IMG + h * GX::HALF_B;
 #pragma unroll
             for (int i = 0; i < (GX::NCH_HALF + GX::NG - 1) / GX::NG; ++i) {
                 const int ch = w + GX::NG * i;
@@ -808,8 +721,63 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         auto get_F = [&](int c) {
             if ((QFA_GX_ABL & 4) && c > 0) return;
             const unsigned char *sbase = uniform_ptr(PGX + (size_t)tile_of(c) * GX::TILE_B);
-            unsigned char *fp = lds + L::L_FP + (c & 1) * 3072;
+            unsigned char *fp = lds + GX::L_FP + (c & 1) * 3072;
             if (w < 3) glds16a(sbase + GX::OFF_FP + w * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(fp + w * 1024)));
+        };
+        // Every lane of a flushing wave issues its request: the number of requests per wave is then a constant, which
+        // the counted wait below needs.  Default mode (float atomics): a lane outside the arrays adds 0 to an element
+        // inside them, a different one for each lane (195 000 tile-steps adding to ONE spare address took 50 ms).
+        // Deterministic mode (plain stores into the block's slab row, every element written exactly once): such a lane
+        // stores into the 64 spare floats at the end of the row.
+        float *sink = accF + (slab_stride - 64) + lane;
+        // tile tg leaves the workgroup: role B sums the four groups' partials (fixed order) and adds them to the packed
+        // buffer.  Default: 256 threads, 32 KP / 256 outputs each (a wave's 64 lanes cover 256 contiguous bytes at
+        // N_h = KP).  Deterministic with N_h a multiple of 4: the first 8 KP threads, one 16-byte store each.
+        const bool wide = det && (Nh & 3) == 0;
+        constexpr int NWIDE = 8 * KP;                      // threads of the 16-byte form: 128 (waves 0, 1) / 64 (wave 0)
+        auto flush_F = [&](int tg, int par) {
+            if (QFA_GX_ABL & 2) return;
+            const float *pp = reinterpret_cast<const float *>(lds + GX::L_PART + par * GX::NG * GX::PARTF * 4);
+            if (wide) {
+                if (tidB >= NWIDE) return;                                            // wave-uniform
+                const int pxl = tidB / (KP / 4), b4 = 4 * (tidB % (KP / 4));
+                const int px = 32 * tg + pxl;
+                const float4 *q4 = reinterpret_cast<const float4 *>(pp + pxl * KP + b4);
+                const float4 v0 = q4[0], v1 = q4[GX::PARTF / 4], v2 = q4[2 * GX::PARTF / 4], v3 = q4[3 * GX::PARTF / 4];
+                const float4 v = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
+                                  (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w)};
+                const bool ok = (b4 < Nh) & (px < Npix);
+                if (ok) *reinterpret_cast<float4 *>(accF + (size_t)px * Nh + b4) = v;
+                else *sink = v.x;
+                return;
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < GX::PARTF / 256; ++k4) {
+                const int o = tidB + 256 * k4;
+                float v = (QFA_GX_ABL & 64) ? 1.f : (pp[o] + pp[GX::PARTF + o]) + (pp[2 * GX::PARTF + o] + pp[3 * GX::PARTF + o]);
+                const int px = 32 * tg + o / KP, bb = o % KP;
+                const bool ok = (bb < Nh) & (px < Npix);
+                if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); continue; }
+                if (det) *(ok ? accF + (size_t)px * Nh + bb : sink) = v;
+                else atomicAdd(accF + (size_t)min(px, Npix - 1) * Nh + bb % Nh, ok ? v : 0.f);
+            }
+        };
+        // per-pixel sums [sumA | gPsi | gOmega | cnt] of tile tg: thread (which = t >> 5, pxl = t & 31) of 128 -- waves
+        // 0 and 1, or waves 2 and 3 when the F sums go out as 16-byte stores (one request per wave and tile then)
+        auto flush_P = [&](int tg, int par) {
+            if (QFA_GX_ABL & 2) return;
+            if (wide ? tidB < 128 : tidB >= 128) return;                              // wave-uniform (waves 2, 3 / 0, 1)
+            const int which = (tidB >> 5) & 3, pxl = tidB & 31;
+            const float *q = reinterpret_cast<const float *>(lds + GX::L_PSUM + par * GX::NG * 512) + which * 32 + pxl;
+            float v = (QFA_GX_ABL & 64) ? 1.f : (q[0] + q[128]) + (q[256] + q[384]);
+            if (QFA_GX_ABL & 32) { asm volatile("" ::"v"(v)); return; }
+            const int px = 32 * tg + pxl;
+            const bool ok = (px < Npix) & ((which != 2) | (px < Nb));
+            // (default mode: a red pixel's lane of the gOmega group adds 0 to the pixel's count instead)
+            const int pxc = min(px, Npix - 1);
+            const int offc = (which == 2 && pxc >= Nb) ? 2 * Npix + Nb + pxc : which * Npix - (which == 3 ? Npix - Nb : 0) + pxc;
+            if (det) *(ok ? accA + offc : sink) = v;
+            else atomicAdd(accA + offc, ok ? v : 0.f);
         };
         // stage 3 of tile c, in two parts (the two half-steps of tile c + 1; balanced, so that neither half-step waits for
         // this role): part 0 = the gamma term and the first half of the MFMA groups, part 1 = the second half, added to
@@ -819,11 +787,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             const int par = c & 1;
             if constexpr (WB) {
                 // half PART of tile c: beta / gamma of the lane's four spectra (pixel 2 lo + PART) as role A left them
-                const float *bsl = reinterpret_cast<const float *>(lds + L::L_BETA + (par * GX::NG + w) * 2048);
-                const float *gsl = reinterpret_cast<const float *>(lds + L::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
+                const float *bsl = reinterpret_cast<const float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
+                const float *gsl = reinterpret_cast<const float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
                 const float4 b4 = *reinterpret_cast<const float4 *>(bsl + (PART * 64 + lane) * 4);
                 const float4 g4 = *reinterpret_cast<const float4 *>(gsl + (PART * 64 + lane) * 4);
-                const float *frow = reinterpret_cast<const float *>(lds + L::L_FP + (c & 1) * 3072) + (2 * loB + PART) * GX::FROW;
+                const float *frow = reinterpret_cast<const float *>(lds + GX::L_FP + (c & 1) * 3072) + (2 * loB + PART) * GX::FROW;
                 float fa[KP];
 #pragma unroll
                 for (int a4 = 0; a4 < KP / 4; ++a4) {
@@ -861,15 +829,15 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                     }
                 }
                 // the lane holds accF[px = 2 lo + PART][b = 4 g + r] of its group: one 16-byte store into the group's slot
-                float *part = reinterpret_cast<float *>(lds + L::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
+                float *part = reinterpret_cast<float *>(lds + GX::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
                 if (KP == 16 || gB < KP / 4)
                     *reinterpret_cast<float4 *>(part + (2 * loB + PART) * KP + 4 * gB) = float4{acc[0], acc[1], acc[2], acc[3]};
                 return;
             }
-            const unsigned char *fp = lds + L::L_FP + (c & 1) * 3072 + lane * 16;
-            const float *bslot = reinterpret_cast<const float *>(lds + L::L_BETA + (par * GX::NG + w) * 2048);
-            const float *gslot = reinterpret_cast<const float *>(lds + L::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
-            float *part = reinterpret_cast<float *>(lds + L::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
+            const unsigned char *fp = lds + GX::L_FP + (c & 1) * 3072 + lane * 16;
+            const float *bslot = reinterpret_cast<const float *>(lds + GX::L_BETA + (par * GX::NG + w) * 2048);
+            const float *gslot = reinterpret_cast<const float *>(lds + GX::L_GAM + (par * GX::NG + w) * 32 * GX::GROW * 4);
+            float *part = reinterpret_cast<float *>(lds + GX::L_PART + (par * GX::NG + w) * GX::PARTF * 4);
             const u32x4 Fh = *reinterpret_cast<const u32x4 *>(fp), Fm = *reinterpret_cast<const u32x4 *>(fp + 1024),
                         Fl = *reinterpret_cast<const u32x4 *>(fp + 2048);
             f32x16 zero;
@@ -920,15 +888,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #if QFA_GX_BPRIO && QFA_GX_BPRIO < 4
         __builtin_amdgcn_s_setprio(QFA_GX_BPRIO);
 #endif
-        constexpr int AHEAD = L::RING - 1;                 // half-steps between the request of an image half and its first read
-        if (n > 0) {
-            get_img(0);
-            if (AHEAD == 2) get_img(1);
-        }
+        if (n > 0) get_img(0);
         dma_wait<0>();
         step_barrier();
-        // requests of this wave for one image half / one F block (the counted wait leaves a whole half-step's requests in flight)
-        const int n_img = (GX::NCH_HALF - w + GX::NG - 1) / GX::NG, n_fp = w < 3 ? 1 : 0;
         for (int c = 0; c < n + 2; ++c) {
 #if QFA_GX_BPRIO == 4
             // this role is the slower one while role A works on a red tile, and the faster one on a blue tile
@@ -940,15 +902,15 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 const int t = 2 * c + h;
                 // The image DMA first, the flushes behind it, and a wait that leaves exactly the flushes in flight: they
                 // are device-scope atomics with a long round trip, and have until the end of the NEXT half-step.
-                int n_dma = 0;                             // image / F requests issued in THIS half-step
-                if (t + AHEAD < 2 * n) { get_img(t + AHEAD); n_dma += n_img; }
-                if (h == 0 && c < n) { get_F(c); n_dma += n_fp; }      // (first read in half-step 2 c + 2: landed behind the wait of 2 c + 1)
-                if (QFA_GX_ABL & 4) n_dma = 0;
-                // this wave's flush requests of the half-step (wave-uniform; none when role A flushes)
-                int nreq = 0;
-                if (!QFA_GX_FLUSH_A && h == 0) {
-                    if (c >= 1 && c <= n) nreq += flush_P(tile_of(c - 1), (c - 1) & 1);
-                    if (c >= 2) nreq += flush_F(tile_of(c - 2), c & 1);
+                if (t + 1 < 2 * n) get_img(t + 1);
+                if (h == 1 && c < n) get_F(c);
+                // requests of this wave's flushes (wave-uniform): F 2 (one as a 16-byte store, waves 0 and 1), P 1
+                const bool wP = wide ? tidB >= 128 : tidB < 128, wF = !wide || tidB < NWIDE;
+                const int nreq = (h == 0 && c >= 1 && c <= n && wP ? 1 : 0) +
+                                 (h == 0 && c >= 2 && wF ? (wide ? 1 : GX::PARTF / 256) : 0);
+                if (h == 0) {
+                    if (c >= 1 && c <= n) flush_P(tile_of(c - 1), (c - 1) & 1);
+                    if (c >= 2) flush_F(tile_of(c - 2), c & 1);
                 }
                 GXS(8 * h + 0)
                 if (c >= 1 && c <= n && active) {
@@ -957,16 +919,10 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
                 }
                 GXS(8 * h + 1)
                 if (QFA_GX_ABL & 2) dma_wait<0>();
-                else if (AHEAD == 2) {
-                    // three image slots: what this half-step requested (image of half t + 2, F block, flushes) may stay in
-                    // flight; everything older -- the image of half t + 1, the F block requested one half-step earlier --
-                    // has landed behind this wait
-                    dma_wait_n(n_dma + nreq);
-                }
                 else if (nreq == 3) dma_wait<3>();
                 else if (nreq == 2) dma_wait<2>();
                 else if (nreq == 1) dma_wait<1>();
-                else dma_wait<0>();            // (role A flushes: the image DMA is all this role has in flight)
+                else dma_wait<0>();
                 GXS(8 * h + 2)
                 step_barrier();
                 GXS(8 * h + 3)

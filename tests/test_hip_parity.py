@@ -733,3 +733,20 @@ def test_factored_z_input_form_matches_zabs_form_and_oracle(dev, npix, nh, B, fl
     pf = [x.cpu().numpy() for x in m.predict(ft[0], ft[1], None, ft[3], zfac=zfac)]
     for a, r, tol in zip(pf, pz, (5e-6, 2e-5, 2e-5, 2e-6, 5e-6)):
         assert np.max(np.abs(a - r)) <= tol * np.max(np.abs(r)), tol
+
+
+def test_sync_flag_returns_the_calls_own_status(dev):
+    """QFA_F_SYNC drains the stream inside the call, so that an asynchronous fault of this call's kernels would be returned
+    by this call (include/qfa_hip.h); on a healthy launch the results are those of the asynchronous call."""
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(300)
+    p, mu = synthetic.mock_parameters(300, nb, 12, seed=77)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, 40, seed=78)
+    m = make_model(dev, p, mu)
+    m.deterministic = True
+    a0 = m.accumulate(*batch_t(b, dev)).clone()
+    m.flags = _lib.F_SYNC
+    a1 = m.accumulate(*batch_t(b, dev)).clone()
+    assert np.array_equal(a0.cpu().numpy(), a1.cpu().numpy(), equal_nan=True)
+    pr = m.predict(*batch_t(b, dev, "flux"))
+    assert all(np.isfinite(x.cpu().numpy()).all() for x in pr)
