@@ -164,91 +164,107 @@ __global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void
                     glds16a(sbase + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(lds + (u & 1) * X::S1_HALF + ch * 1024)));
             }
         };
+        // Schedule of the requests (round 3).  The eight stores of a tile need an HBM write round trip; in the round-2
+        // order the image DMA of the next half-step was issued BEHIND them, and since vmcnt retires in issue order the wait
+        // for that DMA in front of the next barrier was a wait for the stores -- one write latency per tile on the
+        // critical path of every workgroup.  Now everything a tile step requests is issued IN FRONT of its stores:
+        //   half-step (c, 1):  mu(c + 1), image (c + 1, 0) -> slot 0 | MFMAs on slot 1 | barrier | image (c + 1, 1) -> slot 1 |
+        //                      stores of tile c | wait: all but [image (c + 1, 1), stores(c)] | barrier
+        //   half-step (c + 1, 0):  MFMAs on slot 0 | wait: all but stores(c) | barrier
+        // so the stores of tile c are first waited for at the end of half-step (c + 1, 1): three half-steps later.  Price: a
+        // third barrier per tile (slot 1 must be free before it is refilled in the same half-step).
+        const int n_p = (NCH - wv + 3) / 4;                  // image pieces of one half moved by this wave
         load_mu(t0);
         get_half(0);
+        get_half(1);
         dma_wait<0>();
         wg_barrier();
         asm volatile("" ::: "memory");
         float co0[4], un0[4];
+        bool prev_counted = false;                           // the previous tile's stores are the 8 youngest requests
+        auto stage1 = [&](int slot, f32x4 &afy, f32x4 &aq) {
+            const unsigned char *bp = lds + slot * X::S1_HALF + lane * 16;
+            afy = f32x4{0.f, 0.f, 0.f, 0.f};
+            aq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < X::NKS; ++ks) {
+                const u32x4 bh = *reinterpret_cast<const u32x4 *>(bp + ks * 3072),
+                            bm = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 1024),
+                            bl = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 2048);
+                if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
+                else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
+                __builtin_amdgcn_sched_barrier(0);           // (four waves per SIMD hide the LDS latency: one B buffer)
+            }
+        };
         for (int c = 0; c < n; ++c) {
             const int tg = t0 + c;
+            const bool more = c + 1 < n;
             land_mu();
             const float mc[2] = {mn0, mn1};
+            // ---- half-step (c, 0)
+            if (active) {
+                f32x4 afy, aq;
+                stage1(0, afy, aq);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int u = 2 * c + h;
-                if (h == 0 && c + 1 < n) load_mu(tg + 1);
-                if (u + 1 < 2 * n) get_half(u + 1);
-                bool counted = false;
-                if (active) {
-                    const unsigned char *bp = lds + (u & 1) * X::S1_HALF + lane * 16;
-                    f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
-#if QFA_PX_SINGLE_B          // (four waves per SIMD hide the LDS latency; the second B buffer would cost the fourth wave)
+                for (int r = 0; r < 4; ++r) {
+                    co0[r] = afy[r] + mc[0];
+                    un0[r] = __builtin_amdgcn_sqrtf(aq[r]);
+                }
+            }
+            if (prev_counted) dma_wait<8>();                 // image (c, 1) has landed; the stores of tile c - 1 may still fly
+            else dma_wait<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();
+            asm volatile("" ::: "memory");
+            // ---- half-step (c, 1)
+            if (more) {
+                load_mu(tg + 1);
+                get_half(2 * c + 2);                         // slot 0 is free behind the barrier
+            }
+            f32x4 afy1 = {0.f, 0.f, 0.f, 0.f}, aq1 = {0.f, 0.f, 0.f, 0.f};
+            if (active) stage1(1, afy1, aq1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();                                    // every wave has read slot 1
+            asm volatile("" ::: "memory");
+            int q1 = 0;
+            if (more) {
+                get_half(2 * c + 3);
+                q1 = n_p;
+            }
+            bool counted = false;
+            if (active) {
+                const float m = mc[1];
+                const int px = 32 * tg + 2 * lo;
+                if (full_wave && 32 * tg + 31 < Npix) {      // wave-uniform: exactly eight store instructions
 #pragma unroll
-                    for (int ks = 0; ks < X::NKS; ++ks) {
-                        const u32x4 bh = *reinterpret_cast<const u32x4 *>(bp + ks * 3072),
-                                    bm = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 1024),
-                                    bl = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 2048);
-                        if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
-                        else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int r = 0; r < 4; ++r) {
+                        const size_t o = (size_t)(s0 + 4 * g + r) * Npix + px;
+                        *reinterpret_cast<pxf2 *>(cont + o) = pxf2{{co0[r], afy1[r] + m}};
+                        *reinterpret_cast<pxf2 *>(unc + o) = pxf2{{un0[r], __builtin_amdgcn_sqrtf(aq1[r])}};
                     }
-#else
-                    u32x4 bq[2][3];
+                    counted = true;
+                } else {
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
-#pragma unroll
-                    for (int ks = 0; ks < X::NKS; ++ks) {
-                        if (ks + 1 < X::NKS) {
-#pragma unroll
-                            for (int pc = 0; pc < 3; ++pc)
-                                bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = s0 + 4 * g + r;
+                        if (s < B && px < Npix) {
+                            cont[(size_t)s * Npix + px] = co0[r];
+                            unc[(size_t)s * Npix + px] = un0[r];
                         }
-                        const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
-                        if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
-                        else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
-                    }
-#endif
-                    const float m = mc[h];
-                    if (h == 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            co0[r] = afy[r] + m;
-                            un0[r] = __builtin_amdgcn_sqrtf(aq[r]);
-                        }
-                    } else {
-                        const int px = 32 * tg + 2 * lo;
-                        if (full_wave && 32 * tg + 31 < Npix) {          // wave-uniform: exactly eight store instructions
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const size_t o = (size_t)(s0 + 4 * g + r) * Npix + px;
-                                *reinterpret_cast<pxf2 *>(cont + o) = pxf2{{co0[r], afy[r] + m}};
-                                *reinterpret_cast<pxf2 *>(unc + o) = pxf2{{un0[r], __builtin_amdgcn_sqrtf(aq[r])}};
-                            }
-                            counted = true;
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int s = s0 + 4 * g + r;
-                                if (s < B && px < Npix) {
-                                    cont[(size_t)s * Npix + px] = co0[r];
-                                    unc[(size_t)s * Npix + px] = un0[r];
-                                }
-                                if (s < B && px + 1 < Npix) {
-                                    cont[(size_t)s * Npix + px + 1] = afy[r] + m;
-                                    unc[(size_t)s * Npix + px + 1] = __builtin_amdgcn_sqrtf(aq[r]);
-                                }
-                            }
+                        if (s < B && px + 1 < Npix) {
+                            cont[(size_t)s * Npix + px + 1] = afy1[r] + m;
+                            unc[(size_t)s * Npix + px + 1] = __builtin_amdgcn_sqrtf(aq1[r]);
                         }
                     }
                 }
-                // the pieces of half u + 1 were issued before this half-step's stores: all but the eight stores must be done
-                if (counted) dma_wait<8>();
-                else dma_wait<0>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                wg_barrier();
-                asm volatile("" ::: "memory");
             }
+            // image (c + 1, 0) and mu(c + 1) were issued in front of the image (c + 1, 1) pieces and the stores
+            if (counted) dma_wait_n(8 + q1);
+            else dma_wait<0>();
+            prev_counted = counted;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();
+            asm volatile("" ::: "memory");
         }
         return;
     }
