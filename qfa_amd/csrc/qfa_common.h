@@ -221,11 +221,38 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {       // [15:0] = bf16(a), [31:16] = bf16(b), RNE
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// [15:0] = bf16(a), [31:16] = bf16(b), round to nearest even: v_cvt_pk_bf16_f32, selected by hipcc from the vector conversion.
+// (Rounds 1-2 wrote the instruction as inline asm; hipcc then knows nothing about its result, which is what left the
+// VALU -> MFMA hazard of section 4 of DESIGN.md uncovered and made v_dot2c_f32_bf16 behind it return stale operands.)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2));
 }
+// The bf16 pairs {-1, 0} and {0, -1} in SGPRs, hidden from constant folding: hipcc encodes a known 0x0000bf80 operand of
+// v_dot2c_f32_bf16 as the INLINE constant -1.0, which the instruction reads as float32 bits (0xbf800000 = {0, -1}): the wrong half.
+__device__ __forceinline__ unsigned split_c_lo() {
+    unsigned c;
+    asm("s_mov_b32 %0, 0xbf80" : "=s"(c));
+    return c;
+}
+__device__ __forceinline__ unsigned split_c_hi() {
+    unsigned c;
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(c));
+    return c;
+}
+// x - bf16 half of a packed pair in ONE instruction: v_dot2c_f32_bf16  D = D + A.lo B.lo + A.hi B.hi  with B = {-1, 0} / {0, -1}
+// (the shift / and + v_sub_f32 form costs two).  Bit-identical to the subtraction on 4.2 M random pairs with exponents
+// 2^-67 .. 2^62 (round 3, on the card); below that the dot instruction flushes denormal residuals.
+__device__ __forceinline__ float sub_bf16_lo(float x, unsigned packed) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), __builtin_bit_cast(bf16x2, split_c_lo()), x, false);
+}
+__device__ __forceinline__ float sub_bf16_hi(float x, unsigned packed) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), __builtin_bit_cast(bf16x2, split_c_hi()), x, false);
+}
+#ifndef QFA_SPLIT_DOT2
+#define QFA_SPLIT_DOT2 1      // 0: residuals by shift / and + v_sub_f32 (11 instead of 7 instructions per pair of values)
+#endif
 // two float32 values -> three packed bf16 pairs with x = h + m + l exactly
 __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
 #if QFA_ABL == 12          // timing only: no split arithmetic
@@ -233,9 +260,15 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned
     return;
 #endif
     h = cvt_pk_bf16(x0, x1);
+#if QFA_SPLIT_DOT2
+    const float r0 = sub_bf16_lo(x0, h), r1 = sub_bf16_hi(x1, h);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = sub_bf16_lo(r0, m), s1 = sub_bf16_hi(r1, m);
+#else
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
     m = cvt_pk_bf16(r0, r1);
     const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+#endif
     l = cvt_pk_bf16(s0, s1);
 }
 __device__ __forceinline__ f32x4 xdl(const u32x4 &a, const u32x4 &b, f32x4 c) {          // K = 32
