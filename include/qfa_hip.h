@@ -80,6 +80,8 @@ typedef struct {
 #define QFA_F_SYNC         0x20u /* debugging: synchronise `stream` before returning, so that an asynchronous fault of
                                     THIS call's kernels is returned by THIS call (positive hipError_t) instead of
                                     surfacing at the caller's next synchronisation without context               */
+#define QFA_F_PASS2_PIXRES 0x40u /* N_h = 9..16: the pixel-resident form of the all-XDL pass 2 (k_grads_t: a wave owns 16
+                                  * pixels and walks the spectra; the per-spectrum operands stream through LDS)           */
 #define QFA_F_PASS2_WFORM  0x10u /* N_h <= 16: the one-wave-per-SIMD form of the all-XDL pass 2 (k_grads_w: stage 3
                                     re-associated as a K = spectrum GEMM; same results, slower -- DESIGN.md)    */
 

@@ -23,6 +23,7 @@ TAU_IDS = {"becker": 0, "fg": 1, "kamble": 2, "mock": 3}
 ABI_VERSION = 2
 # `flags` of qfa_nll_grad_ex_f32 / qfa_predict_ex_f32 (include/qfa_hip.h QFA_F_*)
 F_PASS2_F32, F_PASS2_XDL, F_S3_FAST, F_PREDICT_F32, F_PASS2_WFORM, F_SYNC = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+F_PASS2_PIXRES = 0x40
 
 
 class QFAHipError(RuntimeError):

@@ -1,0 +1,682 @@
+// qfa_grads_t.h -- pass 2 (gradients) for N_h = 9..16 in its PIXEL-RESIDENT form: a wave owns 16 pixels and walks the spectra.
+//
+// k_grads_x (qfa_grads_x.h) keeps the per-spectrum operands of 64 spectra in registers and walks the pixel axis: every
+// tile step ends in a contraction of W with F on the VALU, 34 16-byte LDS stores of partial sums per wave, a flush that
+// reads them back and 0.54 GB of float atomics per launch at c3 -- and the kernel is bound by the instructions it
+// issues ("What binds pass 2").  Every output of pass 2 is a sum over SPECTRA per pixel, so here
+// the roles of the two axes are exchanged:
+//   * a wave owns ONE 16-pixel tile for the whole launch: the stage-1 image of its pixels (B operand, 60 registers),
+//     their Psi / omega / factored-z terms, and the running sums -- W[px][a][b] = sum_s Z_s[a][b] beta[s][px] as 16
+//     MFMA accumulator tiles (64 registers), the gamma term, gPsi, gOmega, sumA, the count;
+//   * the per-spectrum operands of a group of 16 spectra (the "state": [Cinv' | y] pieces for stage 1, Z and p pieces
+//     for stage 3, 52 KiB, written once per launch by k_prep_pst) stream through an LDS ring by LDS-DMA, shared by
+//     the workgroup's 8 waves (8 tiles = 128 pixels);
+//   * beta / gamma never leave the lane: stage 2 leaves them in exactly the layout stage 3's B operand wants;
+//   * F enters once, at the end: accF[px][b] = sum_a F[px][a] W[px][a][b] + the gamma term, then ONE atomic (or slab
+//     store) per output element and spectra range -- no partial sums in LDS, no flush in the loop.
+// Per (16 spectra x 16 pixels) a wave issues 36 + 51 MFMAs (as before), 52 ds_read_b128 for their streamed operands,
+// stage 2 of four elements per lane and two bf16 splits.
+//
+// Workgroup = 512 threads = 8 waves = 8 tiles (strided over the pixel axis: tile pb + PB w, so that every workgroup
+// gets its share of blue tiles) x one RANGE of spectra groups; grid = PB pixel blocks x R ranges, block = pb R + r.  With
+// R a multiple of 8 the workgroups of one range sit on one XCD (block % 8) and walk the same state in step: it is read from
+// HBM once and from that XCD's L2 by the others (measured: 3.9 GB fetched per launch at c3 against 3.6 GB of spectra).
+// The schedule of a step (one barrier per group, the two waves of a SIMD a stage apart) is described at the walk below.
+// The spectra (delta, sigma, zabs rows -- or the per-spectrum factors of the factored-z form: 64 bytes per row and tile;
+// masks 16) are staged per wave, two groups ahead, as in k_grads_x.  All DMA is asm (untracked) with counted waits;
+// ragged tiles (the last tile of a pixel axis that is no multiple of 16, the tile that straddles the end of the blue side in
+// the zabs form) stage 4-byte pieces and wait for everything.
+#pragma once
+#include "qfa_common.h"
+#include "qfa_xdl_kernels.h"
+#include "qfa_grads_x.h"          // split8, SpecA's neighbours: the image format of stage 1 is k_prep_pgx's, per 16 pixels
+
+template <int KP_>
+struct GTT {
+    static constexpr int KP = KP_, KK2 = KP * (KP + 1) / 2;
+    // K axis of stage 1: the KK2 pair products, then (in the free slots of the last 32-wide block, from slot YOFF) the KP
+    // values of F / y.  The pixel side (B operand, in registers for the whole walk) is ONE image of NKQ blocks; the spectrum
+    // side has NKQ blocks [Cinv' | 0] for f^T Cinv f and one more block [0 | y | 0] that meets the last image block again
+    // for f^T y: 36 MFMAs as with a separate y block, 60 instead of 72 registers.
+    static constexpr int NKQ = (KK2 + 31) / 32;              // 5
+    static constexpr int YOFF = (KK2 % 32 + 7) / 8 * 8;      // 8
+    static_assert(KK2 % 32 != 0 && YOFF + KP <= 32, "F / y share the last pair block");
+    static constexpr int NKS = NKQ + 1;                      // blocks of the spectrum side (6)
+    // per 16-pixel tile in global memory (k_prep_pgt)
+    static constexpr int IMG_B = NKQ * 3 * 1024;             // [ks][piece][lane (g, lo)][8 k] bf16: B[k = 32 ks + 8 g + j][px = lo]
+    static constexpr int OFF_PAR = IMG_B;                    // float Psi[16] | omega[16] | ti[16] | pwi[16] | l2i[16]
+    static constexpr int OFF_F = IMG_B + 512;                // float F[16 px][KP]
+    static constexpr int TILE_B = (OFF_F + 16 * KP * 4 + 1023) / 1024 * 1024;
+    // per group of 16 spectra in global memory (k_prep_pst)
+    static constexpr int S1_B = NKS * 3 * 1024;              // [block][piece][lane (g, lo = spectrum)][8 k]: A[s][k] of stage 1
+    static constexpr int S1P_B = S1_B;                       // (the S1 part as the ring holds it)
+    static constexpr int Z_B = KP * 2 * 1024;                // [a][operand 1, 2][lane (g, lo = b)][4 dwords]
+    static constexpr int ZP_B = Z_B + 2 * 1024;              // + the p operands (gamma term)
+    static constexpr int STATE_B = S1P_B + ZP_B;
+    static constexpr int NW = 8;                             // waves = tiles per workgroup
+    // a part moves as 1-KiB pieces, each wave a contiguous run of them (one write of M0 per run, glds16_run): wave w takes
+    // XQ + (w < XR) pieces from piece w XQ + min(w, XR)
+    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34
+    static constexpr int S1_Q = S1_PCS / NW, S1_R = S1_PCS % NW, Z_Q = Z_PCS / NW, Z_R = Z_PCS % NW;     // 2 r 2, 4 r 2
+    static_assert(S1_Q >= 1 && S1_Q + 1 <= 5 && Z_Q >= 1 && Z_Q + 1 <= 5, "runs of 1..5 pieces");
+    // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
+    // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
+    static constexpr int STG_ARR = 1024, STG_MASK = 3 * STG_ARR, STG_B = 3 * STG_ARR + 256;
+    static constexpr int L_S1 = 0;                           // [2][S1P_B]
+    static constexpr int L_Z = L_S1 + 2 * S1P_B;             // [2][ZP_B]
+    static constexpr int L_STG = L_Z + 2 * ZP_B;             // [NW][2][STG_B]
+    static constexpr int L_TOTAL = L_STG + NW * 2 * STG_B;
+};
+static_assert(GTT<16>::L_TOTAL <= 160 * 1024, "k_grads_t LDS");
+
+// the split of the launch: tiles, pixel blocks, ranges of spectra groups (host and device agree through this struct)
+struct GtPlan {
+    int T16, PB, R, gpr;          // 16-pixel tiles; pixel blocks of 8 tiles; ranges; groups of 16 spectra per range
+    __host__ __device__ int items() const { return PB * R; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_prep_pgt : F, Psi, omega (+ the per-pixel factors of the factored-z form) -> the image of every 16-pixel tile
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void k_prep_pgt(const float *__restrict__ F, const float *__restrict__ Psi,
+                                                  const float *__restrict__ omega, const float4 *__restrict__ ZP,
+                                                  int Npix, int Nb, int Nh, unsigned char *__restrict__ PGT) {
+    using GT = GTT<KP>;
+    unsigned char *tile = PGT + (size_t)blockIdx.x * GT::TILE_B;
+    const int p0 = 16 * blockIdx.x;
+    __shared__ float f[16][KP + 1];
+    for (int i = threadIdx.x; i < 16 * KP; i += 256) {
+        const int px = i / KP, a = i % KP;
+        f[px][a] = (p0 + px < Npix && a < Nh) ? F[(size_t)(p0 + px) * Nh + a] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GT::NKQ * 64; i += 256) {
+        const int lane = i & 63, ks = i >> 6;
+        const int px = lane & 15, g = lane >> 4;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = 32 * ks + 8 * g + j;                       // pair index, or KK2-block slot of F
+            float x = 0.f;
+            if (q < GT::KK2) {
+                int a = 0;
+                while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
+                const int b = a + (q - pair_index(a, a, KP));
+                x = f[px][a] * f[px][b];
+            } else {
+                const int a = q - (32 * (GT::NKQ - 1) + GT::YOFF);
+                if (a >= 0 && a < KP) x = f[px][a];
+            }
+            v[j] = x;
+        }
+        u32x4 ph, pm, pl;
+        split8(v, ph, pm, pl);
+        unsigned char *dst = tile + ks * 3072 + lane * 16;
+        *reinterpret_cast<u32x4 *>(dst) = ph;
+        *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+        *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+    }
+    if (threadIdx.x < 128) {
+        const int j = threadIdx.x, px = p0 + (j & 15);
+        float v = 0.f;
+        if (j < 16) v = px < Npix ? Psi[px] : 0.f;
+        else if (j < 32) v = px < Nb ? omega[px] : 0.f;
+        else if (j < 80 && ZP && px < Nb) {
+            const float4 q = ZP[px];
+            v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
+        }
+        reinterpret_cast<float *>(tile + GT::OFF_PAR)[j] = v;
+    }
+    float *fr = reinterpret_cast<float *>(tile + GT::OFF_F);
+    for (int i = threadIdx.x; i < 16 * KP; i += 256) fr[i] = f[i / KP][i % KP];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_prep_pst : the solve's output (SOL, float32 per spectrum) -> the state of every group of 16 spectra as split-bf16
+// MFMA operands, in the order the walk streams them.  One block per group.
+//   S1 part: A[m = spectrum lo][k = 8 g + j of block ks] = ks < NKQ: Cinv'[pair 32 ks + 8 g + j] | ks = NKQ: y[8 g + j - YOFF]
+//   Z  part: per column tile a, operands ZA1 = {l01, l23, h01, h23}, ZA2 = {h01, h23, m01, m23} of
+//            x[r] = Z_{4 g + r}[a][b = lo] (row m = b; k = 8 g + j <-> spectrum 4 g + (j & 3), piece slot j >> 2);
+//            then the same two operands of p_{4 g + r}[b]
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void k_prep_pst(const float *__restrict__ SOL, int B, int Nh, unsigned char *__restrict__ PST) {
+    using C = Cfg<KP>;
+    using GT = GTT<KP>;
+    unsigned char *st = PST + (size_t)blockIdx.x * GT::STATE_B;
+    const int s0 = 16 * blockIdx.x;
+    for (int i = threadIdx.x; i < GT::NKS * 64; i += 256) {
+        const int lane = i & 63, ks = i >> 6, lo = lane & 15, g = lane >> 4;
+        const bool v = s0 + lo < B;
+        const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float val = 0.f;
+            if (ks < GT::NKQ) {                                          // blocks 0 .. NKQ - 1: Cinv' (doubled off-diagonals)
+                const int q = 32 * ks + 8 * g + j;
+                if (v && q < GT::KK2) val = sol[C::SOL_CI + q];
+            } else {                                                     // block NKQ: y in the slots of F in the last image block
+                const int a = 8 * g + j - GT::YOFF;
+                if (v && a >= 0 && a < KP) val = sol[a];
+            }
+            x[j] = val;
+        }
+        u32x4 h, m, l;
+        split8(x, h, m, l);
+        unsigned char *dst = st + ks * 3072 + lane * 16;
+        *reinterpret_cast<u32x4 *>(dst) = h;
+        *reinterpret_cast<u32x4 *>(dst + 1024) = m;
+        *reinterpret_cast<u32x4 *>(dst + 2048) = l;
+    }
+    for (int i = threadIdx.x; i < (KP + 1) * 64; i += 256) {
+        const int lane = i & 63, a = i >> 6, lo = lane & 15, g = lane >> 4;       // a == KP: the p operands
+        float x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = s0 + 4 * g + r;
+            const bool v = s < B && lo < Nh && lo < KP;
+            const float *sol = SOL + (size_t)(v ? s : 0) * C::NSOL;
+            x[r] = v ? (a < KP ? sol[C::SOL_Z + a * KP + (lo & (KP - 1))] : sol[C::SOL_P + (lo & (KP - 1))]) : 0.f;
+        }
+        unsigned h01, m01, l01, h23, m23, l23;
+        split2(x[0], x[1], h01, m01, l01);
+        split2(x[2], x[3], h23, m23, l23);
+        unsigned char *dst = st + GT::S1P_B + a * 2048 + lane * 16;
+        *reinterpret_cast<u32x4 *>(dst) = u32x4{l01, l23, h01, h23};
+        *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{h01, h23, m01, m23};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_grads_t
+// slab != NULL: deterministic mode -- the sums of range r go to row r of the slab (plain stores, every element of the row
+// written exactly once), the scalar sums to slabS[block][wave][3]; the slab reducer adds the rows in order.
+// ------------------------------------------------------------------------------------------------
+#ifndef QFA_GT_STAMPS
+#define QFA_GT_STAMPS 0    // diagnostic build (tools/gt_stamps.sh): s_memtime shares of the walk of two waves of one workgroup
+#endif
+#if QFA_GT_STAMPS
+__device__ unsigned long long qfa_gt_stamps[2 * 16];
+#define GTS(i)                                                                                 \
+    {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        unsigned long long t_;                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        st_[i] += (unsigned)(t_ - st_last);                                                    \
+        st_last = t_;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+#else
+#define GTS(i) {}
+#endif
+template <int KP, bool HASA, bool ZF>
+__global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix, int Nb,
+                                                    int Nh, GtPlan gp, const unsigned char *__restrict__ PGT,
+                                                    const unsigned char *__restrict__ PST, const float4 *__restrict__ ZS,
+                                                    float *__restrict__ accum,
+                                                    float *__restrict__ slab, double *__restrict__ slabS, int slab_stride,
+                                                    Scal64 *__restrict__ sc64) {
+    using GT = GTT<KP>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[GT::L_TOTAL];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv8 = wave_uniform(tid >> 6);
+    const int lo = lane & 15, g = lane >> 4;
+    const int rr = (int)blockIdx.x % gp.R, pb = (int)blockIdx.x / gp.R;
+    const int G = (B + 15) >> 4;
+    const int g0 = rr * gp.gpr;                             // first group of the range
+    const int n = max(0, min(gp.gpr, G - g0));              // groups in the range (the same for every wave: the barriers)
+    const int tl = pb + gp.PB * wv8;                        // this wave's tile
+#ifndef QFA_GT_ONLY
+#define QFA_GT_ONLY 0      // timing experiments (wrong results): 1 = waves 0..3 only, 2 = waves 4..7 only
+#endif
+    const bool active = tl < gp.T16 && (QFA_GT_ONLY == 0 || (QFA_GT_ONLY == 1) == (wv8 < 4));      // wave-uniform
+    const int px = 16 * tl + lo;
+    const bool inb = active && px < Npix, blue = active && px < Nb;
+    const bool blueTile = active && 16 * tl < Nb;           // wave-uniform: the tile has blue pixels
+    const DevConsts k = load_consts(p, tau);
+    const bool det = slab != nullptr;
+    float *accF = det ? slab + (size_t)rr * (size_t)slab_stride : accum;
+    float *accA = accF + (size_t)Npix * Nh;                 // sumA | gPsi | gOmega | cnt
+    float *accS = accum + (size_t)Npix * Nh + 3 * (size_t)Npix + Nb;
+
+#if QFA_GT_STAMPS
+    unsigned st_[8];
+    for (int i = 0; i < 8; ++i) st_[i] = 0;
+    unsigned long long st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+    // ---- static operands of the wave's tile
+    const unsigned char *tile = PGT + (size_t)(active ? tl : 0) * GT::TILE_B;
+    u32x4 IBh[GT::NKQ], IBm[GT::NKQ], IBl[GT::NKQ];
+#pragma unroll
+    for (int ks = 0; ks < GT::NKQ; ++ks) {
+        IBh[ks] = *reinterpret_cast<const u32x4 *>(tile + ks * 3072 + lane * 16);
+        IBm[ks] = *reinterpret_cast<const u32x4 *>(tile + ks * 3072 + 1024 + lane * 16);
+        IBl[ks] = *reinterpret_cast<const u32x4 *>(tile + ks * 3072 + 2048 + lane * 16);
+    }
+    const float *par = reinterpret_cast<const float *>(tile + GT::OFF_PAR);
+    const float Psi = par[lo], om = par[16 + lo];
+    const float ti = ZF ? par[32 + lo] : 0.f, pwi = ZF ? par[48 + lo] : 0.f, l2i = ZF ? par[64 + lo] : 0.f;
+
+    // Every load of this prologue is consumed HERE: hipcc puts the s_waitcnt of a load in front of its first use, and a first
+    // use inside the walk leaves a vmcnt(0..4) in the loop that drains the untracked DMA queue in every step (stage 2 of
+    // a blue group took 2 550 cycles that way, tools/gt_stamps.sh)
+#pragma unroll
+    for (int ks = 0; ks < GT::NKQ; ++ks) asm volatile("" ::"v"(IBh[ks]), "v"(IBm[ks]), "v"(IBl[ks]));
+    asm volatile("" ::"v"(Psi), "v"(om), "v"(ti), "v"(pwi), "v"(l2i), "v"(k.tau0), "v"(k.c0), "v"(k.beta), "v"(k.t_amp), "v"(k.t_lscale),
+                 "v"(k.t_expo), "v"(k.t_off), "v"(k.offp), "v"(k.k1), "v"(k.omc0));
+
+    // ---- running sums
+    f32x4 W[KP];
+#pragma unroll
+    for (int a = 0; a < KP; ++a) W[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
+    float gPsi = 0.f, gOm = 0.f, sA = 0.f, cnt = 0.f;
+    double d_tau0 = 0.0, d_c0 = 0.0, d_beta = 0.0;
+    f32x4 betaR = {0.f, 0.f, 0.f, 0.f}, gamR = {0.f, 0.f, 0.f, 0.f};      // stage 2 -> stage 3 (across one barrier)
+
+    // ---- spectra staging of this wave
+    unsigned char *stg = lds + GT::L_STG + wv8 * 2 * GT::STG_B;
+    const bool fastp = active && 16 * tl + 15 < Npix;
+    const bool zblue = !ZF && blueTile;                     // the tile stages zabs
+    const bool fastz = !zblue || 16 * tl + 15 < Nb;
+    const bool slow = active && !(fastp && fastz);          // ragged tiles: 4-byte pieces, every wait a full one
+    const bool zfb = ZF && blueTile;                        // the tile stages the per-spectrum factors of the factored-z form
+    const int nsp = !active ? 0 : ((zblue || zfb) ? 4 : 3); // requests per group of a fast tile
+    // group t of the range: rows s0 .. s0 + 15
+    auto stage_spectra = [&](int t, int bufi) {
+        if (!active) return;
+        const int s0 = 16 * (g0 + t);
+        const int last_row = min(15, B - 1 - s0);                                     // wave-uniform, >= 0
+        const float *dbase = uniform_ptr(bt.delta + (size_t)s0 * Npix);
+        const float *ebase = uniform_ptr(bt.error + (size_t)s0 * Npix);
+        const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)s0 * Npix);
+        const float *zbase = zblue ? uniform_ptr(bt.zabs + (size_t)s0 * Nb) : dbase;
+        const unsigned dst = wave_uniform(lds_addr(stg + bufi * GT::STG_B));
+#if QFA_TRACKED_LOADS
+        {
+            float *sf = reinterpret_cast<float *>(stg + bufi * GT::STG_B);
+            unsigned char *mb = stg + bufi * GT::STG_B + GT::STG_MASK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 4 * i + g;
+                const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+                const int pxx = 16 * tl + lo;
+                const unsigned o = row * (unsigned)Npix + (unsigned)min(pxx, Npix - 1);
+                sf[0 * 256 + q * 16 + lo] = dbase[o];
+                sf[1 * 256 + q * 16 + lo] = ebase[o];
+                if (zblue) sf[2 * 256 + q * 16 + lo] = zbase[row * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)];
+                mb[q * 16 + lo] = pxx < Npix ? mbase[o] : (unsigned char)0;
+            }
+            if (zfb && lane < 16) reinterpret_cast<float4 *>(sf + 2 * 256)[lane] = ZS[s0 + min(lane, last_row)];
+            (void)dst;
+            return;
+        }
+#endif
+        // factored-z form: the factors of the 16 spectra (row r at float4 index r of array 2), one request of 16 lanes
+        if (zfb && lane < 16)
+            glds16a(uniform_ptr(ZS + s0), 16u * (unsigned)min(lane, last_row), dst + 2 * GT::STG_ARR);
+        if (!slow) {
+            const int q = lane >> 2;                                                  // staging slot; holds row q ^ ((q >> 2) & 1)
+            const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+            const unsigned pc = 16u * (unsigned)tl + 4u * (unsigned)(lane & 3);       // first pixel of the lane's piece
+            const unsigned o = row * (unsigned)Npix + pc;
+            // delta, sigma, (zabs,) the masks (16 rows x 16 bytes as 4-byte pieces): one write of M0, the LDS offsets in the
+            // instructions' immediate fields, taken off the global bases again
+            const unsigned vo = 4u * o, vz = 4u * (row * (unsigned)Nb + pc);
+            const unsigned char *eb = reinterpret_cast<const unsigned char *>(ebase) - GT::STG_ARR;
+            const unsigned char *zb = reinterpret_cast<const unsigned char *>(zbase) - 2 * GT::STG_ARR;
+            const unsigned char *mb_ = reinterpret_cast<const unsigned char *>(mbase) - GT::STG_MASK;
+            if (zblue)
+                asm volatile("s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+                             "global_load_lds_dwordx4 %0, %4 offset:1024\n\tglobal_load_lds_dwordx4 %1, %5 offset:2048\n\t"
+                             "global_load_lds_dword %2, %6 offset:3072"
+                             ::"v"(vo), "v"(vz), "v"(o), "s"(dbase), "s"(eb), "s"(zb), "s"(mb_), "s"(dst) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                             "global_load_lds_dwordx4 %0, %3 offset:1024\n\tglobal_load_lds_dword %1, %4 offset:3072"
+                             ::"v"(vo), "v"(o), "s"(dbase), "s"(eb), "s"(mb_), "s"(dst) : "memory");
+            return;
+        }
+        // ragged tile: 4-byte pieces with the pixel clamped per lane (4 slots per instruction), masks through registers
+        unsigned char *mb = stg + bufi * GT::STG_B + GT::STG_MASK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 4 * i + g;
+            const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+            const int pxx = 16 * tl + lo;
+            const unsigned o = row * (unsigned)Npix + (unsigned)min(pxx, Npix - 1);
+            glds4a(dbase, 4u * o, dst + i * 256);
+            glds4a(ebase, 4u * o, dst + GT::STG_ARR + i * 256);
+            if (zblue) glds4a(zbase, 4u * (row * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+            mb[q * 16 + lo] = pxx < Npix ? mbase[o] : (unsigned char)0;
+        }
+    };
+
+    // ---- the state parts: every wave moves its contiguous run of pieces
+    const int s1_first = wv8 * GT::S1_Q + min(wv8, GT::S1_R), z_first = wv8 * GT::Z_Q + min(wv8, GT::Z_R);
+    const bool s1_long = wv8 < GT::S1_R, z_long = wv8 < GT::Z_R;          // wave-uniform: one piece more
+    const int s1_req = GT::S1_Q + (s1_long ? 1 : 0), z_req = GT::Z_Q + (z_long ? 1 : 0);
+    auto issue_S1 = [&](int t) {
+        const unsigned char *src = uniform_ptr(PST + (size_t)(g0 + t) * GT::STATE_B + s1_first * 1024);
+        const unsigned dst = wave_uniform(lds_addr(lds + GT::L_S1 + (t & 1) * GT::S1P_B + s1_first * 1024));
+        if (s1_long) glds16_run<GT::S1_Q + 1>(src, (unsigned)lane * 16u, dst);
+        else glds16_run<GT::S1_Q>(src, (unsigned)lane * 16u, dst);
+    };
+    auto issue_Z = [&](int t) {
+        const unsigned char *src = uniform_ptr(PST + (size_t)(g0 + t) * GT::STATE_B + GT::S1P_B + z_first * 1024);
+        const unsigned dst = wave_uniform(lds_addr(lds + GT::L_Z + (t & 1) * GT::ZP_B + z_first * 1024));
+        if (z_long) glds16_run<GT::Z_Q + 1>(src, (unsigned)lane * 16u, dst);
+        else glds16_run<GT::Z_Q>(src, (unsigned)lane * 16u, dst);
+    };
+
+    // A part's pieces are issued one by one BETWEEN the MFMA groups of the stage that runs in the same half-step: eight waves
+    // that issue their runs together behind the barrier fill the texture path's queue (16 cycles per piece) and wait in
+    // front of it -- 900 - 1 400 cycles per group and wave (tools/gt_stamps.sh).  j-th piece of this wave's run:
+    struct Part {
+        const unsigned char *src;
+        unsigned dst;
+        int cnt;
+    };
+    auto part_S1 = [&](int t) {          // (t >= n: nothing to issue)
+        return Part{uniform_ptr(PST + (size_t)(g0 + min(t, n - 1)) * GT::STATE_B + s1_first * 1024),
+                    (unsigned)wave_uniform(lds_addr(lds + GT::L_S1 + (t & 1) * GT::S1P_B + s1_first * 1024)), t < n ? s1_req : 0};
+    };
+    auto part_Z = [&](int t) {
+        return Part{uniform_ptr(PST + (size_t)(g0 + min(t, n - 1)) * GT::STATE_B + GT::S1P_B + z_first * 1024),
+                    (unsigned)wave_uniform(lds_addr(lds + GT::L_Z + (t & 1) * GT::ZP_B + z_first * 1024)), t < n ? z_req : 0};
+    };
+    auto piece = [&](const Part &pt, int j) {
+        if (j < pt.cnt) glds16a_nc(pt.src + 1024 * j, (unsigned)lane * 16u, pt.dst + 1024 * j);
+    };
+
+    // ---- stage 1 of group t (its results wait in afy / aq for stage 2, one half-step later)
+    f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+    auto stage1 = [&](int t, const Part &pt) {
+        const unsigned char *sp = lds + GT::L_S1 + (t & 1) * GT::S1P_B + lane * 16;
+        afy = f32x4{0.f, 0.f, 0.f, 0.f};
+        aq = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 aop[2][3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) aop[0][pc] = *reinterpret_cast<const u32x4 *>(sp + pc * 1024);
+#pragma unroll
+        for (int ks = 0; ks < GT::NKS; ++ks) {
+            if (ks + 1 < GT::NKS) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    aop[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(sp + (ks + 1) * 3072 + pc * 1024);
+            }
+            piece(pt, ks);
+            const u32x4 &ah = aop[ks & 1][0], &am = aop[ks & 1][1], &al = aop[ks & 1][2];
+            if (ks < GT::NKQ) aq = xdl6(ah, am, al, IBh[ks], IBm[ks], IBl[ks], aq);
+            else afy = xdl6(ah, am, al, IBh[GT::NKQ - 1], IBm[GT::NKQ - 1], IBl[GT::NKQ - 1], afy);     // the y block
+        }
+        GTS(5)
+    };
+    // ---- stage 2 of group t
+    auto stage2_t = [&](auto blue_tag, int t, const Part &pt) {
+        constexpr bool BLUE = decltype(blue_tag)::value;       // (the tile has blue pixels: wave-uniform, one branch per stage)
+        const int s0 = 16 * (g0 + t);
+        // the lane's four elements: spectra 4 g + r at pixel lo; the mask goes into the sign of sigma
+        const unsigned char *sb = stg + (t & 1) * GT::STG_B;
+        float dv[4], sgv[4], zv[4];
+        unsigned mk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = (4 * g + r) ^ (g & 1);
+            dv[r] = *reinterpret_cast<const float *>(sb + (q * 16 + lo) * 4);
+            sgv[r] = *reinterpret_cast<const float *>(sb + GT::STG_ARR + (q * 16 + lo) * 4);
+            zv[r] = (!ZF && BLUE) ? *reinterpret_cast<const float *>(sb + 2 * GT::STG_ARR + (q * 16 + lo) * 4) : 0.f;
+            mk[r] = sb[GT::STG_MASK + q * 16 + lo];
+            // (every read is issued here: left to itself hipcc reads sigma under a branch on the mask, one LDS round trip
+            // after the other -- 3 600 cycles for stage 2 of a blue group, tools/gt_stamps.sh)
+            asm volatile("" : "+v"(sgv[r]), "+v"(mk[r]));
+        }
+        float zqx[4], zqy[4], zqz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zqx[r] = 0.f; zqy[r] = 0.f; zqz[r] = 0.f; }
+        if (ZF && BLUE) {
+            const float4 *zsl = reinterpret_cast<const float4 *>(sb + 2 * GT::STG_ARR);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 q = zsl[4 * g + r];
+                zqx[r] = q.x; zqy[r] = q.y; zqz[r] = q.z;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staging buffer read: it may be overwritten now
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sgv[r] = mk[r] ? fabsf(sgv[r]) : -1.f;
+        GTS(6)
+        if (t + 2 < n) stage_spectra(t + 2, t & 1);
+        piece(pt, 0);
+        piece(pt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        GTS(2)
+        float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool wv_ = inb & (s0 + 4 * g + r < B) & (__float_as_int(sgv[r]) >= 0);
+            const float dd = wv_ ? dv[r] : 0.f;
+            const float sg = sgv[r];
+            if (BLUE) {
+                float l2, pw, Ab, re;
+                if (ZF) {                                                                         // qfa_common.h, ZFac
+                    l2 = zqz[r] + l2i;
+                    pw = zqy[r] * pwi;
+                    Ab = fast_exp2(fmaf(zqx[r], ti, k.offp));                                    // QFA/model.py:125
+                    re = k.omc0 - fast_exp2(k.k1 * pw);                                           // QFA/utils.py:91
+                } else {
+                    l2 = fast_log2(1.0f + zv[r]);
+                    pw = fast_exp2(k.beta * l2);
+                    const float tauv = k.t_amp * fast_exp2(k.t_expo * (l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
+                    Ab = fast_exp2(-tauv * QFA_LOG2E);                                            // QFA/model.py:125
+                    re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);                       // QFA/utils.py:91
+                }
+                if (HASA) Ab = bt.A_blue[(size_t)min(s0 + 4 * g + r, B - 1) * Nb + (unsigned)min(px, Nb - 1)];   // custom tau callable
+                const float Av = blue ? Ab : 1.f;
+                const float zd = blue ? re * re : 0.f;
+                const float A2 = Av * Av;
+                const float D = A2 * Psi + om * zd + sg * sg;
+                const float wD = wv_ ? fast_rcp(D) : 0.f;
+                const float wDA = wD * Av;
+                const float uu = wD * (dd - Av * afy[r]);                   // (Sigma^-1 delta)_i
+                const float dS = wD - wDA * wDA * aq[r];                    // diag(Sigma^-1)_i
+                const float dG = 0.5f * (dS - uu * uu);                     // QFA/model.py:136,138
+                gPsi += A2 * dG;                                            // :139
+                gOm += dG * zd;                                             // :140
+                const float root = 1.0f - k.tau0 * pw - k.c0;               // :141
+                const float e = dG * (om * zd) * zd * 2.0f * root;
+                t_tau0 -= e * pw;                                           // :142
+                t_beta -= e * (k.tau0 * pw * (l2 * QFA_LN2));               // :143
+                t_c0 -= e;                                                  // :144
+                cnt += wv_ ? 1.f : 0.f;
+                betaR[r] = wDA * Av;
+                sA += betaR[r] * Av;
+                gamR[r] = Av * uu;
+            } else {                                                        // red tile: A = 1, zd = 0
+                const float D = Psi + sg * sg;
+                const float wD = wv_ ? fast_rcp(D) : 0.f;
+                const float uu = wD * (dd - afy[r]);
+                const float dS = wD - wD * wD * aq[r];
+                gPsi += 0.5f * (dS - uu * uu);
+                cnt += wv_ ? 1.f : 0.f;
+                betaR[r] = wD;
+                sA += wD;
+                gamR[r] = uu;
+            }
+            if (r & 1) {                                       // two elements at a time: bounds the live temporaries
+                __builtin_amdgcn_sched_barrier(0);
+                piece(pt, r == 1 ? 2 : 4);
+                if (r == 1) piece(pt, 3);
+            }
+        }
+        if (BLUE) {                                            // float32 inside a group, float64 across the walk
+            d_tau0 += (double)t_tau0;
+            d_c0 += (double)t_c0;
+            d_beta += (double)t_beta;
+        }
+    };
+    auto stage2 = [&](int t, const Part &pt) {
+        if (blueTile) stage2_t(std::true_type{}, t, pt);
+        else stage2_t(std::false_type{}, t, pt);
+    };
+
+    // ---- stage 3 of group t: W[a] += Z pieces x the lane's own beta pieces (K = spectrum), the gamma term likewise
+    auto stage3 = [&](int t, const Part &pt) {
+        const unsigned char *zp = lds + GT::L_Z + (t & 1) * GT::ZP_B + lane * 16;
+        unsigned h01, m01, l01, h23, m23, l23;
+        split2(betaR[0], betaR[1], h01, m01, l01);
+        split2(betaR[2], betaR[3], h23, m23, l23);
+        const u32x4 bhl = {h01, h23, l01, l23}, bmm = {m01, m23, m01, m23}, bhh = {h01, h23, h01, h23};
+        u32x4 zop[2][2];
+        zop[0][0] = *reinterpret_cast<const u32x4 *>(zp);
+        zop[0][1] = *reinterpret_cast<const u32x4 *>(zp + 1024);
+#pragma unroll
+        for (int a = 0; a < KP; ++a) {
+            zop[(a + 1) & 1][0] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048);          // (a + 1 == KP: the p operands)
+            zop[(a + 1) & 1][1] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048 + 1024);
+            if (a % 3 == 0) piece(pt, a / 3);
+            const u32x4 &Z1 = zop[a & 1][0], &Z2 = zop[a & 1][1];
+            W[a] = xdl(Z2, bhh, xdl(Z2, bmm, xdl(Z1, bhl, W[a])));
+        }
+        split2(gamR[0], gamR[1], h01, m01, l01);
+        split2(gamR[2], gamR[3], h23, m23, l23);
+        const u32x4 ghl = {h01, h23, l01, l23}, gmm = {m01, m23, m01, m23}, ghh = {h01, h23, h01, h23};
+        const u32x4 &P1 = zop[KP & 1][0], &P2 = zop[KP & 1][1];
+        gacc = xdl(P2, ghh, xdl(P2, gmm, xdl(P1, ghl, gacc)));                                      // sum_s p_s[b] gamma[s][px]
+    };
+
+    // ---- the walk: ONE barrier per group, and the two waves of a SIMD (w, w + 4) a stage apart in the same rotation:
+    //   waves 0..3, step t: stage 3 (t)  [Z part of t + 1]   stage 1 (t + 1)  [S1 part of t + 2]   stage 2 (t + 1)
+    //   waves 4..7, step t: stage 2 (t)  [Z part of t + 1]   stage 3 (t)      [S1 part of t + 2]   stage 1 (t + 1)
+    // so that one wave's VALU phase (stage 2) meets the other's MFMAs.  The barrier of step t says: the Z part of group t
+    // and the S1 part of group t + 1 (requested during step t - 1) have landed, and nobody reads Z(t - 1) and S1(t) any
+    // more -- their slots take Z(t + 1) and S1(t + 2), piece by piece between the MFMA groups / elements of the stages.
+    // Counted wait in front of the barrier: waves 0..3 end a step with the spectra requests of stage 2, which stay in flight;
+    // waves 4..7 issue theirs a whole step before the wait.
+    // (Measured forms of this loop, profiles/r3_ablation_pass2.txt: a barrier per half-step with waves 4..7 half a step
+    // behind: 7 100 cycles per group -- the stages of a wave ALONE take 5 700 and are no slower beside a partner in another
+    // phase, every barrier adds the skew between waves; all eight waves in the same phase, one barrier: 7 400 -- two waves of
+    // a SIMD in the same phase do slow each other down.)
+    // The stages sit in straight-line loops: under conditions inside one loop hipcc kept two copies of the 64 accumulator
+    // registers of W (result of the first MFMA of a chain in fresh registers, copied back at the end of the step).
+    if (n > 0) {
+        stage_spectra(0, 0);
+        if (n > 1) stage_spectra(1, 1);
+        issue_S1(0);
+        if (n > 1) issue_S1(1);
+        issue_Z(0);
+    }
+    dma_wait<0>();
+    step_barrier();
+    const bool lead = wv8 < 4;
+    const Part none{nullptr, 0u, 0};
+    if (active && n > 0) {
+        stage1(0, none);
+        if (lead) stage2(0, none);
+    }
+    if (!active) {
+        for (int t = 0; t < n; ++t) {
+            dma_wait<0>();
+            step_barrier();
+            if (t + 1 < n) issue_Z(t + 1);
+            if (t + 2 < n) issue_S1(t + 2);
+        }
+    } else if (lead) {
+        for (int t = 0; t < n; ++t) {
+            if (slow || QFA_TRACKED_LOADS || t + 2 >= n) dma_wait<0>();
+            else dma_wait_n(nsp);
+            GTS(0)
+            step_barrier();
+            GTS(1)
+            stage3(t, part_Z(t + 1));
+            GTS(4)
+            if (t + 1 < n) {
+                stage1(t + 1, part_S1(t + 2));
+                stage2(t + 1, none);
+                GTS(3)
+            }
+        }
+    } else {
+        for (int t = 0; t < n; ++t) {
+            dma_wait<0>();
+            GTS(0)
+            step_barrier();
+            GTS(1)
+            stage2(t, part_Z(t + 1));
+            GTS(3)
+            stage3(t, part_S1(t + 2));
+            GTS(4)
+            if (t + 1 < n) stage1(t + 1, none);
+        }
+    }
+#if QFA_GT_STAMPS
+    if (blockIdx.x == 100 && (wv8 == 0 || wv8 == 4) && lane == 0) {
+        st_[7] = n;
+        for (int i = 0; i < 8; ++i) qfa_gt_stamps[(wv8 >> 2) * 16 + i] = st_[i];
+    }
+#endif
+    dma_wait<0>();
+
+    // ---- the end of the walk: F enters, the sums leave
+    if (active) {
+        const float *fr = reinterpret_cast<const float *>(tile + GT::OFF_F) + lo * KP;
+        f32x4 acc = gacc;
+#pragma unroll
+        for (int a4 = 0; a4 < KP / 4; ++a4) {
+            const float4 f4 = *reinterpret_cast<const float4 *>(fr + 4 * a4);
+            const float fa[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa[j], W[4 * a4 + j][r], acc[r]);
+        }
+        if (inb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = 4 * g + r;
+                if (b < Nh) {
+                    float *q = accF + (size_t)px * Nh + b;
+                    if (det) *q = acc[r];
+                    else atomicAdd(q, acc[r]);
+                }
+            }
+        }
+        // per-pixel sums over the lanes lo + 16 g'
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            sA += __shfl_xor(sA, o);
+            gPsi += __shfl_xor(gPsi, o);
+            gOm += __shfl_xor(gOm, o);
+            cnt += __shfl_xor(cnt, o);
+        }
+        if (inb) {
+            // quantity g of the pixel: sumA | gPsi | gOmega (blue pixels) | cnt
+            const float v = g == 0 ? sA : (g == 1 ? gPsi : (g == 2 ? gOm : cnt));
+            const bool ok = g != 2 || px < Nb;
+            float *q = accA + (g == 0 ? px : (g == 1 ? Npix + px : (g == 2 ? 2 * Npix + px : 2 * Npix + Nb + px)));
+            if (ok) {
+                if (det) *q = v;
+                else atomicAdd(q, v);
+            }
+        }
+    }
+    double s_tau0 = d_tau0, s_c0 = d_c0, s_beta = d_beta;
+    for (int o = 32; o >= 1; o >>= 1) {
+        s_tau0 += __shfl_xor(s_tau0, o);
+        s_c0 += __shfl_xor(s_c0, o);
+        s_beta += __shfl_xor(s_beta, o);
+    }
+    if (det) {
+        if (lane == 0) {
+            double *q = slabS + ((size_t)blockIdx.x * GT::NW + wv8) * 3;
+            q[0] = s_tau0; q[1] = s_c0; q[2] = s_beta;
+        }
+    } else {
+        scal64_commit(sc64, s_tau0, s_c0, s_beta, gridDim.x * (unsigned)GT::NW, accS);
+    }
+}

@@ -2,13 +2,15 @@
 // is iterated on separately from the rest of the library.
 #include "qfa_grads_x.h"
 #include "qfa_grads_w.h"
+#include "qfa_grads_t.h"       // (GTT: the image size; the kernel itself is built in qfa_gt.hip)
 #include "qfa_predict_x.h"
 
 #include "qfa_host.h"
 
-size_t qfa_gx_image_bytes(int KP, int ntiles32) {            // the larger of the two forms' images (one region serves both)
+size_t qfa_gx_image_bytes(int KP, int ntiles32) {            // the largest of the forms' images (one region serves all)
     const size_t x = KP == 8 ? GXT<8>::TILE_B : GXT<16>::TILE_B, w = KP == 8 ? GWT<8>::TILE_B : GWT<16>::TILE_B;
-    return (size_t)ntiles32 * (x > w ? x : w);
+    const size_t t = KP == 16 ? 2 * (size_t)GTT<16>::TILE_B : 0;      // (two 16-pixel tiles per 32 pixels)
+    return (size_t)ntiles32 * std::max(t, std::max(x, w));
 }
 
 // pass 2, one-wave-per-SIMD form (qfa_grads_w.h)

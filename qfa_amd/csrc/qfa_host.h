@@ -18,6 +18,14 @@ void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
                    int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, const float *ZS, const float *ZP,
                    float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st);
 
+// the pixel-resident form of the all-XDL pass 2 (qfa_grads_t.h, built in qfa_gx.hip; N_h = 9..16): QFA_F_PASS2_PIXRES
+struct GtPlan;
+size_t qfa_gt_state_bytes(int KP, int B);
+int qfa_gt_items(int B, int Npix, int max_ranges);
+void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                   int max_ranges, unsigned char *PGT, unsigned char *PST, const float *SOL, const float *ZS, const float *ZP,
+                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st, int *ranges_out);
+
 // posterior writer for N_h <= 16 on the XDL pipe (qfa_predict_x.h, built in qfa_gx.hip)
 size_t qfa_px_image_bytes(int KP, int ntiles32);
 void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int Nh, int ntiles32, const WorkPlan &wp,
@@ -94,7 +102,7 @@ struct Layout {
     int spb1;                                          // spectra per block of pass 1's plan (128 for the 8-wave k_moments_x)
     WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
     WorkPlan wpp;                                      // posterior writer on the XDL pipe (k_predict_x, N_h <= 16)
-    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, oZS, oZP, total;   // float offsets
+    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, oZS, oZP, oPST, total;   // float offsets
     int bg_stride;                                     // beta / gamma hand-over of pass 2 at N_h = 17..32 ([2][Bpad][NpixPad])
 };
 
@@ -143,6 +151,8 @@ Layout make_layout_t(int B, int Npix) {
     L.oZP = take(4 * (size_t)L.NpixPad);                //                        per-pixel factors ZP (blue pixels)
     L.oRED = take(2 * 2 * NRED + 2 + sizeof(Scal64) / 4);   // k_reduce_nll: 2 x NRED doubles + the ticket counter; then the
                                                             // float64 scalar-gradient sums of pass 2 (Scal64)
+    L.oPST = 0;                                         // pixel-resident pass 2: the per-group state images (qfa_grads_t.h)
+    if constexpr (KP == 16) L.oPST = take(qfa_gt_state_bytes(KP, B) / 4);
     L.oBG = 0;
     L.bg_stride = round_up(Npix, 32);
     if constexpr (KP == 32) L.oBG = take(2 * (size_t)round_up(B, 64) * L.bg_stride);
@@ -271,7 +281,8 @@ struct DetLayout {
 };
 inline DetLayout det_layout(int B, int Npix, int Nb, int Nh) {
     const Layout L = make_layout(B, Npix, Nh);
-    const size_t items = (size_t)(L.wp2.items() > L.wp2x.items() ? L.wp2.items() : L.wp2x.items());
+    size_t items = (size_t)(L.wp2.items() > L.wp2x.items() ? L.wp2.items() : L.wp2x.items());
+    if (L.KP == 16) items = std::max(items, 2 * (size_t)qfa_gt_items(B, Npix, (int)det_rows(B)));   // (8 waves per item there)
     DetLayout D;
     D.NF = det_rows_floats(Npix, Nb, Nh);
     D.stride = det_row_stride(Npix, Nb, Nh);
@@ -284,10 +295,12 @@ inline size_t det_slab_bytes(int B, int Npix, int Nb, int Nh) { return det_layou
 
 // the fixed-order reduction of the slab into the packed buffer: rows in chunks of DET_CHUNK_ROWS (float64 partials,
 // rows in order), then the chunks in order
-inline void launch_reduce_slab(const float *slab, const DetLayout &D, int B, int nitemwaves, float *accum, hipStream_t st) {
+inline void launch_reduce_slab(const float *slab, const DetLayout &D, int B, int nitemwaves, float *accum, hipStream_t st,
+                               int rows = -1) {
     const double *slabS = reinterpret_cast<const double *>(reinterpret_cast<const char *>(slab) + D.oS);
     double *part = reinterpret_cast<double *>(const_cast<char *>(reinterpret_cast<const char *>(slab)) + D.oPart);
-    const int nblk = (int)det_rows(B), nch = (int)det_chunks(B);
+    // rows written by the launch: one per block of 64 spectra, or (pixel-resident pass 2) one per range of spectra
+    const int nblk = rows >= 0 ? rows : (int)det_rows(B), nch = (nblk + DET_CHUNK_ROWS - 1) / DET_CHUNK_ROWS;
     const unsigned gx = (unsigned)((D.NF + 255) / 256);
     k_reduce_slab_rows<<<dim3(gx, (unsigned)nch), 256, 0, st>>>(slab, nblk, D.NF, D.stride, part);
     k_reduce_slab_fin<<<gx, 256, 0, st>>>(part, slabS, nch, nitemwaves, D.NF, accum);
@@ -325,6 +338,16 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     const int nred = B <= 2048 ? 1 : (B >= 2048 * NRED ? NRED : (B + 2047) / 2048);     // small batches: one block, no hand-over
     k_reduce_nll<<<nred, 256, 0, st>>>(nllbuf, NBL, B, accum + accS, red, ticket);
     mark(3);
+    if (pass2_xdl && KP == 16 && (flags & QFA_F_PASS2_PIXRES)) {
+        int ranges = 0;
+        qfa_gt_launch(KP, p, b, tau, B, Npix, Nb, Nh, slab ? (int)det_rows(B) : (1 << 30),
+                      reinterpret_cast<unsigned char *>(ws + L.oPGX), reinterpret_cast<unsigned char *>(ws + L.oPST), SOL,
+                      reinterpret_cast<const float *>(zt.ZS), reinterpret_cast<const float *>(zt.ZP), accum, slab, slabS,
+                      (int)D.stride, sc64, st, &ranges);
+        if (slab) launch_reduce_slab(slab, D, B, qfa_gt_items(B, Npix, (int)det_rows(B)) * 8, accum, st, ranges);
+        mark(4);
+        return hip_status(st, flags);
+    }
     if (pass2_xdl) {
         if (!(flags & QFA_F_PASS2_WFORM))
             qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,

@@ -66,6 +66,17 @@ __device__ __forceinline__ void glds16a(const void *sbase, unsigned voff, unsign
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 #endif
 }
+// The same request without the "memory" clobber, for a piece issued in the middle of a stage: the clobber keeps hipcc from
+// moving the stage's own LDS reads across the statement, which exposes a full LDS latency at every piece.  Safe where the
+// protocol already separates the piece's destination from everything the stage reads (the destination is a ring slot that
+// nobody reads before the next counted wait + barrier, which do carry the clobber).
+__device__ __forceinline__ void glds16a_nc(const void *sbase, unsigned voff, unsigned lds_dst) {
+#if QFA_TRACKED_LOADS
+    glds16a(sbase, voff, lds_dst);
+#else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst));
+#endif
+}
 template <int N>
 __device__ __forceinline__ void dma_wait() {
 #if QFA_TRACKED_LOADS
@@ -91,6 +102,37 @@ __device__ __forceinline__ void glds4a(const void *sbase, unsigned voff, unsigne
         (__attribute__((address_space(3))) void *)(size_t)__builtin_amdgcn_readfirstlane((int)lds_dst), 4, 0, 0);
 #else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#endif
+}
+// N consecutive 1-KiB pieces (global and LDS both contiguous) behind ONE write of M0: the instruction's immediate offset
+// moves the global address and the LDS address together.  (A write of M0 behind an LDS-DMA waits until the texture path has
+// accepted that request -- ~150 cycles per piece when every piece sets M0 itself, tools/gt_stamps.sh.)  The offsets are
+// biased by -2048 so that five pieces fit the signed 13-bit field.
+template <int N>
+__device__ __forceinline__ void glds16_run(const void *sbase, unsigned voff, unsigned lds_dst) {
+    static_assert(N >= 1 && N <= 5, "pieces per run");
+#if QFA_TRACKED_LOADS
+#pragma unroll
+    for (int i = 0; i < N; ++i) glds16a(reinterpret_cast<const unsigned char *>(sbase) + 1024 * i, voff, lds_dst + 1024 * i);
+#else
+    const unsigned char *sb = reinterpret_cast<const unsigned char *>(sbase) + 2048;
+    const unsigned d = lds_dst + 2048;
+    if constexpr (N == 1)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048" ::"v"(voff), "s"(sb), "s"(d) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:-1024" ::"v"(voff), "s"(sb), "s"(d) : "memory");
+    else if constexpr (N == 3)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:-1024\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(d) : "memory");
+    else if constexpr (N == 4)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:-1024\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sb), "s"(d) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:-1024\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sb), "s"(d) : "memory");
 #endif
 }
 // s_waitcnt vmcnt(k) for a wave-uniform run-time k (0..63): all but the k youngest vector-memory requests retired

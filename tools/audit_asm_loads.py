@@ -11,7 +11,7 @@ dynamic check, tests/test_tracked_loads.py.  Exit code 1 on a violation.
 import re, sys
 paths = sys.argv[1:] or ["qfa_amd/csrc/build/qfa_gx-hip-amdgcn-amd-amdhsa-gfx950.s"]
 src = "\n".join(open(p).read() for p in paths)
-NO_SCRATCH = ("_Z9k_grads_x", "_Z11k_predict_x")
+NO_SCRATCH = ("_Z9k_grads_x", "_Z9k_grads_t", "_Z11k_predict_x")
 bad = 0
 for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", src, re.S | re.M):
     name, body = m.group(1), m.group(2).split("\n")
