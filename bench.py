@@ -18,8 +18,8 @@ no masks).
 `python bench.py --gpus N` without a launcher starts the N ranks itself (fresh child processes, before this process
 touches the GPU) and relays rank 0's line.  Rank 0 prints ONE JSON line.
 
-`roofline` describes the dominant kernel (pass 2: k_grads_x at N_h = 9..16, k_grads at N_h <= 8, the three launches
-k_s12_x + 2 k_grads_s3 at N_h = 17..32; its mean duration is measured with HIP events recorded by the library on the
+`roofline` describes the dominant kernel (pass 2: at N_h = 9..16 k_grads_t from 96 spectra per CU on and k_grads_x below,
+k_grads / k_grads_x at N_h <= 8, the three launches k_s12_x + 2 k_grads_s3 at N_h = 17..32; its mean duration is measured with HIP events recorded by the library on the
 launch stream inside the timed region).  The contractions are float32 products ISSUED as bf16 piece products on the XDL
 pipe (operands split into three bf16 pieces, six products per float32 product: DESIGN.md section 4), so `achieved` =
 the issued bf16 flops per launch / duration and `peak` = the dense bf16 MFMA peak (2.5 PFLOP/s); the algorithmic float32
@@ -401,7 +401,10 @@ def main():
         p2_name = "k_s12_x+2*k_grads_s3"      # pass 2 at N_h = 17..32: three launches, timed together by the stage events
     else:                                     # the same rule as pass2_use_xdl (qfa_host.h)
         xdl_form = False if (fl & 0x1) else (True if (fl & 0x2) else (nh > 8 or B >= 96 * torch.cuda.get_device_properties(dev).multi_processor_count))
-        p2_name = ("k_grads_w" if (fl & 0x10) else "k_grads_x") if xdl_form else "k_grads"
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        # ... and pass2_use_pixres: the pixel-resident form (k_grads_t) at N_h = 9..16 from 96 spectra per CU on
+        pixres = xdl_form and nh > 8 and not (fl & (0x1 | 0x10 | 0x4)) and (bool(fl & 0x40) or (not (fl & 0x2) and B >= 96 * ncu))
+        p2_name = ("k_grads_t" if pixres else ("k_grads_w" if (fl & 0x10) else "k_grads_x")) if xdl_form else "k_grads"
     dominant = p2_name if ms_p2 >= ms_p1 else "k_moments_x"
     dom_ms, dom_flops = (ms_p2, f2) if dominant == p2_name else (ms_p1, f1)
     # The contractions are ISSUED as bf16 piece products on the XDL pipe: per spectrum
@@ -411,7 +414,7 @@ def main():
     # `roofline` prices the issued bf16 flops of the dominant kernel against the dense bf16 MFMA peak.
     nk2 = npix * nh * nh
     s3 = 3 if fast else (6 if nh <= 16 else 4)
-    if dominant in ("k_grads_x", "k_grads_w", "k_s12_x+2*k_grads_s3"):
+    if dominant in ("k_grads_x", "k_grads_t", "k_grads_w", "k_s12_x+2*k_grads_s3"):
         xdl_flops = (6 * 1 + s3 * 2) * nk2
     elif dominant == "k_moments_x":
         xdl_flops = 6 * 4 * nk2
@@ -428,8 +431,9 @@ def main():
                 p2key = {"k_grads_w": "k_grads_x"}.get(p2_name, p2_name)
                 parts = [tj.get(kk + "_hbm_bytes_per_launch") for kk in ("k_moments", "k_solve", p2key)]
                 traffic_step = sum(parts) if all(x is not None for x in parts) else None
-                if fz is not None and all((kk + "_hbm_bytes_per_launch") in tj for kk in ("k_moments_x_zfac", "k_grads_x_zfac", "k_solve")):
-                    fz["measured_hbm_bytes_per_step"] = sum(tj[kk + "_hbm_bytes_per_launch"] for kk in ("k_moments_x_zfac", "k_grads_x_zfac", "k_solve"))
+                p2z = p2key + "_zfac"
+                if fz is not None and all((kk + "_hbm_bytes_per_launch") in tj for kk in ("k_moments_x_zfac", p2z, "k_solve")):
+                    fz["measured_hbm_bytes_per_step"] = sum(tj[kk + "_hbm_bytes_per_launch"] for kk in ("k_moments_x_zfac", p2z, "k_solve"))
                     fz["traffic_ratio"] = fz["measured_hbm_bytes_per_step"] / (fz["alg_bytes_per_spectrum"] * B)
         except Exception:
             traffic = None

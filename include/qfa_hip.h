@@ -73,15 +73,18 @@ typedef struct {
 
 /* `flags` of the *_ex_f32 entry points (0 = the defaults; A/B timing and the cross-checks in tests/). */
 #define QFA_F_PASS2_F32    0x1u  /* N_h <= 16: pass 2 in its float32-MFMA form (k_grads)                        */
-#define QFA_F_PASS2_XDL    0x2u  /* N_h <= 16: pass 2 in its all-XDL form (k_grads_x)                        */
+#define QFA_F_PASS2_XDL    0x2u  /* N_h <= 16: pass 2 in its two-role all-XDL form (k_grads_x: 64 spectra per workgroup
+                                  * walk the pixel axis)                                                         */
 #define QFA_F_S3_FAST      0x4u  /* stage 3 of pass 2 with three bf16 piece products (operands carried to ~17
                                     bits, <= 1.1e-5 per product) instead of the float32-grade six              */
 #define QFA_F_PREDICT_F32  0x8u  /* posterior writer in its float32-MFMA form (k_predict_out)                   */
 #define QFA_F_SYNC         0x20u /* debugging: synchronise `stream` before returning, so that an asynchronous fault of
                                     THIS call's kernels is returned by THIS call (positive hipError_t) instead of
                                     surfacing at the caller's next synchronisation without context               */
-#define QFA_F_PASS2_PIXRES 0x40u /* N_h = 9..16: the pixel-resident form of the all-XDL pass 2 (k_grads_t: a wave owns 16
-                                  * pixels and walks the spectra; the per-spectrum operands stream through LDS)           */
+#define QFA_F_PASS2_PIXRES 0x40u /* N_h = 9..16: pass 2 in its pixel-resident all-XDL form (k_grads_t: a wave owns 16
+                                  * pixels and walks the spectra; the per-spectrum operands stream through LDS).  Without
+                                  * any QFA_F_PASS2_* flag the library picks: this form from 96 spectra per CU on,
+                                  * k_grads_x below (qfa_host.h, pass2_form)                                          */
 #define QFA_F_PASS2_WFORM  0x10u /* N_h <= 16: the one-wave-per-SIMD form of the all-XDL pass 2 (k_grads_w: stage 3
                                     re-associated as a K = spectrum GEMM; same results, slower -- DESIGN.md)    */
 

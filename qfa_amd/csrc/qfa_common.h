@@ -271,6 +271,15 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned
 #endif
     l = cvt_pk_bf16(s0, s1);
 }
+// eight float32 values -> three u32x4 of packed bf16 pieces
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned a, b, c;
+        split2(x[2 * q], x[2 * q + 1], a, b, c);
+        h[q] = a; m[q] = b; l[q] = c;
+    }
+}
 __device__ __forceinline__ f32x4 xdl(const u32x4 &a, const u32x4 &b, f32x4 c) {          // K = 32
 #if QFA_ABL == 11          // timing only: no XDL MFMA
     asm volatile("" ::"v"(a), "v"(b));

@@ -29,45 +29,7 @@
 #pragma once
 #include "qfa_common.h"
 #include "qfa_xdl_kernels.h"
-#include "qfa_grads_x.h"          // split8, SpecA's neighbours: the image format of stage 1 is k_prep_pgx's, per 16 pixels
-
-template <int KP_>
-struct GTT {
-    static constexpr int KP = KP_, KK2 = KP * (KP + 1) / 2;
-    // K axis of stage 1: the KK2 pair products, then (in the free slots of the last 32-wide block, from slot YOFF) the KP
-    // values of F / y.  The pixel side (B operand, in registers for the whole walk) is ONE image of NKQ blocks; the spectrum
-    // side has NKQ blocks [Cinv' | 0] for f^T Cinv f and one more block [0 | y | 0] that meets the last image block again
-    // for f^T y: 36 MFMAs as with a separate y block, 60 instead of 72 registers.
-    static constexpr int NKQ = (KK2 + 31) / 32;              // 5
-    static constexpr int YOFF = (KK2 % 32 + 7) / 8 * 8;      // 8
-    static_assert(KK2 % 32 != 0 && YOFF + KP <= 32, "F / y share the last pair block");
-    static constexpr int NKS = NKQ + 1;                      // blocks of the spectrum side (6)
-    // per 16-pixel tile in global memory (k_prep_pgt)
-    static constexpr int IMG_B = NKQ * 3 * 1024;             // [ks][piece][lane (g, lo)][8 k] bf16: B[k = 32 ks + 8 g + j][px = lo]
-    static constexpr int OFF_PAR = IMG_B;                    // float Psi[16] | omega[16] | ti[16] | pwi[16] | l2i[16]
-    static constexpr int OFF_F = IMG_B + 512;                // float F[16 px][KP]
-    static constexpr int TILE_B = (OFF_F + 16 * KP * 4 + 1023) / 1024 * 1024;
-    // per group of 16 spectra in global memory (k_prep_pst)
-    static constexpr int S1_B = NKS * 3 * 1024;              // [block][piece][lane (g, lo = spectrum)][8 k]: A[s][k] of stage 1
-    static constexpr int S1P_B = S1_B;                       // (the S1 part as the ring holds it)
-    static constexpr int Z_B = KP * 2 * 1024;                // [a][operand 1, 2][lane (g, lo = b)][4 dwords]
-    static constexpr int ZP_B = Z_B + 2 * 1024;              // + the p operands (gamma term)
-    static constexpr int STATE_B = S1P_B + ZP_B;
-    static constexpr int NW = 8;                             // waves = tiles per workgroup
-    // a part moves as 1-KiB pieces, each wave a contiguous run of them (one write of M0 per run, glds16_run): wave w takes
-    // XQ + (w < XR) pieces from piece w XQ + min(w, XR)
-    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34
-    static constexpr int S1_Q = S1_PCS / NW, S1_R = S1_PCS % NW, Z_Q = Z_PCS / NW, Z_R = Z_PCS % NW;     // 2 r 2, 4 r 2
-    static_assert(S1_Q >= 1 && S1_Q + 1 <= 5 && Z_Q >= 1 && Z_Q + 1 <= 5, "runs of 1..5 pieces");
-    // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
-    // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
-    static constexpr int STG_ARR = 1024, STG_MASK = 3 * STG_ARR, STG_B = 3 * STG_ARR + 256;
-    static constexpr int L_S1 = 0;                           // [2][S1P_B]
-    static constexpr int L_Z = L_S1 + 2 * S1P_B;             // [2][ZP_B]
-    static constexpr int L_STG = L_Z + 2 * ZP_B;             // [NW][2][STG_B]
-    static constexpr int L_TOTAL = L_STG + NW * 2 * STG_B;
-};
-static_assert(GTT<16>::L_TOTAL <= 160 * 1024, "k_grads_t LDS");
+#include "qfa_gt_layout.h"        // GTT, build_state
 
 // the split of the launch: tiles, pixel blocks, ranges of spectra groups (host and device agree through this struct)
 struct GtPlan {
@@ -133,67 +95,15 @@ __global__ __launch_bounds__(256) void k_prep_pgt(const float *__restrict__ F, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_prep_pst : the solve's output (SOL, float32 per spectrum) -> the state of every group of 16 spectra as split-bf16
-// MFMA operands, in the order the walk streams them.  One block per group.
-//   S1 part: A[m = spectrum lo][k = 8 g + j of block ks] = ks < NKQ: Cinv'[pair 32 ks + 8 g + j] | ks = NKQ: y[8 g + j - YOFF]
-//   Z  part: per column tile a, operands ZA1 = {l01, l23, h01, h23}, ZA2 = {h01, h23, m01, m23} of
-//            x[r] = Z_{4 g + r}[a][b = lo] (row m = b; k = 8 g + j <-> spectrum 4 g + (j & 3), piece slot j >> 2);
-//            then the same two operands of p_{4 g + r}[b]
+// k_prep_pst : the state images from the float32 record SOL (one block per group).  The training step does not launch it:
+// k_solve builds the images itself (qfa_step_kernels.h, template argument STATE); this kernel serves tools and tests.
 // ------------------------------------------------------------------------------------------------
 template <int KP>
 __global__ __launch_bounds__(256) void k_prep_pst(const float *__restrict__ SOL, int B, int Nh, unsigned char *__restrict__ PST) {
-    using C = Cfg<KP>;
-    using GT = GTT<KP>;
-    unsigned char *st = PST + (size_t)blockIdx.x * GT::STATE_B;
-    const int s0 = 16 * blockIdx.x;
-    for (int i = threadIdx.x; i < GT::NKS * 64; i += 256) {
-        const int lane = i & 63, ks = i >> 6, lo = lane & 15, g = lane >> 4;
-        const bool v = s0 + lo < B;
-        const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float val = 0.f;
-            if (ks < GT::NKQ) {                                          // blocks 0 .. NKQ - 1: Cinv' (doubled off-diagonals)
-                const int q = 32 * ks + 8 * g + j;
-                if (v && q < GT::KK2) val = sol[C::SOL_CI + q];
-            } else {                                                     // block NKQ: y in the slots of F in the last image block
-                const int a = 8 * g + j - GT::YOFF;
-                if (v && a >= 0 && a < KP) val = sol[a];
-            }
-            x[j] = val;
-        }
-        u32x4 h, m, l;
-        split8(x, h, m, l);
-        unsigned char *dst = st + ks * 3072 + lane * 16;
-        *reinterpret_cast<u32x4 *>(dst) = h;
-        *reinterpret_cast<u32x4 *>(dst + 1024) = m;
-        *reinterpret_cast<u32x4 *>(dst + 2048) = l;
-    }
-    for (int i = threadIdx.x; i < (KP + 1) * 64; i += 256) {
-        const int lane = i & 63, a = i >> 6, lo = lane & 15, g = lane >> 4;       // a == KP: the p operands
-        float x[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = s0 + 4 * g + r;
-            const bool v = s < B && lo < Nh && lo < KP;
-            const float *sol = SOL + (size_t)(v ? s : 0) * C::NSOL;
-            x[r] = v ? (a < KP ? sol[C::SOL_Z + a * KP + (lo & (KP - 1))] : sol[C::SOL_P + (lo & (KP - 1))]) : 0.f;
-        }
-        unsigned h01, m01, l01, h23, m23, l23;
-        split2(x[0], x[1], h01, m01, l01);
-        split2(x[2], x[3], h23, m23, l23);
-        unsigned char *dst = st + GT::S1P_B + a * 2048 + lane * 16;
-        *reinterpret_cast<u32x4 *>(dst) = u32x4{l01, l23, h01, h23};
-        *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{h01, h23, m01, m23};
-    }
+    build_state<KP>(SOL + (size_t)16 * blockIdx.x * Cfg<KP>::NSOL, 16 * blockIdx.x, B, Nh, PST + (size_t)blockIdx.x * GTT<KP>::STATE_B,
+                    threadIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_grads_t
-// slab != NULL: deterministic mode -- the sums of range r go to row r of the slab (plain stores, every element of the row
-// written exactly once), the scalar sums to slabS[block][wave][3]; the slab reducer adds the rows in order.
-// ------------------------------------------------------------------------------------------------
 #ifndef QFA_GT_STAMPS
 #define QFA_GT_STAMPS 0    // diagnostic build (tools/gt_stamps.sh): s_memtime shares of the walk of two waves of one workgroup
 #endif
@@ -283,9 +193,10 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const bool fastp = active && 16 * tl + 15 < Npix;
     const bool zblue = !ZF && blueTile;                     // the tile stages zabs
     const bool fastz = !zblue || 16 * tl + 15 < Nb;
-    const bool slow = active && !(fastp && fastz);          // ragged tiles: 4-byte pieces, every wait a full one
+    const bool slow = active && !fastp;                     // the ragged last tile: 4-byte pieces, every wait a full one
+    const bool zstrad = active && fastp && !fastz;          // zabs form, the tile across the end of the blue side: zabs as 4-byte pieces
     const bool zfb = ZF && blueTile;                        // the tile stages the per-spectrum factors of the factored-z form
-    const int nsp = !active ? 0 : ((zblue || zfb) ? 4 : 3); // requests per group of a fast tile
+    const int nsp = !active ? 0 : (zstrad ? 7 : ((zblue || zfb) ? 4 : 3));     // requests per group (counted waits; not `slow`)
     // group t of the range: rows s0 .. s0 + 15
     auto stage_spectra = [&](int t, int bufi) {
         if (!active) return;
@@ -330,7 +241,15 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             const unsigned char *eb = reinterpret_cast<const unsigned char *>(ebase) - GT::STG_ARR;
             const unsigned char *zb = reinterpret_cast<const unsigned char *>(zbase) - 2 * GT::STG_ARR;
             const unsigned char *mb_ = reinterpret_cast<const unsigned char *>(mbase) - GT::STG_MASK;
-            if (zblue)
+            if (zstrad) {                   // zabs of the straddling tile: clamped pixels, 4 slots per request
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q4 = 4 * i + g;
+                    const unsigned row4 = (unsigned)min(q4 ^ ((q4 >> 2) & 1), last_row);
+                    glds4a(zbase, 4u * (row4 * (unsigned)Nb + (unsigned)min(16 * tl + lo, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+                }
+            }
+            if (zblue && !zstrad)
                 asm volatile("s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
                              "global_load_lds_dwordx4 %0, %4 offset:1024\n\tglobal_load_lds_dwordx4 %1, %5 offset:2048\n\t"
                              "global_load_lds_dword %2, %6 offset:3072"
@@ -416,37 +335,40 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         }
         GTS(5)
     };
-    // ---- stage 2 of group t
-    auto stage2_t = [&](auto blue_tag, int t, const Part &pt) {
-        constexpr bool BLUE = decltype(blue_tag)::value;       // (the tile has blue pixels: wave-uniform, one branch per stage)
-        const int s0 = 16 * (g0 + t);
-        // the lane's four elements: spectra 4 g + r at pixel lo; the mask goes into the sign of sigma
+    // ---- the lane's four elements of group t out of the staging buffer (spectra 4 g + r at pixel lo); stage 2 pins sigma and
+    // the mask behind its wait: left to itself hipcc reads sigma under a branch on the mask, one LDS round trip after the
+    // other (3 600 cycles for stage 2 of a blue group, tools/gt_stamps.sh).  (Volatile reads wait one by one: 2 200 cycles.
+    // Issued a stage ahead, in front of the MFMAs of stage 1, they made stage 1 2 400 cycles long instead of 1 100.)
+    float dv[4] = {0.f, 0.f, 0.f, 0.f}, sgv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned mk[4] = {0u, 0u, 0u, 0u};
+    auto take = [&](int t) {
         const unsigned char *sb = stg + (t & 1) * GT::STG_B;
-        float dv[4], sgv[4], zv[4];
-        unsigned mk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = (4 * g + r) ^ (g & 1);
             dv[r] = *reinterpret_cast<const float *>(sb + (q * 16 + lo) * 4);
             sgv[r] = *reinterpret_cast<const float *>(sb + GT::STG_ARR + (q * 16 + lo) * 4);
-            zv[r] = (!ZF && BLUE) ? *reinterpret_cast<const float *>(sb + 2 * GT::STG_ARR + (q * 16 + lo) * 4) : 0.f;
+            if (!ZF && blueTile) zv[r] = *reinterpret_cast<const float *>(sb + 2 * GT::STG_ARR + (q * 16 + lo) * 4);
             mk[r] = sb[GT::STG_MASK + q * 16 + lo];
-            // (every read is issued here: left to itself hipcc reads sigma under a branch on the mask, one LDS round trip
-            // after the other -- 3 600 cycles for stage 2 of a blue group, tools/gt_stamps.sh)
-            asm volatile("" : "+v"(sgv[r]), "+v"(mk[r]));
         }
-        float zqx[4], zqy[4], zqz[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { zqx[r] = 0.f; zqy[r] = 0.f; zqz[r] = 0.f; }
-        if (ZF && BLUE) {
-            const float4 *zsl = reinterpret_cast<const float4 *>(sb + 2 * GT::STG_ARR);
+    };
+    // ---- stage 2 of group t
+    auto stage2_t = [&](auto blue_tag, int t, const Part &pt) {
+        constexpr bool BLUE = decltype(blue_tag)::value;       // (the tile has blue pixels: wave-uniform, one branch per stage)
+        const int s0 = 16 * (g0 + t);
+        take(t);
+        float zqx[4] = {0.f, 0.f, 0.f, 0.f}, zqy[4] = {0.f, 0.f, 0.f, 0.f}, zqz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ZF && BLUE) {      // (the factors of the lane's four spectra)
+            const unsigned char *sb = stg + (t & 1) * GT::STG_B;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float4 q = zsl[4 * g + r];
+                const float4 q = reinterpret_cast<const float4 *>(sb + 2 * GT::STG_ARR)[4 * g + r];
                 zqx[r] = q.x; zqy[r] = q.y; zqz[r] = q.z;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staging buffer read: it may be overwritten now
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(sgv[r]), "+v"(mk[r]));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) sgv[r] = mk[r] ? fabsf(sgv[r]) : -1.f;
@@ -537,9 +459,15 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         zop[0][1] = *reinterpret_cast<const u32x4 *>(zp + 1024);
 #pragma unroll
         for (int a = 0; a < KP; ++a) {
+#ifndef QFA_GT_ABL
+#define QFA_GT_ABL 0       // timing experiments (wrong results): 1 = stage 3 without its LDS reads, 2 = stage 3 without its DMA pieces
+#endif
+            if (QFA_GT_ABL & 1) { zop[(a + 1) & 1][0] = IBh[a % GT::NKQ]; zop[(a + 1) & 1][1] = IBm[a % GT::NKQ]; }
+            else {
             zop[(a + 1) & 1][0] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048);          // (a + 1 == KP: the p operands)
             zop[(a + 1) & 1][1] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048 + 1024);
-            if (a % 3 == 0) piece(pt, a / 3);
+            }
+            if (a % 3 == 0 && !(QFA_GT_ABL & 2)) piece(pt, a / 3);
             const u32x4 &Z1 = zop[a & 1][0], &Z2 = zop[a & 1][1];
             W[a] = xdl(Z2, bhh, xdl(Z2, bmm, xdl(Z1, bhl, W[a])));
         }

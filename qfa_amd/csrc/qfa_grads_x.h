@@ -97,15 +97,6 @@ __device__ __forceinline__ f32x16 xdl32_6(const u32x4 &ah, const u32x4 &am, cons
     c = xdl32(am, bh, c);
     return xdl32(ah, bh, c);
 }
-// eight float32 values -> three u32x4 of packed bf16 pieces
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        unsigned a, b, c;
-        split2(x[2 * q], x[2 * q + 1], a, b, c);
-        h[q] = a; m[q] = b; l[q] = c;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_prep_pgx : F, Psi, omega -> the pass-2 image, one block per 32-pixel tile.

@@ -22,15 +22,19 @@ static GtPlan gt_plan(int B, int Npix, int max_ranges) {
     return g;
 }
 int qfa_gt_items(int B, int Npix, int max_ranges) { return gt_plan(B, Npix, max_ranges).items(); }
-void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int max_ranges, unsigned char *PGT, unsigned char *PST, const float *SOL, const float *ZS, const float *ZP,
-                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st, int *ranges_out) {
-    (void)KP;                                            // (N_h = 9..16 only)
+// the per-tile images (beside the other parameter images of the call) and the per-group operand images (behind the solve)
+void qfa_gt_prep_image(const qfa_params_t &p, const float *ZP, int Npix, int Nb, int Nh, unsigned char *PGT, hipStream_t st) {
+    k_prep_pgt<16><<<(Npix + 15) / 16, 256, 0, st>>>(p.F, p.Psi, p.omega, reinterpret_cast<const float4 *>(ZP), Npix, Nb, Nh, PGT);
+}
+void qfa_gt_prep_state(const float *SOL, int B, int Nh, unsigned char *PST, hipStream_t st) {
+    k_prep_pst<16><<<(B + 15) / 16, 256, 0, st>>>(SOL, B, Nh, PST);
+}
+void qfa_gt_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                   int max_ranges, const unsigned char *PGT, const unsigned char *PST, const float *ZS, float *accum,
+                   float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st, int *ranges_out) {
     const GtPlan g = gt_plan(B, Npix, max_ranges);
     if (ranges_out) *ranges_out = g.R;
-    const float4 *zs = reinterpret_cast<const float4 *>(ZS), *zp = reinterpret_cast<const float4 *>(ZP);
-    k_prep_pgt<16><<<g.T16, 256, 0, st>>>(p.F, p.Psi, p.omega, zp, Npix, Nb, Nh, PGT);
-    k_prep_pst<16><<<(B + 15) / 16, 256, 0, st>>>(SOL, B, Nh, PST);
+    const float4 *zs = reinterpret_cast<const float4 *>(ZS);
     auto go = [&](auto hasa, auto zf) {
         k_grads_t<16, decltype(hasa)::value, decltype(zf)::value><<<g.items(), 512, 0, st>>>(
             p, b, tau, B, Npix, Nb, Nh, g, PGT, PST, zs, accum, slab, slabS, slab_stride, sc64);
@@ -39,7 +43,6 @@ void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
     else if (ZS) go(std::false_type{}, std::true_type{});
     else go(std::false_type{}, std::false_type{});
 }
-
 
 #if QFA_GT_STAMPS
 extern "C" int qfa_gt_debug_stamps(unsigned long long *out) {      // diagnostic build only

@@ -1,0 +1,97 @@
+// qfa_gt_layout.h -- the pixel-resident form of pass 2 (qfa_grads_t.h): sizes of its images and LDS rings, and the builder of
+// the per-group operand images ("state"), which runs at the end of k_solve (qfa_step_kernels.h) on the solve's output
+// while it is still in LDS -- or as a kernel of its own (k_prep_pst) on the float32 record SOL.
+#pragma once
+#include "qfa_common.h"
+
+template <int KP_>
+struct GTT {
+    static constexpr int KP = KP_, KK2 = KP * (KP + 1) / 2;
+    // K axis of stage 1: the KK2 pair products, then (in the free slots of the last 32-wide block, from slot YOFF) the KP
+    // values of F / y.  The pixel side (B operand, in registers for the whole walk) is ONE image of NKQ blocks; the spectrum
+    // side has NKQ blocks [Cinv' | 0] for f^T Cinv f and one more block [0 | y | 0] that meets the last image block again
+    // for f^T y: 36 MFMAs as with a separate y block, 60 instead of 72 registers.
+    static constexpr int NKQ = (KK2 + 31) / 32;              // 5
+    static constexpr int YOFF = (KK2 % 32 + 7) / 8 * 8;      // 8
+    static_assert(KK2 % 32 != 0 && YOFF + KP <= 32, "F / y share the last pair block");
+    static constexpr int NKS = NKQ + 1;                      // blocks of the spectrum side (6)
+    // per 16-pixel tile in global memory (k_prep_pgt)
+    static constexpr int IMG_B = NKQ * 3 * 1024;             // [ks][piece][lane (g, lo)][8 k] bf16: B[k = 32 ks + 8 g + j][px = lo]
+    static constexpr int OFF_PAR = IMG_B;                    // float Psi[16] | omega[16] | ti[16] | pwi[16] | l2i[16]
+    static constexpr int OFF_F = IMG_B + 512;                // float F[16 px][KP]
+    static constexpr int TILE_B = (OFF_F + 16 * KP * 4 + 1023) / 1024 * 1024;
+    // per group of 16 spectra in global memory (k_prep_pst)
+    static constexpr int S1_B = NKS * 3 * 1024;              // [block][piece][lane (g, lo = spectrum)][8 k]: A[s][k] of stage 1
+    static constexpr int S1P_B = S1_B;                       // (the S1 part as the ring holds it)
+    static constexpr int Z_B = KP * 2 * 1024;                // [a][operand 1, 2][lane (g, lo = b)][4 dwords]
+    static constexpr int ZP_B = Z_B + 2 * 1024;              // + the p operands (gamma term)
+    static constexpr int STATE_B = S1P_B + ZP_B;
+    static constexpr int NW = 8;                             // waves = tiles per workgroup
+    // a part moves as 1-KiB pieces, each wave a contiguous run of them (one write of M0 per run, glds16_run): wave w takes
+    // XQ + (w < XR) pieces from piece w XQ + min(w, XR)
+    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34
+    static constexpr int S1_Q = S1_PCS / NW, S1_R = S1_PCS % NW, Z_Q = Z_PCS / NW, Z_R = Z_PCS % NW;     // 2 r 2, 4 r 2
+    static_assert(S1_Q >= 1 && S1_Q + 1 <= 5 && Z_Q >= 1 && Z_Q + 1 <= 5, "runs of 1..5 pieces");
+    // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
+    // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
+    static constexpr int STG_ARR = 1024, STG_MASK = 3 * STG_ARR, STG_B = 3 * STG_ARR + 256;
+    static constexpr int L_S1 = 0;                           // [2][S1P_B]
+    static constexpr int L_Z = L_S1 + 2 * S1P_B;             // [2][ZP_B]
+    static constexpr int L_STG = L_Z + 2 * ZP_B;             // [NW][2][STG_B]
+    static constexpr int L_TOTAL = L_STG + NW * 2 * STG_B;
+};
+static_assert(GTT<16>::L_TOTAL <= 160 * 1024, "k_grads_t LDS");
+
+// ------------------------------------------------------------------------------------------------
+// build_state : the solve's output of one group of 16 spectra (`rows`: 16 records of Cfg<KP>::NSOL floats, global memory or
+// LDS) -> the group's state as split-bf16 MFMA operands, in the order the walk streams them.  256 threads.
+//   S1 part: A[m = spectrum lo][k = 8 g + j of block ks] = ks < NKQ: Cinv'[pair 32 ks + 8 g + j] | ks = NKQ: y[8 g + j - YOFF]
+//   Z  part: per column tile a, operands ZA1 = {l01, l23, h01, h23}, ZA2 = {h01, h23, m01, m23} of
+//            x[r] = Z_{4 g + r}[a][b = lo] (row m = b; k = 8 g + j <-> spectrum 4 g + (j & 3), piece slot j >> 2);
+//            then the same two operands of p_{4 g + r}[b]
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__device__ __forceinline__ void build_state(const float *rows, int s0, int B, int Nh, unsigned char *__restrict__ st, int tid) {
+    using C = Cfg<KP>;
+    using GT = GTT<KP>;
+    for (int i = tid; i < GT::NKS * 64; i += 256) {
+        const int lane = i & 63, ks = i >> 6, lo = lane & 15, g = lane >> 4;
+        const bool v = s0 + lo < B;
+        const float *sol = rows + (size_t)(v ? lo : 0) * C::NSOL;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float val = 0.f;
+            if (ks < GT::NKQ) {                                          // blocks 0 .. NKQ - 1: Cinv' (doubled off-diagonals)
+                const int q = 32 * ks + 8 * g + j;
+                if (v && q < GT::KK2) val = sol[C::SOL_CI + q];
+            } else {                                                     // block NKQ: y in the slots of F in the last image block
+                const int a = 8 * g + j - GT::YOFF;
+                if (v && a >= 0 && a < KP) val = sol[a];
+            }
+            x[j] = val;
+        }
+        u32x4 h, m, l;
+        split8(x, h, m, l);
+        unsigned char *dst = st + ks * 3072 + lane * 16;
+        *reinterpret_cast<u32x4 *>(dst) = h;
+        *reinterpret_cast<u32x4 *>(dst + 1024) = m;
+        *reinterpret_cast<u32x4 *>(dst + 2048) = l;
+    }
+    for (int i = tid; i < (KP + 1) * 64; i += 256) {
+        const int lane = i & 63, a = i >> 6, lo = lane & 15, g = lane >> 4;       // a == KP: the p operands
+        float x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool v = s0 + 4 * g + r < B && lo < Nh && lo < KP;
+            const float *sol = rows + (size_t)(v ? 4 * g + r : 0) * C::NSOL;
+            x[r] = v ? (a < KP ? sol[C::SOL_Z + a * KP + (lo & (KP - 1))] : sol[C::SOL_P + (lo & (KP - 1))]) : 0.f;
+        }
+        unsigned h01, m01, l01, h23, m23, l23;
+        split2(x[0], x[1], h01, m01, l01);
+        split2(x[2], x[3], h23, m23, l23);
+        unsigned char *dst = st + GT::S1P_B + a * 2048 + lane * 16;
+        *reinterpret_cast<u32x4 *>(dst) = u32x4{l01, l23, h01, h23};
+        *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{h01, h23, m01, m23};
+    }
+}

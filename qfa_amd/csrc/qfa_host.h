@@ -22,9 +22,11 @@ void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
 struct GtPlan;
 size_t qfa_gt_state_bytes(int KP, int B);
 int qfa_gt_items(int B, int Npix, int max_ranges);
-void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int max_ranges, unsigned char *PGT, unsigned char *PST, const float *SOL, const float *ZS, const float *ZP,
-                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st, int *ranges_out);
+void qfa_gt_prep_image(const qfa_params_t &p, const float *ZP, int Npix, int Nb, int Nh, unsigned char *PGT, hipStream_t st);
+void qfa_gt_prep_state(const float *SOL, int B, int Nh, unsigned char *PST, hipStream_t st);
+void qfa_gt_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+                   int max_ranges, const unsigned char *PGT, const unsigned char *PST, const float *ZS, float *accum,
+                   float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st, int *ranges_out);
 
 // posterior writer for N_h <= 16 on the XDL pipe (qfa_predict_x.h, built in qfa_gx.hip)
 size_t qfa_px_image_bytes(int KP, int ntiles32);
@@ -199,8 +201,19 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
 // forms in tests/).
 inline bool pass2_use_xdl(int KP, int B, unsigned flags) {
     if (flags & QFA_F_PASS2_F32) return false;
-    if (flags & QFA_F_PASS2_XDL) return true;
+    if (flags & (QFA_F_PASS2_XDL | QFA_F_PASS2_PIXRES)) return true;
     return KP == 16 || B >= 96 * cu_count();
+}
+// ... and which all-XDL form at N_h = 9..16: the pixel-resident one (k_grads_t, qfa_grads_t.h) once the batch gives every
+// workgroup a walk long enough to pay for its prologue and for the per-group operand images (k_prep_pst).  Measured on
+// MI355X (tools/time_pass2.py, pass 1 + solve + pass 2 per call, ms): N_pix = 4000: 0.146 / 0.166 at 1 000 spectra, 0.42 /
+// 0.44 at 8 000, 1.43 / 1.35 at 32 000, 4.31 / 3.98 at 100 000 (k_grads_x / k_grads_t); N_pix = 640: 0.089 / 0.101, 0.161 /
+// 0.183, 0.365 / 0.356, 1.085 / 0.971.  QFA_F_PASS2_XDL / QFA_F_PASS2_PIXRES force one.
+inline bool pass2_use_pixres(int KP, int B, unsigned flags) {
+    if (KP != 16 || (flags & (QFA_F_PASS2_F32 | QFA_F_PASS2_WFORM | QFA_F_S3_FAST))) return false;
+    if (flags & QFA_F_PASS2_PIXRES) return true;
+    if (flags & QFA_F_PASS2_XDL) return false;
+    return B >= 96 * cu_count();
 }
 
 // launch errors of the calls just made; with QFA_F_SYNC also the asynchronous ones (the stream is drained first)
@@ -326,6 +339,8 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
     // the float32 images PF / PFT serve k_moments (N_h > 16) and k_grads: not needed when both passes run on the XDL pipe
     if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, zt.ZP, Npix, Nb, Nh, L, PF, PFT, st);
+    const bool pixres = pass2_xdl && pass2_use_pixres(KP, B, flags);
+    if (pixres) qfa_gt_prep_image(p, reinterpret_cast<const float *>(zt.ZP), Npix, Nb, Nh, reinterpret_cast<unsigned char *>(ws + L.oPGX), st);
     mark(1);
     launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, zt, ws, st);
     mark(2);
@@ -334,16 +349,24 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     double *red = reinterpret_cast<double *>(ws + L.oRED);
     unsigned *ticket = reinterpret_cast<unsigned *>(red + 2 * NRED);
     Scal64 *sc64 = reinterpret_cast<Scal64 *>(ticket + 2);      // (zeroed by k_solve, like the ticket)
-    k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr, ticket);
+    // (pixel-resident pass 2: the solve writes the operand images that form streams instead of the float32 record SOL)
+    bool solved = false;
+    if constexpr (KP == 16) {
+        if (pixres) {
+            k_solve<KP, false, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr, ticket,
+                                                                               reinterpret_cast<unsigned char *>(ws + L.oPST));
+            solved = true;
+        }
+    }
+    if (!solved) k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr, ticket);
     const int nred = B <= 2048 ? 1 : (B >= 2048 * NRED ? NRED : (B + 2047) / 2048);     // small batches: one block, no hand-over
     k_reduce_nll<<<nred, 256, 0, st>>>(nllbuf, NBL, B, accum + accS, red, ticket);
     mark(3);
-    if (pass2_xdl && KP == 16 && (flags & QFA_F_PASS2_PIXRES)) {
+    if (pixres) {
         int ranges = 0;
-        qfa_gt_launch(KP, p, b, tau, B, Npix, Nb, Nh, slab ? (int)det_rows(B) : (1 << 30),
-                      reinterpret_cast<unsigned char *>(ws + L.oPGX), reinterpret_cast<unsigned char *>(ws + L.oPST), SOL,
-                      reinterpret_cast<const float *>(zt.ZS), reinterpret_cast<const float *>(zt.ZP), accum, slab, slabS,
-                      (int)D.stride, sc64, st, &ranges);
+        qfa_gt_launch(p, b, tau, B, Npix, Nb, Nh, slab ? (int)det_rows(B) : (1 << 30),
+                      reinterpret_cast<unsigned char *>(ws + L.oPGX), reinterpret_cast<unsigned char *>(ws + L.oPST),
+                      reinterpret_cast<const float *>(zt.ZS), accum, slab, slabS, (int)D.stride, sc64, st, &ranges);
         if (slab) launch_reduce_slab(slab, D, B, qfa_gt_items(B, Npix, (int)det_rows(B)) * 8, accum, st, ranges);
         mark(4);
         return hip_status(st, flags);

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "qfa_common.h"
+#include "qfa_gt_layout.h"       // build_state: k_solve writes the operand images of the pixel-resident pass 2 itself
 
 // ------------------------------------------------------------------------------------------------
 template <int KP>
@@ -389,13 +390,18 @@ static __global__ void k_sum_segments(float4 *__restrict__ mom, const float4 *__
 // pivot column inside the lane group (DPP row broadcast at KP = 16, wavefront shuffles otherwise).  The pivots are the squared Cholesky diagonal, so
 // log det C = sum log(pivot) (finite where the reference's float32 det overflows, QFA/utils.py:54).
 // ------------------------------------------------------------------------------------------------
-template <int KP, bool PREDICT>
+template <int KP, bool PREDICT, bool STATE = false>
 __global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
                                                float *__restrict__ nll_out, float *__restrict__ nblue_out, int B,
                                                int Nh, float *__restrict__ hmean, float *__restrict__ hcov,
-                                               unsigned *__restrict__ ticket = nullptr) {
+                                               unsigned *__restrict__ ticket = nullptr,
+                                               unsigned char *__restrict__ PST = nullptr) {
     using C = Cfg<KP>;
     constexpr int G = 64 / KP;
+    static_assert(!STATE || (KP == 16 && !PREDICT), "state images: N_h = 9..16, training step");
+    // STATE: the block's 16 spectra are one group of the pixel-resident pass 2 (qfa_grads_t.h): their records go to LDS
+    // instead of SOL, and the block turns them into the group's split-bf16 operand images (build_state, qfa_gt_layout.h)
+    __shared__ __attribute__((aligned(16))) float s_rows[STATE ? 16 * C::NSOL : 1];
     if (ticket && blockIdx.x == 0 && threadIdx.x == 0) {
         *ticket = 0u;                                                    // arrival counter of k_reduce_nll (this step)
         Scal64 *q = reinterpret_cast<Scal64 *>(ticket + 2);              // float64 scalar-gradient sums of pass 2
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM,
         if (nblue_out) nblue_out[s] = sc[3];
     }
 
-    float *sol = SOL + (size_t)(valid ? s : 0) * C::NSOL;
+    float *sol = STATE ? s_rows + ((threadIdx.x >> 6) * G + lane / KP) * C::NSOL : SOL + (size_t)(valid ? s : 0) * C::NSOL;
     if (valid) {
         sol[c] = (float)y;
         static_for<KP>([&](auto R) {
@@ -561,6 +567,10 @@ __global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM,
             sol[C::SOL_Z + c * KP + b] = Zr[b];
         });
         sol[C::SOL_P + c] = (float)pc;
+    }
+    if constexpr (STATE) {
+        __syncthreads();
+        build_state<KP>(s_rows, 16 * (int)blockIdx.x, B, Nh, PST + (size_t)blockIdx.x * GTT<KP>::STATE_B, (int)threadIdx.x);
     }
 }
 

@@ -376,6 +376,8 @@ def test_custom_tau_on_the_xdl_pass2(dev, npix, nh, B, monkeypatch):
     m1 = make_model(dev, p, mu)
     m2 = make_model(dev, p, mu, tau=lambda z: 0.751 * ((1 + z) / 4.5) ** 2.90 - 0.132)
     bt = batch_t(b, dev)
+    m2.flags = _lib.F_PASS2_PIXRES                           # (N_h = 9..16: k_grads_t's HASA instantiation)
+    acc_t = m2.accumulate(*bt).clone()
     m1.flags = m2.flags = _lib.F_PASS2_XDL
     acc_x = m2.accumulate(*bt).clone()
     l1, g1 = m1.forward(*bt)
@@ -384,13 +386,14 @@ def test_custom_tau_on_the_xdl_pass2(dev, npix, nh, B, monkeypatch):
     acc_f = m2.accumulate(*bt).clone()
     m1.flags = m2.flags = 0
     for name, sl in PS.sections(m2).items():
-        a, r = acc_x[sl].double().cpu().numpy(), acc_f[sl].double().cpu().numpy()
-        if name in ("cnt", "n_blue", "n_spectra"):
-            assert np.array_equal(a, r), name
-        elif a.size == 1:
-            assert abs(a[0] - r[0]) <= 1e-4 * abs(r[0]) + 1e-6, (name, a, r)
-        else:
-            assert rel_l2(a, r) < 2e-5, (name, rel_l2(a, r))
+        for acc in (acc_x, acc_t):
+            a, r = acc[sl].double().cpu().numpy(), acc_f[sl].double().cpu().numpy()
+            if name in ("cnt", "n_blue", "n_spectra"):
+                assert np.array_equal(a, r), name
+            elif a.size == 1:
+                assert abs(a[0] - r[0]) <= 1e-4 * abs(r[0]) + 1e-6, (name, a, r)
+            else:
+                assert rel_l2(a, r) < 2e-5, (name, rel_l2(a, r))
     assert abs(l1.item() - l2.item()) / abs(l1.item()) < 1e-5
     for k in ("F", "Psi", "omega"):
         a, r = g2[k].cpu().numpy(), g1[k].cpu().numpy()
@@ -579,6 +582,8 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
     acc_f = m.accumulate(*bt).clone()
     m.flags = _lib.F_PASS2_XDL | _lib.F_PASS2_WFORM           # the one-wave-per-SIMD form (k_grads_w, qfa_grads_w.h)
     acc_w = m.accumulate(*bt).clone()
+    m.flags = _lib.F_PASS2_PIXRES                             # N_h = 9..16: the pixel-resident form (k_grads_t, qfa_grads_t.h;
+    acc_t = m.accumulate(*bt).clone()                         # the default from 96 spectra per CU on); else = the default
     m.flags = 0
     for name, sl in PS.sections(m).items():
         aw = acc_w[sl].double().cpu().numpy()
@@ -589,6 +594,13 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
             assert abs(aw[0] - r[0]) <= 1e-4 * abs(r[0]) + 1e-6, (name, aw, r)
         else:
             assert rel_l2(aw, r) < 5e-5, (name, rel_l2(aw, r))
+        at = acc_t[sl].double().cpu().numpy()
+        if name in ("cnt", "n_blue", "n_spectra"):
+            assert np.array_equal(at, r), name
+        elif at.size == 1:
+            assert abs(at[0] - r[0]) <= 1e-4 * abs(r[0]) + 1e-6, (name, at, r)
+        else:
+            assert rel_l2(at, r) < 2e-5, (name, rel_l2(at, r))
         if name in ("cnt", "n_blue", "n_spectra"):
             assert np.array_equal(a, r), name
         elif a.size == 1:
@@ -604,8 +616,10 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
         assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
 
 
-@pytest.mark.parametrize("npix,nh,B", [(4000, 16, 20000), (2000, 8, 10000), (640, 32, 3000), (200, 12, 70)])
-def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B):
+@pytest.mark.parametrize("npix,nh,B,flags", [(4000, 16, 20000, 0), (2000, 8, 10000, 0), (640, 32, 3000, 0), (200, 12, 70, 0),
+                                            (4000, 16, 30000, 0),                       # (default = k_grads_t from 24 576 spectra on)
+                                            (1913, 13, 2100, _lib.F_PASS2_PIXRES), (200, 12, 70, _lib.F_PASS2_PIXRES)])
+def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B, flags):
     """QFA.deterministic = True (qfa_nll_grad_det_f32: per-block slab + fixed-order reducer instead of float32 atomics):
     repeated runs on the same batch are BIT-identical, and agree with the default (atomic) mode to rounding."""
     import torch
@@ -615,6 +629,7 @@ def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B):
     p, mu = synthetic.mock_parameters(npix, nb, nh, seed=nh)
     batch = synthetic.make_batch_torch(p, mu, wav, nb, B, 1234 + nh, dev, masks=True)
     m = make_model(dev, p, mu)
+    m.flags = flags
     ref = m.accumulate(*batch).clone()
     m.deterministic = True
     runs = [m.accumulate(*batch).clone() for _ in range(4)]
@@ -693,7 +708,8 @@ def test_g13_desi_model(dev):
     (200, 16, 70, 0), (97, 9, 33, 0), (1000, 12, 130, 0), (640, 16, 48, _lib.F_PASS2_F32),
     (640, 16, 48, _lib.F_PASS2_XDL | _lib.F_PASS2_WFORM),                       # k_grads<16> / k_grads_w
     (1913, 8, 130, 0), (97, 5, 33, 0), (450, 1, 65, 0), (200, 8, 70, _lib.F_PASS2_XDL),      # k_grads<8> / k_grads_x<8>
-    (450, 32, 70, 0), (1000, 20, 130, 0), (31, 17, 5, 0)])                      # k_moments_x<32>, k_s12_x
+    (450, 32, 70, 0), (1000, 20, 130, 0), (31, 17, 5, 0),                       # k_moments_x<32>, k_s12_x
+    (200, 16, 70, _lib.F_PASS2_PIXRES), (97, 9, 33, _lib.F_PASS2_PIXRES), (1913, 12, 700, _lib.F_PASS2_PIXRES)])    # k_grads_t
 def test_factored_z_input_form_matches_zabs_form_and_oracle(dev, npix, nh, B, flags):
     """ABI v2: qfa_batch_t::zq1 / pix_ratio (1 + zabs[s][i] = zq1[s] pix_ratio[i], reference QFA/dataloader.py:102) through
     every pass-1 / pass-2 form and the predict call: against the zabs form section by section (same arithmetic up to the

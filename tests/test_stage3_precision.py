@@ -57,7 +57,8 @@ def test_f_columns_spanning_three_decades(dev, npix, nh, B):
     b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=901 + nh)
     ol, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
     errs = {}
-    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)):
+    forms = (("six", 0), ("fast", _lib.F_S3_FAST)) + ((("pixres", _lib.F_PASS2_PIXRES),) if 8 < nh <= 16 else ())
+    for name, fl in forms:
         m = _model(dev, p, mu, nb, nr, nh, fl)
         loss, g = m.forward(*_bt(b, dev))
         assert abs(loss.item() - ol) <= 2e-5 * abs(ol)          # (C spans 10^6 here; 7e-6 achieved against 2e-7 on plain data)
@@ -75,6 +76,9 @@ def test_f_columns_spanning_three_decades(dev, npix, nh, B):
     assert six["F"] < lim and six["F_worst_column"] < 2 * lim, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
     assert errs["fast"]["F"] < 3e-3, errs["fast"]                # (not the default)
+    if "pixres" in errs:                                         # the pixel-resident form of pass 2 (k_grads_t): same bar as six
+        t = errs["pixres"]
+        assert t["F"] < lim and t["F_worst_column"] < 2 * lim and t["Psi"] < 2e-5 and t["omega"] < 2e-5, t
 
 
 @pytest.mark.parametrize("nh", [16, 32])
@@ -103,7 +107,7 @@ def test_near_stationary_parameters_after_200_steps(dev, nh):
     sub = {k: data[k][:96] for k in ("delta", "error", "zabs", "mask")}
     ol, og = O.forward(trained, sub["delta"], sub["error"], sub["zabs"], sub["mask"])
     out = {}
-    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)):
+    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)) + ((("pixres", _lib.F_PASS2_PIXRES),) if nh == 16 else ()):
         mm = _model(dev, trained, mu, nb, nr, nh, fl)
         acc = mm.accumulate(*_bt(sub, dev)).clone()
         loss, g = mm._finalize(acc, True)
@@ -118,6 +122,9 @@ def test_near_stationary_parameters_after_200_steps(dev, nh):
     assert six["F_over_terms"] < 8e-6 and six["F_rel"] < 3e-5, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
     assert out["fast"]["F_rel"] < 2e-4, out["fast"]
+    if "pixres" in out:                                          # k_grads_t: the same bars as the six-term default
+        t = out["pixres"]
+        assert t["F_over_terms"] < 8e-6 and t["F_rel"] < 3e-5 and t["Psi"] < 2e-5 and t["omega"] < 2e-5, t
 
 
 def test_headline_shape_20000_spectra_normalised_gradients_vs_float64_oracle(dev, tmp_path):
@@ -134,7 +141,7 @@ def test_headline_shape_20000_spectra_normalised_gradients_vs_float64_oracle(dev
     host = {k: x.cpu().numpy() for k, x in zip(("delta", "error", "zabs", "mask"), batch)}
     ol, og, sums, counts = oracle_pool.oracle_sums(p, host, str(tmp_path / "oracle"))
     out = {}
-    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)):
+    for name, fl in (("six", _lib.F_PASS2_XDL), ("fast", _lib.F_PASS2_XDL | _lib.F_S3_FAST), ("pixres", _lib.F_PASS2_PIXRES)):
         m = _model(dev, p, mu, nb, nr, nh, fl)
         acc = m.accumulate(*batch).clone()
         loss, g = m._finalize(acc, True)
@@ -152,5 +159,9 @@ def test_headline_shape_20000_spectra_normalised_gradients_vs_float64_oracle(dev
     assert six["F"] < 6e-5 and six["F_over_terms"] < 3e-6, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
     assert six["F"] <= 1.05 * fast["F"] + 1e-6, (six["F"], fast["F"])      # six piece products are never the worse form
+    # the pixel-resident form (k_grads_t: W accumulated in float32 MFMA registers over 2 500 spectra per range, F applied once
+    # at the end) meets the same bars
+    t = out["pixres"]
+    assert t["loss"] < 2e-6 and t["F"] < 6e-5 and t["F_over_terms"] < 3e-6 and t["Psi"] < 2e-5 and t["omega"] < 2e-5, t
     del batch
     torch.cuda.empty_cache()

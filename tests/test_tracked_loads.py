@@ -20,14 +20,15 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TRACKED = os.path.join(REPO, "qfa_amd", "libqfa_tracked.so")
 
 
-def run(lib, out, npix, nh, B, form="zabs"):
+def run(lib, out, npix, nh, B, form="zabs", pixres=False):
     env = dict(os.environ)
     if lib:
         env["QFA_HIP_LIB"] = lib
     else:
         env.pop("QFA_HIP_LIB", None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "dump_hot_path.py"), out, str(npix), str(nh), str(B),
-                        "deterministic"] + (["zfac"] if form == "zfac" else []), env=env, capture_output=True, text=True,
+                        "deterministic"] + (["zfac"] if form == "zfac" else []) + (["pixres"] if pixres else []), env=env,
+                       capture_output=True, text=True,
                        timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(out)
@@ -44,5 +45,19 @@ def test_tracked_build_is_bit_identical(tmp_path, npix, nh, B, form):
     assert os.path.exists(TRACKED), "libqfa_tracked.so missing: __graft_entry__.build() / make -C qfa_amd/csrc tracked"
     a = run(None, str(tmp_path / "shipped.npz"), npix, nh, B, form)
     b = run(TRACKED, str(tmp_path / "tracked.npz"), npix, nh, B, form)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (k, float(np.nanmax(np.abs(a[k] - b[k]))))
+
+
+@pytest.mark.parametrize("npix,nh,B", [(4000, 16, 3000),      # k_grads_t: full tiles, several ranges of spectra groups
+                                       (1913, 13, 2500),      # ragged last tile (4-byte pieces, full waits), blue/red boundary inside a tile
+                                       (1000, 12, 70)])       # few groups per range: the first / last steps only
+@pytest.mark.parametrize("form", ["zabs", "zfac"])
+def test_tracked_build_is_bit_identical_pixel_resident_pass2(tmp_path, npix, nh, B, form):
+    """The same comparison for the pixel-resident form of pass 2 (k_grads_t, qfa_grads_t.h: state parts and spectra by
+    untracked LDS-DMA, one counted wait per group)."""
+    assert os.path.exists(TRACKED), "libqfa_tracked.so missing: __graft_entry__.build() / make -C qfa_amd/csrc tracked"
+    a = run(None, str(tmp_path / "shipped.npz"), npix, nh, B, form, pixres=True)
+    b = run(TRACKED, str(tmp_path / "tracked.npz"), npix, nh, B, form, pixres=True)
     for k in a.files:
         assert np.array_equal(a[k], b[k], equal_nan=True), (k, float(np.nanmax(np.abs(a[k] - b[k]))))

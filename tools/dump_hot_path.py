@@ -1,6 +1,6 @@
 """Run the hot path once on seeded synthetic input and dump every output to an .npz (GPU box only).
 
-    python tools/dump_hot_path.py OUT.npz NPIX NH B [deterministic] [zfac]
+    python tools/dump_hot_path.py OUT.npz NPIX NH B [deterministic] [zfac] [pixres]
 
 Used by tests/test_tracked_loads.py to compare two builds of the library (QFA_HIP_LIB selects the one this process
 loads) bit for bit: the packed accumulation buffer, the per-spectrum NLL and the five prediction outputs.
@@ -23,6 +23,9 @@ T = lambda x: torch.tensor(x, device=dev)
 m = QFA(nb, nr, nh, dev, model_params=p)
 m.mu = T(mu)
 m.deterministic = det
+if "pixres" in sys.argv[5:]:              # N_h = 9..16: the pixel-resident form of pass 2 (k_grads_t)
+    from qfa_amd import _lib
+    m.flags = _lib.F_PASS2_PIXRES
 nll = torch.empty(B, device=dev)
 zfac = (T(1.0 + b["zqso"].astype(np.float64)).float(), T((wav[:nb] / synthetic.LYA).astype(np.float32))) if zf else None
 acc = m.accumulate(T(b["delta"]), T(b["error"]), T(b["zabs"]), T(b["mask"]), nll=nll, zfac=zfac).clone()

@@ -9,7 +9,7 @@ for line in open(summary):
         name = line.strip()
         cur = name.split("<")[0]
         # the factored-z instantiations (last template argument `true` of k_grads_x / k_moments_x) are kept apart
-        if cur in ("k_grads_x", "k_moments_x") and name.rstrip(">").endswith("true"):
+        if cur in ("k_grads_x", "k_grads_t", "k_moments_x") and name.rstrip(">").endswith("true"):
             cur += "_zfac"
         if cur == "k_moments_x" and ", true, 4" in name:      # the prediction instantiation of pass 1
             cur = "k_moments_x_predict"
@@ -19,7 +19,10 @@ for line in open(summary):
         if m: vals[cur][m.group(1)] = float(m.group(2))
 res = {"config": cfg, "B": B, "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ*); "
        "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; check: TCC_EA0_RDREQ_128B*128"}
-for k in ("k_grads", "k_grads_x", "k_moments", "k_solve", "k_grads_x_zfac", "k_moments_x_zfac"):
+# (k_prep_pst: the operand images of the pixel-resident pass 2, written behind the solve and counted with it)
+if "k_prep_pst" in vals and "k_solve" in vals:
+    for c in vals["k_prep_pst"]: vals["k_solve"][c] = vals["k_solve"].get(c, 0) + vals["k_prep_pst"][c]
+for k in ("k_grads", "k_grads_x", "k_grads_t", "k_moments", "k_solve", "k_grads_x_zfac", "k_grads_t_zfac", "k_moments_x_zfac"):
     v = vals.get(k, {})
     if k == "k_moments" and "k_moments_x" in vals:      # pass 1 on the XDL pipe (N_h <= 16)
         v = vals["k_moments_x"]

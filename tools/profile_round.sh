@@ -12,4 +12,4 @@ python3 tools/launch_durations.py $d $d.json > gpurun_out/${tag}_${cfg}_kernel_l
 tools/pmc.sh ${tag}${cfg} $cfg "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_EA0_ATOMIC" "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B" "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_HIT TCC_MISS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" > /dev/null
 cp gpurun_out/pmc_${tag}${cfg}_summary.txt gpurun_out/${tag}_${cfg}_pmc_summary.txt
 cat gpurun_out/${tag}_${cfg}_kernel_stats.csv | cut -c1-150
-grep -A12 "^k_grads\|^k_moments\|^k_solve" gpurun_out/${tag}_${cfg}_pmc_summary.txt | grep -v "^--" | head -60
+grep -A12 "^k_grads\|^k_moments\|^k_solve\|^k_prep_pst" gpurun_out/${tag}_${cfg}_pmc_summary.txt | grep -v "^--" | head -60

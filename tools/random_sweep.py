@@ -26,12 +26,15 @@ for case in range(ncase):
     ol, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
     zfac = (T(1.0 + b["zqso"].astype(np.float64)).float(), T((wav[:nb] / synthetic.LYA).astype(np.float32)))
     forms = [("default", 0, None), ("zfac", 0, zfac), ("det", 0, None)]
+    if 8 < nh <= 16: forms += [("det+pixres", _lib.F_PASS2_PIXRES, None)]
     if nh <= 16:
         forms += [("xdl", _lib.F_PASS2_XDL, None), ("xdl+zfac", _lib.F_PASS2_XDL, zfac), ("f32", _lib.F_PASS2_F32, zfac),
                   ("wform", _lib.F_PASS2_XDL | _lib.F_PASS2_WFORM, zfac), ("fast", _lib.F_PASS2_XDL | _lib.F_S3_FAST, None)]
+        if nh > 8:
+            forms += [("pixres", _lib.F_PASS2_PIXRES, None), ("pixres+zfac", _lib.F_PASS2_PIXRES, zfac)]
     msgs = []
     for name, fl, zf in forms:
-        m = QFA(nb, nr, nh, dev, model_params=p); m.mu = T(mu); m.flags = fl; m.deterministic = name == "det"
+        m = QFA(nb, nr, nh, dev, model_params=p); m.mu = T(mu); m.flags = fl; m.deterministic = name.startswith("det")
         try:
             loss, g = m.forward(T(b["delta"]), T(b["error"]), T(b["zabs"]) if zf is None else None, T(b["mask"]), zfac=zf)
             torch.cuda.synchronize()
