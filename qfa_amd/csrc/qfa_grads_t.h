@@ -308,6 +308,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         return Part{uniform_ptr(PST + (size_t)(g0 + min(t, n - 1)) * GT::STATE_B + GT::S1P_B + z_first * 1024),
                     (unsigned)wave_uniform(lds_addr(lds + GT::L_Z + (t & 1) * GT::ZP_B + z_first * 1024)), t < n ? z_req : 0};
     };
+    // (all pieces of a part as ONE run behind one write of M0 at the first slot: no different, tools/ab_pass2.sh)
     auto piece = [&](const Part &pt, int j) {
         if (j < pt.cnt) glds16a_nc(pt.src + 1024 * j, (unsigned)lane * 16u, pt.dst + 1024 * j);
     };
