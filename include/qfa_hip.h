@@ -81,10 +81,11 @@ typedef struct {
 #define QFA_F_SYNC         0x20u /* debugging: synchronise `stream` before returning, so that an asynchronous fault of
                                     THIS call's kernels is returned by THIS call (positive hipError_t) instead of
                                     surfacing at the caller's next synchronisation without context               */
-#define QFA_F_PASS2_PIXRES 0x40u /* N_h = 9..16: pass 2 in its pixel-resident all-XDL form (k_grads_t: a wave owns 16
-                                  * pixels and walks the spectra; the per-spectrum operands stream through LDS).  Without
-                                  * any QFA_F_PASS2_* flag the library picks: this form from 96 spectra per CU on,
-                                  * k_grads_x below (qfa_host.h, pass2_form)                                          */
+#define QFA_F_PASS2_PIXRES 0x40u /* N_h <= 16: pass 2 in its pixel-resident all-XDL form (k_grads_t: a wave owns 16 pixels
+                                  * and walks the spectra; the per-spectrum operands stream through LDS).  Without any
+                                  * QFA_F_PASS2_* flag the library picks: at N_h = 9..16 this form from 96 spectra per CU
+                                  * on and k_grads_x below; at N_h <= 8 k_grads_x from 96 spectra per CU on and k_grads
+                                  * below (qfa_host.h, pass2_use_xdl / pass2_use_pixres)                               */
 #define QFA_F_PASS2_WFORM  0x10u /* N_h <= 16: the one-wave-per-SIMD form of the all-XDL pass 2 (k_grads_w: stage 3
                                     re-associated as a K = spectrum GEMM; same results, slower -- DESIGN.md)    */
 

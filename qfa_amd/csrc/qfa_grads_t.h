@@ -193,10 +193,12 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const bool fastp = active && 16 * tl + 15 < Npix;
     const bool zblue = !ZF && blueTile;                     // the tile stages zabs
     const bool fastz = !zblue || 16 * tl + 15 < Nb;
-    const bool slow = active && !fastp;                     // the ragged last tile: 4-byte pieces, every wait a full one
+    const bool slow = active && !fastp;                     // the ragged last tile: 4-byte pieces
     const bool zstrad = active && fastp && !fastz;          // zabs form, the tile across the end of the blue side: zabs as 4-byte pieces
     const bool zfb = ZF && blueTile;                        // the tile stages the per-spectrum factors of the factored-z form
-    const int nsp = !active ? 0 : (zstrad ? 7 : ((zblue || zfb) ? 4 : 3));     // requests per group (counted waits; not `slow`)
+    // requests per group (the counted waits): fast tile 3 (+ 1: zabs or the factors); zabs tile across the boundary 3 + 4;
+    // ragged tile 4 + 4 + 1 (+ 4: zabs) (+ 1: the factors)
+    const int nsp = !active ? 0 : (slow ? 9 + (zblue ? 4 : 0) + (zfb ? 1 : 0) : (zstrad ? 7 : ((zblue || zfb) ? 4 : 3)));
     // group t of the range: rows s0 .. s0 + 15
     auto stage_spectra = [&](int t, int bufi) {
         if (!active) return;
@@ -260,8 +262,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                              ::"v"(vo), "v"(o), "s"(dbase), "s"(eb), "s"(mb_), "s"(dst) : "memory");
             return;
         }
-        // ragged tile: 4-byte pieces with the pixel clamped per lane (4 slots per instruction), masks through registers
-        unsigned char *mb = stg + bufi * GT::STG_B + GT::STG_MASK;
+        // ragged tile (the last one of a pixel axis that is no multiple of 16): 4-byte pieces with the pixel clamped per lane
+        // (4 slots per request); the masks as one request of 4-byte pieces whose start is clamped to Npix - 4 (mask_lo below
+        // is where the lane then finds its byte) -- everything on the counted path
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = 4 * i + g;
@@ -271,9 +274,17 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             glds4a(dbase, 4u * o, dst + i * 256);
             glds4a(ebase, 4u * o, dst + GT::STG_ARR + i * 256);
             if (zblue) glds4a(zbase, 4u * (row * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
-            mb[q * 16 + lo] = pxx < Npix ? mbase[o] : (unsigned char)0;
+        }
+        {
+            const int q = lane >> 2;
+            const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+            const int st0 = max(0, min(16 * tl + 4 * (lane & 3), Npix - 4));
+            glds4a(mbase, row * (unsigned)Npix + (unsigned)st0, dst + GT::STG_MASK);
         }
     };
+    // where the lane's mask byte sits inside its slot's 16 staged bytes (fast tiles: byte lo)
+    const int mask_lo = (slow && !QFA_TRACKED_LOADS)
+                            ? 4 * (lo >> 2) + min(3, 16 * tl + lo - max(0, min(16 * tl + 4 * (lo >> 2), Npix - 4))) : lo;
 
     // ---- the state parts: every wave moves its contiguous run of pieces
     const int s1_first = wv8 * GT::S1_Q + min(wv8, GT::S1_R), z_first = wv8 * GT::Z_Q + min(wv8, GT::Z_R);
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             dv[r] = *reinterpret_cast<const float *>(sb + (q * 16 + lo) * 4);
             sgv[r] = *reinterpret_cast<const float *>(sb + GT::STG_ARR + (q * 16 + lo) * 4);
             if (!ZF && blueTile) zv[r] = *reinterpret_cast<const float *>(sb + 2 * GT::STG_ARR + (q * 16 + lo) * 4);
-            mk[r] = sb[GT::STG_MASK + q * 16 + lo];
+            mk[r] = sb[GT::STG_MASK + q * 16 + mask_lo];
         }
     };
     // ---- stage 2 of group t
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         }
     } else if (lead) {
         for (int t = 0; t < n; ++t) {
-            if (slow || QFA_TRACKED_LOADS || t + 2 >= n) dma_wait<0>();
+            if (QFA_TRACKED_LOADS || t + 2 >= n) dma_wait<0>();
             else dma_wait_n(nsp);
             GTS(0)
             step_barrier();

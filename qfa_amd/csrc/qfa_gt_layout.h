@@ -40,7 +40,7 @@ struct GTT {
     static constexpr int L_STG = L_Z + 2 * ZP_B;             // [NW][2][STG_B]
     static constexpr int L_TOTAL = L_STG + NW * 2 * STG_B;
 };
-static_assert(GTT<16>::L_TOTAL <= 160 * 1024, "k_grads_t LDS");
+static_assert(GTT<16>::L_TOTAL <= 160 * 1024 && GTT<8>::L_TOTAL <= 160 * 1024, "k_grads_t LDS");
 
 // ------------------------------------------------------------------------------------------------
 // build_state : the solve's output of one group of 16 spectra (`rows`: 16 records of Cfg<KP>::NSOL floats, global memory or

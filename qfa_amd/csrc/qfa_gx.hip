@@ -9,7 +9,7 @@
 
 size_t qfa_gx_image_bytes(int KP, int ntiles32) {            // the largest of the forms' images (one region serves all)
     const size_t x = KP == 8 ? GXT<8>::TILE_B : GXT<16>::TILE_B, w = KP == 8 ? GWT<8>::TILE_B : GWT<16>::TILE_B;
-    const size_t t = KP == 16 ? 2 * (size_t)GTT<16>::TILE_B : 0;      // (two 16-pixel tiles per 32 pixels)
+    const size_t t = 2 * (size_t)(KP == 16 ? GTT<16>::TILE_B : GTT<8>::TILE_B);      // (two 16-pixel tiles per 32 pixels)
     return (size_t)ntiles32 * std::max(t, std::max(x, w));
 }
 

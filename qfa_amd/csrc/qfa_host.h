@@ -22,9 +22,9 @@ void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
 struct GtPlan;
 size_t qfa_gt_state_bytes(int KP, int B);
 int qfa_gt_items(int B, int Npix, int max_ranges);
-void qfa_gt_prep_image(const qfa_params_t &p, const float *ZP, int Npix, int Nb, int Nh, unsigned char *PGT, hipStream_t st);
-void qfa_gt_prep_state(const float *SOL, int B, int Nh, unsigned char *PST, hipStream_t st);
-void qfa_gt_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
+void qfa_gt_prep_image(int KP, const qfa_params_t &p, const float *ZP, int Npix, int Nb, int Nh, unsigned char *PGT, hipStream_t st);
+void qfa_gt_prep_state(int KP, const float *SOL, int B, int Nh, unsigned char *PST, hipStream_t st);
+void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int max_ranges, const unsigned char *PGT, const unsigned char *PST, const float *ZS, float *accum,
                    float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st, int *ranges_out);
 
@@ -154,7 +154,7 @@ Layout make_layout_t(int B, int Npix) {
     L.oRED = take(2 * 2 * NRED + 2 + sizeof(Scal64) / 4);   // k_reduce_nll: 2 x NRED doubles + the ticket counter; then the
                                                             // float64 scalar-gradient sums of pass 2 (Scal64)
     L.oPST = 0;                                         // pixel-resident pass 2: the per-group state images (qfa_grads_t.h)
-    if constexpr (KP == 16) L.oPST = take(qfa_gt_state_bytes(KP, B) / 4);
+    if constexpr (KP == 8 || KP == 16) L.oPST = take(qfa_gt_state_bytes(KP, B) / 4);
     L.oBG = 0;
     L.bg_stride = round_up(Npix, 32);
     if constexpr (KP == 32) L.oBG = take(2 * (size_t)round_up(B, 64) * L.bg_stride);
@@ -210,10 +210,12 @@ inline bool pass2_use_xdl(int KP, int B, unsigned flags) {
 // 0.44 at 8 000, 1.43 / 1.35 at 32 000, 4.31 / 3.98 at 100 000 (k_grads_x / k_grads_t); N_pix = 640: 0.089 / 0.101, 0.161 /
 // 0.183, 0.365 / 0.356, 1.085 / 0.971.  QFA_F_PASS2_XDL / QFA_F_PASS2_PIXRES force one.
 inline bool pass2_use_pixres(int KP, int B, unsigned flags) {
-    if (KP != 16 || (flags & (QFA_F_PASS2_F32 | QFA_F_PASS2_WFORM | QFA_F_S3_FAST))) return false;
+    if ((KP != 16 && KP != 8) || (flags & (QFA_F_PASS2_F32 | QFA_F_PASS2_WFORM | QFA_F_S3_FAST))) return false;
     if (flags & QFA_F_PASS2_PIXRES) return true;
     if (flags & QFA_F_PASS2_XDL) return false;
-    return B >= 96 * cu_count();
+    // N_h <= 8: the walk is bound by its non-MFMA instruction streams, which do not shrink with N_h -- DESI shape (40 000 x
+    // 9243, N_h = 8): 2.12 ms against 1.77 for k_grads_x<8>; available with the flag, not the default
+    return KP == 16 && B >= 96 * cu_count();
 }
 
 // launch errors of the calls just made; with QFA_F_SYNC also the asynchronous ones (the stream is drained first)
@@ -295,7 +297,7 @@ struct DetLayout {
 inline DetLayout det_layout(int B, int Npix, int Nb, int Nh) {
     const Layout L = make_layout(B, Npix, Nh);
     size_t items = (size_t)(L.wp2.items() > L.wp2x.items() ? L.wp2.items() : L.wp2x.items());
-    if (L.KP == 16) items = std::max(items, 2 * (size_t)qfa_gt_items(B, Npix, (int)det_rows(B)));   // (8 waves per item there)
+    if (L.KP == 16 || L.KP == 8) items = std::max(items, 2 * (size_t)qfa_gt_items(B, Npix, (int)det_rows(B)));   // (8 waves per item there)
     DetLayout D;
     D.NF = det_rows_floats(Npix, Nb, Nh);
     D.stride = det_row_stride(Npix, Nb, Nh);
@@ -339,8 +341,8 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
     // the float32 images PF / PFT serve k_moments (N_h > 16) and k_grads: not needed when both passes run on the XDL pipe
     if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, zt.ZP, Npix, Nb, Nh, L, PF, PFT, st);
-    const bool pixres = pass2_xdl && pass2_use_pixres(KP, B, flags);
-    if (pixres) qfa_gt_prep_image(p, reinterpret_cast<const float *>(zt.ZP), Npix, Nb, Nh, reinterpret_cast<unsigned char *>(ws + L.oPGX), st);
+    const bool pixres = pass2_xdl && Npix >= 16 && pass2_use_pixres(KP, B, flags);      // (its ragged-tile staging wants N_pix >= 4)
+    if (pixres) qfa_gt_prep_image(KP, p, reinterpret_cast<const float *>(zt.ZP), Npix, Nb, Nh, reinterpret_cast<unsigned char *>(ws + L.oPGX), st);
     mark(1);
     launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, zt, ws, st);
     mark(2);
@@ -351,7 +353,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     Scal64 *sc64 = reinterpret_cast<Scal64 *>(ticket + 2);      // (zeroed by k_solve, like the ticket)
     // (pixel-resident pass 2: the solve writes the operand images that form streams instead of the float32 record SOL)
     bool solved = false;
-    if constexpr (KP == 16) {
+    if constexpr (KP == 8 || KP == 16) {
         if (pixres) {
             k_solve<KP, false, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr, ticket,
                                                                                reinterpret_cast<unsigned char *>(ws + L.oPST));
@@ -364,7 +366,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     mark(3);
     if (pixres) {
         int ranges = 0;
-        qfa_gt_launch(p, b, tau, B, Npix, Nb, Nh, slab ? (int)det_rows(B) : (1 << 30),
+        qfa_gt_launch(KP, p, b, tau, B, Npix, Nb, Nh, slab ? (int)det_rows(B) : (1 << 30),
                       reinterpret_cast<unsigned char *>(ws + L.oPGX), reinterpret_cast<unsigned char *>(ws + L.oPST),
                       reinterpret_cast<const float *>(zt.ZS), accum, slab, slabS, (int)D.stride, sc64, st, &ranges);
         if (slab) launch_reduce_slab(slab, D, B, qfa_gt_items(B, Npix, (int)det_rows(B)) * 8, accum, st, ranges);

@@ -398,10 +398,11 @@ __global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM,
                                                unsigned char *__restrict__ PST = nullptr) {
     using C = Cfg<KP>;
     constexpr int G = 64 / KP;
-    static_assert(!STATE || (KP == 16 && !PREDICT), "state images: N_h = 9..16, training step");
-    // STATE: the block's 16 spectra are one group of the pixel-resident pass 2 (qfa_grads_t.h): their records go to LDS
-    // instead of SOL, and the block turns them into the group's split-bf16 operand images (build_state, qfa_gt_layout.h)
-    __shared__ __attribute__((aligned(16))) float s_rows[STATE ? 16 * C::NSOL : 1];
+    static_assert(!STATE || ((KP == 16 || KP == 8) && !PREDICT), "state images: N_h <= 16, training step");
+    // STATE: the block's 4 G spectra are one (KP = 16) or two (KP = 8) groups of the pixel-resident pass 2 (qfa_grads_t.h):
+    // their records go to LDS instead of SOL, and the block turns them into the groups' split-bf16 operand images
+    // (build_state, qfa_gt_layout.h)
+    __shared__ __attribute__((aligned(16))) float s_rows[STATE ? 4 * G * C::NSOL : 1];
     if (ticket && blockIdx.x == 0 && threadIdx.x == 0) {
         *ticket = 0u;                                                    // arrival counter of k_reduce_nll (this step)
         Scal64 *q = reinterpret_cast<Scal64 *>(ticket + 2);              // float64 scalar-gradient sums of pass 2
@@ -570,7 +571,12 @@ __global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM,
     }
     if constexpr (STATE) {
         __syncthreads();
-        build_state<KP>(s_rows, 16 * (int)blockIdx.x, B, Nh, PST + (size_t)blockIdx.x * GTT<KP>::STATE_B, (int)threadIdx.x);
+#pragma unroll
+        for (int q = 0; q < (4 * G) / 16; ++q) {
+            const int grp = (int)blockIdx.x * ((4 * G) / 16) + q;
+            if (16 * grp < B)
+                build_state<KP>(s_rows + q * 16 * C::NSOL, 16 * grp, B, Nh, PST + (size_t)grp * GTT<KP>::STATE_B, (int)threadIdx.x);
+        }
     }
 }
 

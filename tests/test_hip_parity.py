@@ -582,8 +582,8 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
     acc_f = m.accumulate(*bt).clone()
     m.flags = _lib.F_PASS2_XDL | _lib.F_PASS2_WFORM           # the one-wave-per-SIMD form (k_grads_w, qfa_grads_w.h)
     acc_w = m.accumulate(*bt).clone()
-    m.flags = _lib.F_PASS2_PIXRES                             # N_h = 9..16: the pixel-resident form (k_grads_t, qfa_grads_t.h;
-    acc_t = m.accumulate(*bt).clone()                         # the default from 96 spectra per CU on); else = the default
+    m.flags = _lib.F_PASS2_PIXRES                             # the pixel-resident form (k_grads_t, qfa_grads_t.h; at N_h = 9..16
+    acc_t = m.accumulate(*bt).clone()                         # the default from 96 spectra per CU on)
     m.flags = 0
     for name, sl in PS.sections(m).items():
         aw = acc_w[sl].double().cpu().numpy()
@@ -618,7 +618,8 @@ def test_pass2_xdl_form_matches_f32_form_and_oracle(dev, npix, nh, B, monkeypatc
 
 @pytest.mark.parametrize("npix,nh,B,flags", [(4000, 16, 20000, 0), (2000, 8, 10000, 0), (640, 32, 3000, 0), (200, 12, 70, 0),
                                             (4000, 16, 30000, 0),                       # (default = k_grads_t from 24 576 spectra on)
-                                            (1913, 13, 2100, _lib.F_PASS2_PIXRES), (200, 12, 70, _lib.F_PASS2_PIXRES)])
+                                            (1913, 13, 2100, _lib.F_PASS2_PIXRES), (200, 12, 70, _lib.F_PASS2_PIXRES),
+                                            (1913, 8, 2100, _lib.F_PASS2_PIXRES)])
 def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B, flags):
     """QFA.deterministic = True (qfa_nll_grad_det_f32: per-block slab + fixed-order reducer instead of float32 atomics):
     repeated runs on the same batch are BIT-identical, and agree with the default (atomic) mode to rounding."""
@@ -709,7 +710,8 @@ def test_g13_desi_model(dev):
     (640, 16, 48, _lib.F_PASS2_XDL | _lib.F_PASS2_WFORM),                       # k_grads<16> / k_grads_w
     (1913, 8, 130, 0), (97, 5, 33, 0), (450, 1, 65, 0), (200, 8, 70, _lib.F_PASS2_XDL),      # k_grads<8> / k_grads_x<8>
     (450, 32, 70, 0), (1000, 20, 130, 0), (31, 17, 5, 0),                       # k_moments_x<32>, k_s12_x
-    (200, 16, 70, _lib.F_PASS2_PIXRES), (97, 9, 33, _lib.F_PASS2_PIXRES), (1913, 12, 700, _lib.F_PASS2_PIXRES)])    # k_grads_t
+    (200, 16, 70, _lib.F_PASS2_PIXRES), (97, 9, 33, _lib.F_PASS2_PIXRES), (1913, 12, 700, _lib.F_PASS2_PIXRES),     # k_grads_t<16>
+    (1000, 8, 130, _lib.F_PASS2_PIXRES), (97, 5, 33, _lib.F_PASS2_PIXRES)])                                         # k_grads_t<8>
 def test_factored_z_input_form_matches_zabs_form_and_oracle(dev, npix, nh, B, flags):
     """ABI v2: qfa_batch_t::zq1 / pix_ratio (1 + zabs[s][i] = zq1[s] pix_ratio[i], reference QFA/dataloader.py:102) through
     every pass-1 / pass-2 form and the predict call: against the zabs form section by section (same arithmetic up to the

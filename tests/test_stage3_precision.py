@@ -57,7 +57,7 @@ def test_f_columns_spanning_three_decades(dev, npix, nh, B):
     b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=901 + nh)
     ol, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
     errs = {}
-    forms = (("six", 0), ("fast", _lib.F_S3_FAST)) + ((("pixres", _lib.F_PASS2_PIXRES),) if 8 < nh <= 16 else ())
+    forms = (("six", 0), ("fast", _lib.F_S3_FAST)) + ((("pixres", _lib.F_PASS2_PIXRES),) if nh <= 16 else ())
     for name, fl in forms:
         m = _model(dev, p, mu, nb, nr, nh, fl)
         loss, g = m.forward(*_bt(b, dev))

@@ -51,7 +51,8 @@ def test_tracked_build_is_bit_identical(tmp_path, npix, nh, B, form):
 
 @pytest.mark.parametrize("npix,nh,B", [(4000, 16, 3000),      # k_grads_t: full tiles, several ranges of spectra groups
                                        (1913, 13, 2500),      # ragged last tile (4-byte pieces, full waits), blue/red boundary inside a tile
-                                       (1000, 12, 70)])       # few groups per range: the first / last steps only
+                                       (1000, 12, 70),        # few groups per range: the first / last steps only
+                                       (1913, 8, 2500)])      # k_grads_t<8>
 @pytest.mark.parametrize("form", ["zabs", "zfac"])
 def test_tracked_build_is_bit_identical_pixel_resident_pass2(tmp_path, npix, nh, B, form):
     """The same comparison for the pixel-resident form of pass 2 (k_grads_t, qfa_grads_t.h: state parts and spectra by

@@ -14,7 +14,7 @@ def rel(a, b):
     if not np.array_equal(np.isnan(a), np.isnan(b)): return np.inf
     n = np.linalg.norm(b[ok]); return np.linalg.norm(a[ok] - b[ok]) / n if n > 0 else np.linalg.norm(a[ok])
 cases = [(640, 16, 48), (640, 16, 500), (1000, 12, 700), (97, 9, 33), (2000, 16, 1500), (1913, 13, 130), (333, 16, 17),
-         (4000, 16, 3000), (64, 10, 1), (1100, 11, 257)]
+         (4000, 16, 3000), (64, 10, 1), (1100, 11, 257), (1913, 8, 700), (97, 5, 33), (450, 1, 65), (2000, 8, 3000), (333, 7, 17)]
 if len(sys.argv) > 1: cases = cases[:int(sys.argv[1])]
 bad = 0
 for npix, nh, B in cases:

@@ -26,11 +26,11 @@ for case in range(ncase):
     ol, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
     zfac = (T(1.0 + b["zqso"].astype(np.float64)).float(), T((wav[:nb] / synthetic.LYA).astype(np.float32)))
     forms = [("default", 0, None), ("zfac", 0, zfac), ("det", 0, None)]
-    if 8 < nh <= 16: forms += [("det+pixres", _lib.F_PASS2_PIXRES, None)]
+    if nh <= 16: forms += [("det+pixres", _lib.F_PASS2_PIXRES, None)]
     if nh <= 16:
         forms += [("xdl", _lib.F_PASS2_XDL, None), ("xdl+zfac", _lib.F_PASS2_XDL, zfac), ("f32", _lib.F_PASS2_F32, zfac),
                   ("wform", _lib.F_PASS2_XDL | _lib.F_PASS2_WFORM, zfac), ("fast", _lib.F_PASS2_XDL | _lib.F_S3_FAST, None)]
-        if nh > 8:
+        if True:
             forms += [("pixres", _lib.F_PASS2_PIXRES, None), ("pixres+zfac", _lib.F_PASS2_PIXRES, zfac)]
     msgs = []
     for name, fl, zf in forms:
