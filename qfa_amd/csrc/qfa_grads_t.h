@@ -286,21 +286,38 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const int mask_lo = (slow && !QFA_TRACKED_LOADS)
                             ? 4 * (lo >> 2) + min(3, 16 * tl + lo - max(0, min(16 * tl + 4 * (lo >> 2), Npix - 4))) : lo;
 
-    // ---- the state parts: every wave moves its contiguous run of pieces
-    const int s1_first = wv8 * GT::S1_Q + min(wv8, GT::S1_R), z_first = wv8 * GT::Z_Q + min(wv8, GT::Z_R);
-    const bool s1_long = wv8 < GT::S1_R, z_long = wv8 < GT::Z_R;          // wave-uniform: one piece more
-    const int s1_req = GT::S1_Q + (s1_long ? 1 : 0), z_req = GT::Z_Q + (z_long ? 1 : 0);
+    // ---- the state parts: a contiguous run of 1-KiB pieces per wave.  A request costs the issuing wave ~80 - 100 cycles, and
+    // the waves with a blue tile are the critical path of a step (stage 2 of a blue group is 1 200 cycles against 800): the
+    // pieces go to the waves with a red tile or none ("duty" waves) when there are at least five of them, else to all eight
+#ifndef QFA_GT_DUTY
+#define QFA_GT_DUTY 1
+#endif
+    int nduty = 0, drank = 0;
+    bool duty = true;
+    {
+        int nd = 0, rk = 0;
+#pragma unroll
+        for (int w = 0; w < GT::NW; ++w) {
+            const int tw = pb + gp.PB * w;
+            const bool d = !(tw < gp.T16 && 16 * tw < Nb);
+            if (w < wv8 && d) ++rk;
+            if (d) ++nd;
+        }
+        if (QFA_GT_DUTY && nd >= 5) { nduty = nd; drank = rk; duty = !blueTile; }
+        else { nduty = GT::NW; drank = wv8; duty = true; }
+    }
+    const int s1_q = GT::S1_PCS / nduty, s1_r = GT::S1_PCS % nduty, z_q = GT::Z_PCS / nduty, z_r = GT::Z_PCS % nduty;
+    const int s1_first = drank * s1_q + min(drank, s1_r), z_first = drank * z_q + min(drank, z_r);
+    const int s1_req = duty ? s1_q + (drank < s1_r ? 1 : 0) : 0, z_req = duty ? z_q + (drank < z_r ? 1 : 0) : 0;     // <= 4, <= 7
     auto issue_S1 = [&](int t) {
         const unsigned char *src = uniform_ptr(PST + (size_t)(g0 + t) * GT::STATE_B + s1_first * 1024);
         const unsigned dst = wave_uniform(lds_addr(lds + GT::L_S1 + (t & 1) * GT::S1P_B + s1_first * 1024));
-        if (s1_long) glds16_run<GT::S1_Q + 1>(src, (unsigned)lane * 16u, dst);
-        else glds16_run<GT::S1_Q>(src, (unsigned)lane * 16u, dst);
+        for (int j = 0; j < s1_req; ++j) glds16a(src + 1024 * j, (unsigned)lane * 16u, dst + 1024 * j);
     };
     auto issue_Z = [&](int t) {
         const unsigned char *src = uniform_ptr(PST + (size_t)(g0 + t) * GT::STATE_B + GT::S1P_B + z_first * 1024);
         const unsigned dst = wave_uniform(lds_addr(lds + GT::L_Z + (t & 1) * GT::ZP_B + z_first * 1024));
-        if (z_long) glds16_run<GT::Z_Q + 1>(src, (unsigned)lane * 16u, dst);
-        else glds16_run<GT::Z_Q>(src, (unsigned)lane * 16u, dst);
+        for (int j = 0; j < z_req; ++j) glds16a(src + 1024 * j, (unsigned)lane * 16u, dst + 1024 * j);
     };
 
     // A part's pieces are issued one by one BETWEEN the MFMA groups of the stage that runs in the same half-step: eight waves
@@ -445,7 +462,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             if (r & 1) {                                       // two elements at a time: bounds the live temporaries
                 __builtin_amdgcn_sched_barrier(0);
                 piece(pt, r == 1 ? 2 : 4);
-                if (r == 1) piece(pt, 3);
+                piece(pt, r == 1 ? 3 : 5);
+                if (r == 3) piece(pt, 6);
             }
         }
         if (BLUE) {                                            // float32 inside a group, float64 across the walk
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             zop[(a + 1) & 1][0] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048);          // (a + 1 == KP: the p operands)
             zop[(a + 1) & 1][1] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048 + 1024);
             }
-            if (a % 3 == 0 && !(QFA_GT_ABL & 2)) piece(pt, a / 3);
+            if (a % 2 == 0 && !(QFA_GT_ABL & 2)) piece(pt, a / 2);
             const u32x4 &Z1 = zop[a & 1][0], &Z2 = zop[a & 1][1];
             W[a] = xdl(Z2, bhh, xdl(Z2, bmm, xdl(Z1, bhl, W[a])));
         }

@@ -27,11 +27,9 @@ struct GTT {
     static constexpr int ZP_B = Z_B + 2 * 1024;              // + the p operands (gamma term)
     static constexpr int STATE_B = S1P_B + ZP_B;
     static constexpr int NW = 8;                             // waves = tiles per workgroup
-    // a part moves as 1-KiB pieces, each wave a contiguous run of them (one write of M0 per run, glds16_run): wave w takes
-    // XQ + (w < XR) pieces from piece w XQ + min(w, XR)
-    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34
-    static constexpr int S1_Q = S1_PCS / NW, S1_R = S1_PCS % NW, Z_Q = Z_PCS / NW, Z_R = Z_PCS % NW;     // 2 r 2, 4 r 2
-    static_assert(S1_Q >= 1 && S1_Q + 1 <= 5 && Z_Q >= 1 && Z_Q + 1 <= 5, "runs of 1..5 pieces");
+    // a part moves as 1-KiB pieces, contiguous runs of them per wave (k_grads_t decides which waves)
+    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34 (KP = 8: 9, 18)
+    static_assert((Z_PCS + 4) / 5 <= 7 && (S1_PCS + 4) / 5 <= 6, "pieces per wave and stage: 7 slots in stage 2, 8 in stage 3, 6 in stage 1");
     // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
     // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
     static constexpr int STG_ARR = 1024, STG_MASK = 3 * STG_ARR, STG_B = 3 * STG_ARR + 256;
