@@ -276,24 +276,27 @@ def test_blue_red_boundary_layouts(dev, npix, nb, nh, B):
     p, mu = synthetic.mock_parameters(npix, nb, nh, seed=npix + nb)
     b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=3 * npix + nb, masks=True)
     m = make_model(dev, p, mu, nb=nb)
-    nll = torch.empty(B, dtype=torch.float32, device=dev)
-    acc = m.accumulate(*batch_t(b, dev), nll=nll)
-    loss, gr = m._finalize(acc, True)
     oloss, ogr = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
     per = np.array([O.nll_and_grads_single(p, b["delta"][s], b["error"][s], b["zabs"][s], b["mask"][s])[0] for s in range(B)])
-    # (a fully masked spectrum: exactly 0.)  An NLL is a sum of terms of order one per unmasked pixel that can cancel
-    # to almost nothing on these 30-pixel spectra (one here is -0.096): the tolerance is relative to the larger of
-    # |NLL| and the pixel count
-    scale = np.maximum(np.abs(per), 0.5 * b["mask"].sum(axis=1))
-    assert np.all(np.abs(nll.cpu().numpy() - per) <= TOL_NLL * scale)
-    assert abs(loss.item() - oloss) / abs(oloss) < TOL_NLL
-    for k in KEYS:
-        ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
-        assert ours.shape == ref.shape, k
-        assert np.array_equal(np.isnan(ours), np.isnan(ref)), k
-        ok = ~np.isnan(ref)
-        if ok.any():
-            assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], k
+    # the default form of pass 2 and (N_h <= 16) the pixel-resident one (k_grads_t: blue / red decided per 16-pixel tile)
+    for flags in (0,) + ((_lib.F_PASS2_PIXRES,) if nh <= 16 else ()):
+        m.flags = flags
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        acc = m.accumulate(*batch_t(b, dev), nll=nll)
+        loss, gr = m._finalize(acc, True)
+        # (a fully masked spectrum: exactly 0.)  An NLL is a sum of terms of order one per unmasked pixel that can cancel
+        # to almost nothing on these 30-pixel spectra (one here is -0.096): the tolerance is relative to the larger of
+        # |NLL| and the pixel count
+        scale = np.maximum(np.abs(per), 0.5 * b["mask"].sum(axis=1))
+        assert np.all(np.abs(nll.cpu().numpy() - per) <= TOL_NLL * scale)
+        assert abs(loss.item() - oloss) / abs(oloss) < TOL_NLL
+        for k in KEYS:
+            ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
+            assert ours.shape == ref.shape, (k, flags)
+            assert np.array_equal(np.isnan(ours), np.isnan(ref)), (k, flags)
+            ok = ~np.isnan(ref)
+            if ok.any():
+                assert rel_l2(ours[ok], ref[ok]) < TOL_G[k], (k, flags)
 
 
 @pytest.mark.parametrize("B,npix,nh,seed", [(5, 200, 4, 11), (20, 900, 8, 12), (18, 640, 16, 13), (7, 450, 32, 14)])
