@@ -400,10 +400,11 @@ def main():
     if nh > 16:
         p2_name = "k_s12_x+2*k_grads_s3"      # pass 2 at N_h = 17..32: three launches, timed together by the stage events
     else:                                     # the same rule as pass2_use_xdl (qfa_host.h)
-        xdl_form = False if (fl & 0x1) else (True if (fl & (0x2 | 0x40)) else (nh > 8 or B >= 96 * torch.cuda.get_device_properties(dev).multi_processor_count))
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        # ... and pass2_use_pixres: the pixel-resident form (k_grads_t) at N_h = 9..16 from 96 spectra per CU on
-        pixres = xdl_form and not (fl & (0x1 | 0x10 | 0x4)) and (bool(fl & 0x40) or (nh > 8 and not (fl & 0x2) and B >= 96 * ncu))
+        xdl_form = not (fl & 0x1)
+        # ... and pass2_use_pixres: the pixel-resident form (k_grads_t) from 96 spectra per CU on (N_h <= 8, 1024 <= N_pix <= 4096: 36)
+        auto_t = B >= 96 * ncu or (nh <= 8 and B >= 36 * ncu and 1024 <= npix <= 4096)
+        pixres = xdl_form and npix >= 16 and not (fl & (0x1 | 0x10 | 0x4)) and (bool(fl & 0x40) or (not (fl & 0x2) and auto_t))
         p2_name = ("k_grads_t" if pixres else ("k_grads_w" if (fl & 0x10) else "k_grads_x")) if xdl_form else "k_grads"
     dominant = p2_name if ms_p2 >= ms_p1 else "k_moments_x"
     dom_ms, dom_flops = (ms_p2, f2) if dominant == p2_name else (ms_p1, f1)

@@ -72,7 +72,7 @@ typedef struct {
 } qfa_batch_t;
 
 /* `flags` of the *_ex_f32 entry points (0 = the defaults; A/B timing and the cross-checks in tests/). */
-#define QFA_F_PASS2_F32    0x1u  /* N_h <= 16: pass 2 in its float32-MFMA form (k_grads)                        */
+#define QFA_F_PASS2_F32    0x1u  /* N_h <= 16: pass 2 in its float32-MFMA form (k_grads; never the default there)    */
 #define QFA_F_PASS2_XDL    0x2u  /* N_h <= 16: pass 2 in its two-role all-XDL form (k_grads_x: 64 spectra per workgroup
                                   * walk the pixel axis)                                                         */
 #define QFA_F_S3_FAST      0x4u  /* stage 3 of pass 2 with three bf16 piece products (operands carried to ~17
@@ -83,9 +83,9 @@ typedef struct {
                                     surfacing at the caller's next synchronisation without context               */
 #define QFA_F_PASS2_PIXRES 0x40u /* N_h <= 16: pass 2 in its pixel-resident all-XDL form (k_grads_t: a wave owns 16 pixels
                                   * and walks the spectra; the per-spectrum operands stream through LDS).  Without any
-                                  * QFA_F_PASS2_* flag the library picks: at N_h = 9..16 this form from 96 spectra per CU
-                                  * on and k_grads_x below; at N_h <= 8 k_grads_x from 96 spectra per CU on and k_grads
-                                  * below (qfa_host.h, pass2_use_xdl / pass2_use_pixres)                               */
+                                  * QFA_F_PASS2_* flag the library picks between k_grads_x (small batches) and this form
+                                  * (from 96 spectra per CU on; N_h <= 8 and 1024 <= N_pix <= 4096: from 36 per CU on) --
+                                  * qfa_host.h, pass2_use_pixres                                                      */
 #define QFA_F_PASS2_WFORM  0x10u /* N_h <= 16: the one-wave-per-SIMD form of the all-XDL pass 2 (k_grads_w: stage 3
                                     re-associated as a K = spectrum GEMM; same results, slower -- DESIGN.md)    */
 

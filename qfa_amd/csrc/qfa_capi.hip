@@ -23,6 +23,11 @@ const double kLymanLam[30] = {1215.6701, 1025.7222, 972.5367, 949.7430, 937.8034
 
 extern "C" {
 
+#if QFA_P1_STAMPS
+extern "C" int qfa_p1_debug_stamps(unsigned long long *out) {   // diagnostic build only (tools/p1_stamps.sh)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qfa_p1_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 #if QFA_ABL == 7
 int qfa_debug_stamps(unsigned long long *out) {      // diagnostic build only
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qfa_dbg_stamps), 64 * sizeof(unsigned long long));

@@ -18,9 +18,9 @@
 // stage 2 of four elements per lane and two bf16 splits.
 //
 // Workgroup = 512 threads = 8 waves = 8 tiles (strided over the pixel axis: tile pb + PB w, so that every workgroup
-// gets its share of blue tiles) x one RANGE of spectra groups; grid = PB pixel blocks x R ranges, block = pb R + r.  With
-// R a multiple of 8 the workgroups of one range sit on one XCD (block % 8) and walk the same state in step: it is read from
-// HBM once and from that XCD's L2 by the others (measured: 3.9 GB fetched per launch at c3 against 3.6 GB of spectra).
+// gets its share of blue tiles) x one RANGE of spectra groups; PB pixel blocks x R ranges, mapped to the grid so that the
+// workgroups of one range sit on one XCD (GtPlan) and walk the same state in step: it is read from HBM once and from that
+// XCD's L2 by the others (measured: 3.9 GB fetched per launch at c3 against 3.6 GB of spectra).
 // The schedule of a step (one barrier per group, the two waves of a SIMD a stage apart) is described at the walk below.
 // The spectra (delta, sigma, zabs rows -- or the per-spectrum factors of the factored-z form: 64 bytes per row and tile;
 // masks 16) are staged per wave, two groups ahead, as in k_grads_x.  All DMA is asm (untracked) with counted waits;
@@ -34,7 +34,11 @@
 // the split of the launch: tiles, pixel blocks, ranges of spectra groups (host and device agree through this struct)
 struct GtPlan {
     int T16, PB, R, gpr;          // 16-pixel tiles; pixel blocks of 8 tiles; ranges; groups of 16 spectra per range
-    __host__ __device__ int items() const { return PB * R; }
+    // Work item i = r PB + pb (range-major).  Workgroup b runs item (b % 8) ceil(PB R / 8) + b / 8: workgroups go to the XCDs
+    // round-robin (b % 8), so every XCD gets a contiguous run of items -- the pixel blocks of ONE or two ranges, which walk
+    // the same state in step and share it in that XCD's L2, whatever R is (the grid is padded to a multiple of 8)
+    __host__ __device__ int per_xcd() const { return (PB * R + 7) / 8; }
+    __host__ __device__ int items() const { return 8 * per_xcd(); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -134,15 +138,17 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const int lane = tid & 63;
     const int wv8 = wave_uniform(tid >> 6);
     const int lo = lane & 15, g = lane >> 4;
-    const int rr = (int)blockIdx.x % gp.R, pb = (int)blockIdx.x / gp.R;
+    const int item = ((int)blockIdx.x & 7) * gp.per_xcd() + ((int)blockIdx.x >> 3);
+    const bool idle = item >= gp.PB * gp.R;                 // (padding of the grid)
+    const int rr = idle ? 0 : item / gp.PB, pb = idle ? 0 : item % gp.PB;
     const int G = (B + 15) >> 4;
     const int g0 = rr * gp.gpr;                             // first group of the range
-    const int n = max(0, min(gp.gpr, G - g0));              // groups in the range (the same for every wave: the barriers)
+    const int n = idle ? 0 : max(0, min(gp.gpr, G - g0));   // groups in the range (the same for every wave: the barriers)
     const int tl = pb + gp.PB * wv8;                        // this wave's tile
 #ifndef QFA_GT_ONLY
 #define QFA_GT_ONLY 0      // timing experiments (wrong results): 1 = waves 0..3 only, 2 = waves 4..7 only
 #endif
-    const bool active = tl < gp.T16 && (QFA_GT_ONLY == 0 || (QFA_GT_ONLY == 1) == (wv8 < 4));      // wave-uniform
+    const bool active = !idle && tl < gp.T16 && (QFA_GT_ONLY == 0 || (QFA_GT_ONLY == 1) == (wv8 < 4));      // wave-uniform
     const int px = 16 * tl + lo;
     const bool inb = active && px < Npix, blue = active && px < Nb;
     const bool blueTile = active && 16 * tl < Nb;           // wave-uniform: the tile has blue pixels

@@ -191,31 +191,32 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
     return 0;
 }
 
-// Which form of pass 2 runs at N_h <= 16 (KP = 8 or 16): the all-XDL two-role form (k_grads_x) or the float32-MFMA form
-// (k_grads, the only one for N_h = 17..32).  Default, from measurements on MI355X (profiles/r3_ablation_pass2.txt):
-//   KP = 16: k_grads_x -- 2.5 - 2.6 ms at c3 against 3.2, and no slower at any batch size down to 64 spectra;
-//   KP = 8 : k_grads_x once the batch fills the chip (one workgroup of 64 spectra per CU, >= 1.5 rounds): 1.51 against 2.11 ms
-//            at the DESI shape (40 000 x 9243), 0.040 / 0.044 at the reference's default batch of 500; k_grads (two
-//            workgroups per CU) below that: 0.174 against 0.197 ms at c2 (10 000 x 2000).
-// QFA_F_PASS2_F32 / QFA_F_PASS2_XDL in the call's `flags` force one form (A/B timing and the cross-check of the two
-// forms in tests/).
+// Which form of pass 2 runs at N_h <= 16 (KP = 8 or 16).  Three forms: k_grads (float32-MFMA stage 1; the only one for
+// N_h = 17..32), the two-role all-XDL k_grads_x, the pixel-resident all-XDL k_grads_t.  Defaults from measurements on MI355X
+// (tools/time_pass2.py: pass 1 + solve + pass 2 per call, ms; profiles/r3_ablation_pass2.txt):
+//   k_grads never: k_grads_x is as fast or faster at every batch size measured, N_h = 8: 0.072 / 0.083 at 500 spectra x 2000 px,
+//     0.104 / 0.117 at 2 000, 0.192 / 0.220 at 8 000, 2.82 / 3.25 at 40 000 x 9243 (the one exception, 10 000 x 2000 --
+//     157 blocks on 256 CUs, 0.281 / 0.258 -- goes to k_grads_t); N_h = 16: 2.5 - 2.6 against 3.2 ms at c3;
+//   k_grads_t once the batch gives every workgroup a walk long enough to pay for its prologue and epilogue:
+//     N_h = 9..16 from 96 spectra per CU (24 576) on: N_pix = 4000: 0.146 / 0.166 at 1 000 spectra, 0.42 / 0.44 at 8 000,
+//       1.43 / 1.35 at 32 000, 4.31 / 3.98 at 100 000 (k_grads_x / k_grads_t); N_pix = 640: 0.161 / 0.183 at 8 000, 1.085 / 0.971 at 100 000;
+//     N_h <= 8 from 96 spectra per CU on, and from 36 per CU (9 216) on for 1024 <= N_pix <= 4096: N_pix = 2000: 0.192 / 0.195 at
+//       8 000, 0.281 / 0.234 at 10 000, 0.522 / 0.432 at 24 000, 1.21 / 0.95 at 64 000; N_pix = 640: 0.116 / 0.141 at 8 000,
+//       0.274 / 0.260 at 32 000, 0.83 / 0.62 at 100 000; N_pix = 9243: 0.635 / 0.700 at 8 000, 1.78 / 1.79 at 24 000, 3.02 / 2.88 at 40 000.
+// QFA_F_PASS2_F32 / QFA_F_PASS2_XDL / QFA_F_PASS2_PIXRES in the call's `flags` force one form (A/B timing and the cross-checks of
+// the forms in tests/).
 inline bool pass2_use_xdl(int KP, int B, unsigned flags) {
+    (void)B;
     if (flags & QFA_F_PASS2_F32) return false;
-    if (flags & (QFA_F_PASS2_XDL | QFA_F_PASS2_PIXRES)) return true;
-    return KP == 16 || B >= 96 * cu_count();
+    return KP == 16 || KP == 8;
 }
-// ... and which all-XDL form at N_h = 9..16: the pixel-resident one (k_grads_t, qfa_grads_t.h) once the batch gives every
-// workgroup a walk long enough to pay for its prologue and for the per-group operand images (k_prep_pst).  Measured on
-// MI355X (tools/time_pass2.py, pass 1 + solve + pass 2 per call, ms): N_pix = 4000: 0.146 / 0.166 at 1 000 spectra, 0.42 /
-// 0.44 at 8 000, 1.43 / 1.35 at 32 000, 4.31 / 3.98 at 100 000 (k_grads_x / k_grads_t); N_pix = 640: 0.089 / 0.101, 0.161 /
-// 0.183, 0.365 / 0.356, 1.085 / 0.971.  QFA_F_PASS2_XDL / QFA_F_PASS2_PIXRES force one.
-inline bool pass2_use_pixres(int KP, int B, unsigned flags) {
-    if ((KP != 16 && KP != 8) || (flags & (QFA_F_PASS2_F32 | QFA_F_PASS2_WFORM | QFA_F_S3_FAST))) return false;
+inline bool pass2_use_pixres(int KP, int B, int Npix, unsigned flags) {
+    if ((KP != 16 && KP != 8) || Npix < 16 || (flags & (QFA_F_PASS2_F32 | QFA_F_PASS2_WFORM | QFA_F_S3_FAST))) return false;
     if (flags & QFA_F_PASS2_PIXRES) return true;
     if (flags & QFA_F_PASS2_XDL) return false;
-    // N_h <= 8: the walk is bound by its non-MFMA instruction streams, which do not shrink with N_h -- DESI shape (40 000 x
-    // 9243, N_h = 8): 2.12 ms against 1.77 for k_grads_x<8>; available with the flag, not the default
-    return KP == 16 && B >= 96 * cu_count();
+    const int ncu = cu_count();
+    if (B >= 96 * ncu) return true;
+    return KP == 8 && B >= 36 * ncu && Npix >= 1024 && Npix <= 4096;
 }
 
 // launch errors of the calls just made; with QFA_F_SYNC also the asynchronous ones (the stream is drained first)
@@ -341,7 +342,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
     // the float32 images PF / PFT serve k_moments (N_h > 16) and k_grads: not needed when both passes run on the XDL pipe
     if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, zt.ZP, Npix, Nb, Nh, L, PF, PFT, st);
-    const bool pixres = pass2_xdl && Npix >= 16 && pass2_use_pixres(KP, B, flags);      // (its ragged-tile staging wants N_pix >= 4)
+    const bool pixres = pass2_xdl && pass2_use_pixres(KP, B, Npix, flags);             // (its ragged-tile staging wants N_pix >= 4)
     if (pixres) qfa_gt_prep_image(KP, p, reinterpret_cast<const float *>(zt.ZP), Npix, Nb, Nh, reinterpret_cast<unsigned char *>(ws + L.oPGX), st);
     mark(1);
     launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, zt, ws, st);

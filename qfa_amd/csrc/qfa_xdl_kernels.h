@@ -274,6 +274,23 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
     c = xdl(ah, bm, c);
     return xdl(ah, bh, c);
 }
+#ifndef QFA_P1_STAMPS
+#define QFA_P1_STAMPS 0    // diagnostic build (tools/p1_stamps.sh): s_memtime shares of the tile steps of one wave of pass 1
+#endif
+#if QFA_P1_STAMPS
+__device__ unsigned long long qfa_p1_stamps[2 * 16];
+#define P1S(i)                                                                                 \
+    {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        unsigned long long t_;                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        st_[(BLUE ? 8 : 0) + i] += (unsigned)(t_ - st_last);                                   \
+        st_last = t_;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+#else
+#define P1S(i) {}
+#endif
 template <int KP, bool PREDICT, int NW, bool ZF>      // ZF: factored-z input form (ZS = per-spectrum factors; zabs is not read)
 __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_moments_x(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
                                                       const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
@@ -307,6 +324,12 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
     const unsigned voffN = (unsigned)(offN + 8 * g) * 4u, voffB = (unsigned)(offB + 8 * g) * 4u,
                    voffM = (unsigned)(offN + 8 * g);
 
+#if QFA_P1_STAMPS
+    unsigned st_[16];
+    for (int i = 0; i < 16; ++i) st_[i] = 0;
+    unsigned long long st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
     f32x4 accC[C::NT], accT[C::NT], accb[C::NFT], accb2[C::NFT];
 #pragma unroll
     for (int t = 0; t < C::NT; ++t) accC[t] = accT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -500,7 +523,9 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             Pieces w;
             if (QFA_P1_EARLY_DMA && c + 1 < n && !(QFA_P1_ABL & 8)) stage(ta + c + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+            P1S(0)
             land<BLUE && !ZF>(cur);
+            P1S(1)
             if (QFA_P1_ABL & 4) {            // timing only: no weights (pieces straight from the spectra registers)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -511,21 +536,27 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 }
             } else if (active) weights(ta + c, cur, lds[buf], w);
             __builtin_amdgcn_sched_barrier(0);
+            P1S(2)
             if (!QFA_P1_EARLY_DMA && c + 1 < n && !(QFA_P1_ABL & 8)) stage(ta + c + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+            P1S(7)
             const bool reload = active & (c + 2 < n) & !(QFA_P1_ABL & 1);
             if (reload) load_spec(ta + c + 2, cur);
             __builtin_amdgcn_sched_barrier(0);
+            P1S(3)
             if (QFA_P1_ABL & 2) {            // timing only: no MFMAs (the pieces stay live)
                 asm volatile("" ::"v"(w.w1h), "v"(w.w1m), "v"(w.w1l), "v"(w.w3h), "v"(w.w3m), "v"(w.w3l));
                 if (BLUE) asm volatile("" ::"v"(w.w2h), "v"(w.w2m), "v"(w.w2l), "v"(w.w4h), "v"(w.w4m), "v"(w.w4l));
             } else if (active) mfmas(lds[buf], w, std::integral_constant<int, 0>{});
+            P1S(4)
             // retire everything up to and including the DMA: it was issued before the 5 (red: 2 delta, 2 sigma,
             // 1 mask) / 7 (blue: + 2 zabs) spectra loads of this step (the ragged-end path issues more, smaller ones)
             if (reload) dma_wait<(BLUE && !ZF) ? 7 : 5>();
             else dma_wait<0>();
+            P1S(5)
             wg_barrier();
             asm volatile("" ::: "memory");
+            P1S(6)
         };
 
         // N_h > 16, one tile in two sweeps: sub-image 0 lives in ring slot 0, sub-image 1 in slot 1.  Sweep 0: weights,
@@ -615,6 +646,10 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
     for (int t = 0; t < C::NFT; ++t) accb2[t] = accb[t];
     run(std::true_type{}, t0, min(t1, nbt));
 
+#if QFA_P1_STAMPS
+    if (blockIdx.x == 300 && wv == 0 && lane == 0)
+        for (int i = 0; i < 16; ++i) qfa_p1_stamps[i] = st_[i];
+#endif
     if (!active) return;
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4g + r, column 16t + sl
     float *momseg = mom_segment<C::NMOM>(MOM, wp, seg, Bpad, 16 * NW);

@@ -16,8 +16,8 @@ for B in BS:
     d, e, z, m_, zq = synthetic.make_batch_torch(p, mu, wav, nb, B, seed=2, device=dev, return_zq=True)
     zfac = ((1.0 + zq.double()).float(), torch.tensor((wav[:nb] / synthetic.LYA).astype(np.float32), device=dev))
     out = []
-    for name, fl, zf in (("x", _lib.F_PASS2_XDL, None), ("t", _lib.F_PASS2_XDL | _lib.F_PASS2_PIXRES, None),
-                         ("x+zf", _lib.F_PASS2_XDL, zfac), ("t+zf", _lib.F_PASS2_XDL | _lib.F_PASS2_PIXRES, zfac)):
+    for name, fl, zf in (("f", _lib.F_PASS2_F32, None), ("x", _lib.F_PASS2_XDL, None), ("t", _lib.F_PASS2_PIXRES, None),
+                         ("f+zf", _lib.F_PASS2_F32, zfac), ("x+zf", _lib.F_PASS2_XDL, zfac), ("t+zf", _lib.F_PASS2_PIXRES, zfac)):
         m = QFA(nb, nr, nh, dev, model_params=p); m.mu = torch.tensor(mu, device=dev); m.flags = fl
         for _ in range(3): m.accumulate(d, e, z if zf is None else None, m_, zfac=zf)
         torch.cuda.synchronize()
