@@ -186,9 +186,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                  "v"(k.t_expo), "v"(k.t_off), "v"(k.offp), "v"(k.k1), "v"(k.omc0));
 
     // ---- running sums
-    f32x4 W[KP];
+    f32x4 W[GT::NWT];
 #pragma unroll
-    for (int a = 0; a < KP; ++a) W[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < GT::NWT; ++a) W[a] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
     float gPsi = 0.f, gOm = 0.f, sA = 0.f, cnt = 0.f;
     double d_tau0 = 0.0, d_c0 = 0.0, d_beta = 0.0;
@@ -494,13 +494,13 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         zop[0][0] = *reinterpret_cast<const u32x4 *>(zp);
         zop[0][1] = *reinterpret_cast<const u32x4 *>(zp + 1024);
 #pragma unroll
-        for (int a = 0; a < KP; ++a) {
+        for (int a = 0; a < GT::NWT; ++a) {
 #ifndef QFA_GT_ABL
 #define QFA_GT_ABL 0       // timing experiments (wrong results): 1 = stage 3 without its LDS reads, 2 = stage 3 without its DMA pieces
 #endif
             if (QFA_GT_ABL & 1) { zop[(a + 1) & 1][0] = IBh[a % GT::NKQ]; zop[(a + 1) & 1][1] = IBm[a % GT::NKQ]; }
             else {
-            zop[(a + 1) & 1][0] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048);          // (a + 1 == KP: the p operands)
+            zop[(a + 1) & 1][0] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048);          // (a + 1 == NWT: the p operands)
             zop[(a + 1) & 1][1] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048 + 1024);
             }
             if (a % 2 == 0 && !(QFA_GT_ABL & 2)) piece(pt, a / 2);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         split2(gamR[0], gamR[1], h01, m01, l01);
         split2(gamR[2], gamR[3], h23, m23, l23);
         const u32x4 ghl = {h01, h23, l01, l23}, gmm = {m01, m23, m01, m23}, ghh = {h01, h23, h01, h23};
-        const u32x4 &P1 = zop[KP & 1][0], &P2 = zop[KP & 1][1];
+        const u32x4 &P1 = zop[GT::NWT & 1][0], &P2 = zop[GT::NWT & 1][1];
         gacc = xdl(P2, ghh, xdl(P2, gmm, xdl(P1, ghl, gacc)));                                      // sum_s p_s[b] gamma[s][px]
     };
 
@@ -590,19 +590,32 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     if (active) {
         const float *fr = reinterpret_cast<const float *>(tile + GT::OFF_F) + lo * KP;
         f32x4 acc = gacc;
+        if constexpr (GT::APT == 1) {
 #pragma unroll
-        for (int a4 = 0; a4 < KP / 4; ++a4) {
-            const float4 f4 = *reinterpret_cast<const float4 *>(fr + 4 * a4);
-            const float fa[4] = {f4.x, f4.y, f4.z, f4.w};
+            for (int a4 = 0; a4 < KP / 4; ++a4) {
+                const float4 f4 = *reinterpret_cast<const float4 *>(fr + 4 * a4);
+                const float fa[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa[j], W[4 * a4 + j][r], acc[r]);
+                    for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa[j], W[4 * a4 + j][r], acc[r]);
+            }
+        } else {
+            // KP = 8: the lane's rows 4 g + r of tile wt are (a = 2 wt + (g >> 1), b = 4 (g & 1) + r); the two a of a tile sit in
+            // the lanes g and g ^ 2, summed across them below
+#pragma unroll
+            for (int wt = 0; wt < GT::NWT; ++wt) {
+                const float fa = fr[2 * wt + (g >> 1)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa, W[wt][r], acc[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], 32);
         }
-        if (inb) {
+        if (inb && (GT::APT == 1 || g < 2)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int b = 4 * g + r;
+                const int b = (GT::APT == 1 ? 4 * g : 4 * (g & 1)) + r;
                 if (b < Nh) {
                     float *q = accF + (size_t)px * Nh + b;
                     if (det) *q = acc[r];

@@ -23,12 +23,16 @@ struct GTT {
     // per group of 16 spectra in global memory (k_prep_pst)
     static constexpr int S1_B = NKS * 3 * 1024;              // [block][piece][lane (g, lo = spectrum)][8 k]: A[s][k] of stage 1
     static constexpr int S1P_B = S1_B;                       // (the S1 part as the ring holds it)
-    static constexpr int Z_B = KP * 2 * 1024;                // [a][operand 1, 2][lane (g, lo = b)][4 dwords]
+    // stage 3: column tiles of W.  KP = 16: one per a (rows m = b).  KP = 8: the 8 rows b of TWO a fill one 16-row MFMA tile
+    // (row m <-> a = 2 tile + (m >> 3), b = m & 7): half the MFMAs, operand reads and accumulator registers
+    static constexpr int APT = 16 / KP;                      // a per tile (1 or 2)
+    static constexpr int NWT = KP / APT;                     // tiles (16 or 4)
+    static constexpr int Z_B = NWT * 2 * 1024;               // [tile][operand 1, 2][lane (g, lo = row m)][4 dwords]
     static constexpr int ZP_B = Z_B + 2 * 1024;              // + the p operands (gamma term)
     static constexpr int STATE_B = S1P_B + ZP_B;
     static constexpr int NW = 8;                             // waves = tiles per workgroup
     // a part moves as 1-KiB pieces, contiguous runs of them per wave (k_grads_t decides which waves)
-    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34 (KP = 8: 9, 18)
+    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34 (KP = 8: 9, 10)
     static_assert((Z_PCS + 4) / 5 <= 7 && (S1_PCS + 4) / 5 <= 6, "pieces per wave and stage: 7 slots in stage 2, 8 in stage 3, 6 in stage 1");
     // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
     // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
@@ -44,9 +48,9 @@ static_assert(GTT<16>::L_TOTAL <= 160 * 1024 && GTT<8>::L_TOTAL <= 160 * 1024, "
 // build_state : the solve's output of one group of 16 spectra (`rows`: 16 records of Cfg<KP>::NSOL floats, global memory or
 // LDS) -> the group's state as split-bf16 MFMA operands, in the order the walk streams them.  256 threads.
 //   S1 part: A[m = spectrum lo][k = 8 g + j of block ks] = ks < NKQ: Cinv'[pair 32 ks + 8 g + j] | ks = NKQ: y[8 g + j - YOFF]
-//   Z  part: per column tile a, operands ZA1 = {l01, l23, h01, h23}, ZA2 = {h01, h23, m01, m23} of
-//            x[r] = Z_{4 g + r}[a][b = lo] (row m = b; k = 8 g + j <-> spectrum 4 g + (j & 3), piece slot j >> 2);
-//            then the same two operands of p_{4 g + r}[b]
+//   Z  part: per column tile, operands ZA1 = {l01, l23, h01, h23}, ZA2 = {h01, h23, m01, m23} of
+//            x[r] = Z_{4 g + r}[a][b] (row m = lo <-> (a, b): GTT::APT; k = 8 g + j <-> spectrum 4 g + (j & 3), piece slot j >> 2);
+//            then the same two operands of p_{4 g + r}[b] (rows b < KP)
 // ------------------------------------------------------------------------------------------------
 template <int KP>
 __device__ __forceinline__ void build_state(const float *rows, int s0, int B, int Nh, unsigned char *__restrict__ st, int tid) {
@@ -76,19 +80,20 @@ __device__ __forceinline__ void build_state(const float *rows, int s0, int B, in
         *reinterpret_cast<u32x4 *>(dst + 1024) = m;
         *reinterpret_cast<u32x4 *>(dst + 2048) = l;
     }
-    for (int i = tid; i < (KP + 1) * 64; i += 256) {
-        const int lane = i & 63, a = i >> 6, lo = lane & 15, g = lane >> 4;       // a == KP: the p operands
+    for (int i = tid; i < (GT::NWT + 1) * 64; i += 256) {
+        const int lane = i & 63, wt = i >> 6, lo = lane & 15, g = lane >> 4;      // wt == NWT: the p operands
+        const int a = wt * GT::APT + (lo >> (KP == 8 ? 3 : 4)), bcol = lo & (KP - 1);           // row lo of tile wt <-> Z[a][bcol]
         float x[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool v = s0 + 4 * g + r < B && lo < Nh && lo < KP;
+            const bool v = s0 + 4 * g + r < B && bcol < Nh && (wt < GT::NWT || lo < KP);
             const float *sol = rows + (size_t)(v ? 4 * g + r : 0) * C::NSOL;
-            x[r] = v ? (a < KP ? sol[C::SOL_Z + a * KP + (lo & (KP - 1))] : sol[C::SOL_P + (lo & (KP - 1))]) : 0.f;
+            x[r] = v ? (wt < GT::NWT ? sol[C::SOL_Z + a * KP + bcol] : sol[C::SOL_P + bcol]) : 0.f;
         }
         unsigned h01, m01, l01, h23, m23, l23;
         split2(x[0], x[1], h01, m01, l01);
         split2(x[2], x[3], h23, m23, l23);
-        unsigned char *dst = st + GT::S1P_B + a * 2048 + lane * 16;
+        unsigned char *dst = st + GT::S1P_B + wt * 2048 + lane * 16;
         *reinterpret_cast<u32x4 *>(dst) = u32x4{l01, l23, h01, h23};
         *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{h01, h23, m01, m23};
     }
