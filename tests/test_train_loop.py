@@ -286,8 +286,9 @@ def test_step_graph_key_follows_adam_buffers():
     assert all(float(opt.m[k].abs().sum()) > 0 for k in ("F", "Psi"))      # the LIVE moments were updated
 
 
-@pytest.mark.parametrize("npix,nh", [(640, 16), (704, 24), (640, 12)])
-def test_training_trajectory_on_the_xdl_path_matches_oracle_loop(tmp_path, npix, nh):
+@pytest.mark.parametrize("npix,nh,flags", [(640, 16, 0), (704, 24, 0), (640, 12, 0),
+                                           (640, 16, 0x40), (640, 8, 0x40)])      # 0x40 = F_PASS2_PIXRES: k_solve's operand images + k_grads_t
+def test_training_trajectory_on_the_xdl_path_matches_oracle_loop(tmp_path, npix, nh, flags):
     """north_star: "learned F / Psi / mu within a stated fp32 tolerance" -- on the kernels the headline runs on
     (N_h = 9..16: k_moments_x + k_grads_x; 17..32: k_moments_x<32> + k_s12_x + k_grads_s3), not only the N_h = 4 case above.
     3 epochs x 4 batches (one partial) against the oracle-driven replica of QFA/model.py:204-215; tolerance 2e-5 on
@@ -299,8 +300,10 @@ def test_training_trajectory_on_the_xdl_path_matches_oracle_loop(tmp_path, npix,
     p, mu = synthetic.mock_parameters(npix, nb, nh, seed=60 + nh)
     b = synthetic.make_batch_numpy(p, mu, wav, nb, 120, seed=61 + nh)       # 120 = 3 x 32 + 24
     model = QFA(nb, nr, nh, dev, model_params=p)
+    model.flags = flags
     opt = Adam(model.parameters, dev, scheduler=step_scheduler(0.9, 1), learning_rate=1e-3, weight_decay=1e-1)
-    model.train(opt, FakeLoader(b, mu, 32, dev), 3, str(tmp_path), save_interval=10, smooth_interval=2, quiet=True)
+    model.train(opt, FakeLoader(b, mu, 32, dev), 3, str(tmp_path), save_interval=10, smooth_interval=2, quiet=True,
+                use_graph=bool(flags))       # (the pixel-resident cases also replay the step as a hipGraph)
     ref, losses = _oracle_train(p, b, 32, 3, 1e-3, 0.9, 1, 1e-1, 2)
     assert opt.i == 3
     for k in KEYS:
