@@ -84,7 +84,7 @@ typedef struct {
 #define QFA_F_PASS2_PIXRES 0x40u /* N_h <= 16: pass 2 in its pixel-resident all-XDL form (k_grads_t: a wave owns 16 pixels
                                   * and walks the spectra; the per-spectrum operands stream through LDS).  Without any
                                   * QFA_F_PASS2_* flag the library picks between k_grads_x (small batches) and this form
-                                  * (from 96 spectra per CU on; N_h <= 8 and 1024 <= N_pix <= 4096: from 36 per CU on) --
+                                  * (from 96 spectra per CU on; N_h <= 8 and N_pix >= 1024: from 36 per CU on) --
                                   * qfa_host.h, pass2_use_pixres                                                      */
 #define QFA_F_PASS2_WFORM  0x10u /* N_h <= 16: the one-wave-per-SIMD form of the all-XDL pass 2 (k_grads_w: stage 3
                                     re-associated as a K = spectrum GEMM; same results, slower -- DESIGN.md)    */

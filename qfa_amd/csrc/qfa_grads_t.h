@@ -33,7 +33,7 @@
 
 // the split of the launch: tiles, pixel blocks, ranges of spectra groups (host and device agree through this struct)
 struct GtPlan {
-    int T16, PB, R, gpr;          // 16-pixel tiles; pixel blocks of 8 tiles; ranges; groups of 16 spectra per range
+    int T16, PB, R, gpr;          // wave tiles (GTT::PXW pixels each); pixel blocks of 8 wave tiles; ranges; groups of 16 spectra per range
     // Work item i = r PB + pb (range-major).  Workgroup b runs item (b % 8) ceil(PB R / 8) + b / 8: workgroups go to the XCDs
     // round-robin (b % 8), so every XCD gets a contiguous run of items -- the pixel blocks of ONE or two ranges, which walk
     // the same state in step and share it in that XCD's L2, whatever R is (the grid is padded to a multiple of 8)
@@ -50,11 +50,13 @@ __global__ __launch_bounds__(256) void k_prep_pgt(const float *__restrict__ F, c
                                                   int Npix, int Nb, int Nh, unsigned char *__restrict__ PGT) {
     using GT = GTT<KP>;
     unsigned char *tile = PGT + (size_t)blockIdx.x * GT::TILE_B;
-    const int p0 = 16 * blockIdx.x;
+    // tile blockIdx = TPW wt + j of wave tile wt: column lo <-> pixel PXW wt + TPW lo + j
+    const int p0 = GT::PXW * ((int)blockIdx.x / GT::TPW) + (int)blockIdx.x % GT::TPW;
+    auto pixel = [&](int lo) { return p0 + GT::TPW * lo; };
     __shared__ float f[16][KP + 1];
     for (int i = threadIdx.x; i < 16 * KP; i += 256) {
         const int px = i / KP, a = i % KP;
-        f[px][a] = (p0 + px < Npix && a < Nh) ? F[(size_t)(p0 + px) * Nh + a] : 0.f;
+        f[px][a] = (pixel(px) < Npix && a < Nh) ? F[(size_t)pixel(px) * Nh + a] : 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < GT::NKQ * 64; i += 256) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void k_prep_pgt(const float *__restrict__ F, c
         *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
     }
     if (threadIdx.x < 128) {
-        const int j = threadIdx.x, px = p0 + (j & 15);
+        const int j = threadIdx.x, px = pixel(j & 15);
         float v = 0.f;
         if (j < 16) v = px < Npix ? Psi[px] : 0.f;
         else if (j < 32) v = px < Nb ? omega[px] : 0.f;
@@ -144,14 +146,22 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const int G = (B + 15) >> 4;
     const int g0 = rr * gp.gpr;                             // first group of the range
     const int n = idle ? 0 : max(0, min(gp.gpr, G - g0));   // groups in the range (the same for every wave: the barriers)
-    const int tl = pb + gp.PB * wv8;                        // this wave's tile
+    constexpr int TPW = GT::TPW, PXW = GT::PXW;
+    const int wt = pb + gp.PB * wv8;                        // this wave's tile of PXW pixels
 #ifndef QFA_GT_ONLY
 #define QFA_GT_ONLY 0      // timing experiments (wrong results): 1 = waves 0..3 only, 2 = waves 4..7 only
 #endif
-    const bool active = !idle && tl < gp.T16 && (QFA_GT_ONLY == 0 || (QFA_GT_ONLY == 1) == (wv8 < 4));      // wave-uniform
-    const int px = 16 * tl + lo;
-    const bool inb = active && px < Npix, blue = active && px < Nb;
-    const bool blueTile = active && 16 * tl < Nb;           // wave-uniform: the tile has blue pixels
+    const bool active = !idle && wt < gp.T16 && (QFA_GT_ONLY == 0 || (QFA_GT_ONLY == 1) == (wv8 < 4));      // wave-uniform
+    // 16-pixel tile j of the wave: column lo <-> pixel PXW wt + TPW lo + j
+    int px[TPW];
+    bool inb[TPW], blue[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        px[j] = PXW * wt + TPW * lo + j;
+        inb[j] = active && px[j] < Npix;
+        blue[j] = active && px[j] < Nb;
+    }
+    const bool blueTile = active && PXW * wt < Nb;          // wave-uniform: the wave tile has blue pixels
     const DevConsts k = load_consts(p, tau);
     const bool det = slab != nullptr;
     float *accF = det ? slab + (size_t)rr * (size_t)slab_stride : accum;
@@ -164,49 +174,72 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     unsigned long long st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
-    // ---- static operands of the wave's tile
-    const unsigned char *tile = PGT + (size_t)(active ? tl : 0) * GT::TILE_B;
-    u32x4 IBh[GT::NKQ], IBm[GT::NKQ], IBl[GT::NKQ];
+    // ---- static operands of the wave's tiles
+    const unsigned char *tile[TPW];
+    u32x4 IBh[TPW][GT::NKQ], IBm[TPW][GT::NKQ], IBl[TPW][GT::NKQ];
+    float Psi[TPW], om[TPW], ti[TPW], pwi[TPW], l2i[TPW];
 #pragma unroll
-    for (int ks = 0; ks < GT::NKQ; ++ks) {
-        IBh[ks] = *reinterpret_cast<const u32x4 *>(tile + ks * 3072 + lane * 16);
-        IBm[ks] = *reinterpret_cast<const u32x4 *>(tile + ks * 3072 + 1024 + lane * 16);
-        IBl[ks] = *reinterpret_cast<const u32x4 *>(tile + ks * 3072 + 2048 + lane * 16);
+    for (int j = 0; j < TPW; ++j) {
+        tile[j] = PGT + (size_t)(active ? TPW * wt + j : 0) * GT::TILE_B;
+#pragma unroll
+        for (int ks = 0; ks < GT::NKQ; ++ks) {
+            IBh[j][ks] = *reinterpret_cast<const u32x4 *>(tile[j] + ks * 3072 + lane * 16);
+            IBm[j][ks] = *reinterpret_cast<const u32x4 *>(tile[j] + ks * 3072 + 1024 + lane * 16);
+            IBl[j][ks] = *reinterpret_cast<const u32x4 *>(tile[j] + ks * 3072 + 2048 + lane * 16);
+        }
+        const float *par = reinterpret_cast<const float *>(tile[j] + GT::OFF_PAR);
+        Psi[j] = par[lo]; om[j] = par[16 + lo];
+        ti[j] = ZF ? par[32 + lo] : 0.f; pwi[j] = ZF ? par[48 + lo] : 0.f; l2i[j] = ZF ? par[64 + lo] : 0.f;
     }
-    const float *par = reinterpret_cast<const float *>(tile + GT::OFF_PAR);
-    const float Psi = par[lo], om = par[16 + lo];
-    const float ti = ZF ? par[32 + lo] : 0.f, pwi = ZF ? par[48 + lo] : 0.f, l2i = ZF ? par[64 + lo] : 0.f;
 
     // Every load of this prologue is consumed HERE: hipcc puts the s_waitcnt of a load in front of its first use, and a first
     // use inside the walk leaves a vmcnt(0..4) in the loop that drains the untracked DMA queue in every step (stage 2 of
     // a blue group took 2 550 cycles that way, tools/gt_stamps.sh)
 #pragma unroll
-    for (int ks = 0; ks < GT::NKQ; ++ks) asm volatile("" ::"v"(IBh[ks]), "v"(IBm[ks]), "v"(IBl[ks]));
-    asm volatile("" ::"v"(Psi), "v"(om), "v"(ti), "v"(pwi), "v"(l2i), "v"(k.tau0), "v"(k.c0), "v"(k.beta), "v"(k.t_amp), "v"(k.t_lscale),
-                 "v"(k.t_expo), "v"(k.t_off), "v"(k.offp), "v"(k.k1), "v"(k.omc0));
+    for (int j = 0; j < TPW; ++j) {
+#pragma unroll
+        for (int ks = 0; ks < GT::NKQ; ++ks) asm volatile("" ::"v"(IBh[j][ks]), "v"(IBm[j][ks]), "v"(IBl[j][ks]));
+        asm volatile("" ::"v"(Psi[j]), "v"(om[j]), "v"(ti[j]), "v"(pwi[j]), "v"(l2i[j]));
+    }
+    asm volatile("" ::"v"(k.tau0), "v"(k.c0), "v"(k.beta), "v"(k.t_amp), "v"(k.t_lscale), "v"(k.t_expo), "v"(k.t_off), "v"(k.offp),
+                 "v"(k.k1), "v"(k.omc0));
 
     // ---- running sums
-    f32x4 W[GT::NWT];
+    f32x4 W[TPW][GT::NWT], gacc[TPW];
+    float gPsi[TPW], gOm[TPW], sA[TPW], cnt[TPW];
+    f32x4 betaR[TPW], gamR[TPW];                            // stage 2 -> stage 3 (across one barrier)
 #pragma unroll
-    for (int a = 0; a < GT::NWT; ++a) W[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
-    float gPsi = 0.f, gOm = 0.f, sA = 0.f, cnt = 0.f;
+    for (int j = 0; j < TPW; ++j) {
+#pragma unroll
+        for (int a = 0; a < GT::NWT; ++a) W[j][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gacc[j] = betaR[j] = gamR[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gPsi[j] = gOm[j] = sA[j] = cnt[j] = 0.f;
+    }
     double d_tau0 = 0.0, d_c0 = 0.0, d_beta = 0.0;
-    f32x4 betaR = {0.f, 0.f, 0.f, 0.f}, gamR = {0.f, 0.f, 0.f, 0.f};      // stage 2 -> stage 3 (across one barrier)
 
-    // ---- spectra staging of this wave
+    // ---- spectra staging of this wave: per array [16 slots][PXW px] float (slot q holds row q ^ ((q >> 2) & 1): the rows
+    // 4 g + r that a lane's reads touch then alternate between the two halves of the banks), mask bytes as PXW / 16 halves
+    // [16 slots][16]
     unsigned char *stg = lds + GT::L_STG + wv8 * 2 * GT::STG_B;
-    const bool fastp = active && 16 * tl + 15 < Npix;
+    const bool fastp = active && PXW * wt + PXW - 1 < Npix;
     const bool zblue = !ZF && blueTile;                     // the tile stages zabs
-    const bool fastz = !zblue || 16 * tl + 15 < Nb;
+    const bool fastz = !zblue || PXW * wt + PXW - 1 < Nb;
     const bool slow = active && !fastp;                     // the ragged last tile: 4-byte pieces
     const bool zstrad = active && fastp && !fastz;          // zabs form, the tile across the end of the blue side: zabs as 4-byte pieces
     const bool zfb = ZF && blueTile;                        // the tile stages the per-spectrum factors of the factored-z form
-    // requests per group (the counted waits): fast tile 3 (+ 1: zabs or the factors); zabs tile across the boundary 3 + 4;
-    // ragged tile 4 + 4 + 1 (+ 4: zabs) (+ 1: the factors)
-    const int nsp = !active ? 0 : (slow ? 9 + (zblue ? 4 : 0) + (zfb ? 1 : 0) : (zstrad ? 7 : ((zblue || zfb) ? 4 : 3)));
+    // requests per group (the counted waits).  TPW = 1: fast tile 3 (+ 1: zabs or the factors); zabs tile across the boundary
+    // 3 + 4; ragged tile 4 + 4 + 1 (+ 4: zabs) (+ 1: the factors).  In general: 16-byte pieces TPW per array, 4-byte pieces
+    // 4 TPW per array, the masks TPW
+    const int nsp = !active ? 0
+                            : (slow ? 9 * TPW + (zblue ? 4 * TPW : 0) + (zfb ? 1 : 0)
+                                    : (zstrad ? 7 * TPW : 3 * TPW + (zblue ? TPW : 0) + (zfb ? 1 : 0)));
+    // first byte of the 4-byte mask piece (half h of the tile, piece pc) in its row; the ragged tile clamps it to Npix - 4
+    auto mask_start = [&](int h, int pc) __attribute__((always_inline)) {
+        const int st = PXW * wt + 16 * h + 4 * pc;
+        return slow ? max(0, min(st, Npix - 4)) : st;
+    };
     // group t of the range: rows s0 .. s0 + 15
-    auto stage_spectra = [&](int t, int bufi) {
+    auto stage_spectra = [&](int t, int bufi) __attribute__((always_inline)) {
         if (!active) return;
         const int s0 = 16 * (g0 + t);
         const int last_row = min(15, B - 1 - s0);                                     // wave-uniform, >= 0
@@ -215,22 +248,23 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)s0 * Npix);
         const float *zbase = zblue ? uniform_ptr(bt.zabs + (size_t)s0 * Nb) : dbase;
         const unsigned dst = wave_uniform(lds_addr(stg + bufi * GT::STG_B));
+        auto slot_row = [&](int q) __attribute__((always_inline)) { return (unsigned)min(q ^ ((q >> 2) & 1), last_row); };
 #if QFA_TRACKED_LOADS
         {
             float *sf = reinterpret_cast<float *>(stg + bufi * GT::STG_B);
             unsigned char *mb = stg + bufi * GT::STG_B + GT::STG_MASK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = 4 * i + g;
-                const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
-                const int pxx = 16 * tl + lo;
+            for (int i = 0; i < 4 * TPW; ++i) {
+                const int e = 64 * i + lane, q = e / PXW, pl = e % PXW;               // (slot, pixel of the wave tile)
+                const unsigned row = slot_row(q);
+                const int pxx = PXW * wt + pl;
                 const unsigned o = row * (unsigned)Npix + (unsigned)min(pxx, Npix - 1);
-                sf[0 * 256 + q * 16 + lo] = dbase[o];
-                sf[1 * 256 + q * 16 + lo] = ebase[o];
-                if (zblue) sf[2 * 256 + q * 16 + lo] = zbase[row * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)];
-                mb[q * 16 + lo] = pxx < Npix ? mbase[o] : (unsigned char)0;
+                sf[0 * (GT::STG_ARR / 4) + q * PXW + pl] = dbase[o];
+                sf[1 * (GT::STG_ARR / 4) + q * PXW + pl] = ebase[o];
+                if (zblue) sf[2 * (GT::STG_ARR / 4) + q * PXW + pl] = zbase[row * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)];
+                mb[(pl >> 4) * 256 + q * 16 + (pl & 15)] = pxx < Npix ? mbase[o] : (unsigned char)0;
             }
-            if (zfb && lane < 16) reinterpret_cast<float4 *>(sf + 2 * 256)[lane] = ZS[s0 + min(lane, last_row)];
+            if (zfb && lane < 16) reinterpret_cast<float4 *>(sf + 2 * (GT::STG_ARR / 4))[lane] = ZS[s0 + min(lane, last_row)];
             (void)dst;
             return;
         }
@@ -238,59 +272,84 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         // factored-z form: the factors of the 16 spectra (row r at float4 index r of array 2), one request of 16 lanes
         if (zfb && lane < 16)
             glds16a(uniform_ptr(ZS + s0), 16u * (unsigned)min(lane, last_row), dst + 2 * GT::STG_ARR);
-        if (!slow) {
-            const int q = lane >> 2;                                                  // staging slot; holds row q ^ ((q >> 2) & 1)
-            const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
-            const unsigned pc = 16u * (unsigned)tl + 4u * (unsigned)(lane & 3);       // first pixel of the lane's piece
-            const unsigned o = row * (unsigned)Npix + pc;
-            // delta, sigma, (zabs,) the masks (16 rows x 16 bytes as 4-byte pieces): one write of M0, the LDS offsets in the
-            // instructions' immediate fields, taken off the global bases again
-            const unsigned vo = 4u * o, vz = 4u * (row * (unsigned)Nb + pc);
-            const unsigned char *eb = reinterpret_cast<const unsigned char *>(ebase) - GT::STG_ARR;
-            const unsigned char *zb = reinterpret_cast<const unsigned char *>(zbase) - 2 * GT::STG_ARR;
-            const unsigned char *mb_ = reinterpret_cast<const unsigned char *>(mbase) - GT::STG_MASK;
-            if (zstrad) {                   // zabs of the straddling tile: clamped pixels, 4 slots per request
+        // the masks: per half of 16 pixels one request of 4-byte pieces (lane = (slot, piece))
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int q4 = 4 * i + g;
-                    const unsigned row4 = (unsigned)min(q4 ^ ((q4 >> 2) & 1), last_row);
-                    glds4a(zbase, 4u * (row4 * (unsigned)Nb + (unsigned)min(16 * tl + lo, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+        for (int h = 0; h < TPW; ++h) {
+            if (TPW == 1 && !slow) break;                    // (TPW = 1, fast tile: inside the one statement below)
+            const int q = lane >> 2;
+            glds4a(mbase, slot_row(q) * (unsigned)Npix + (unsigned)mask_start(h, lane & 3), dst + GT::STG_MASK + h * 256);
+        }
+        if (!slow) {
+            if constexpr (TPW == 1) {
+                const int q = lane >> 2;                                              // staging slot
+                const unsigned row = slot_row(q);
+                const unsigned pc = 16u * (unsigned)wt + 4u * (unsigned)(lane & 3);   // first pixel of the lane's piece
+                const unsigned o = row * (unsigned)Npix + pc;
+                // delta, sigma, (zabs,) the masks (16 rows x 16 bytes as 4-byte pieces): one write of M0, the LDS offsets in the
+                // instructions' immediate fields, taken off the global bases again
+                const unsigned vo = 4u * o, vz = 4u * (row * (unsigned)Nb + pc);
+                const unsigned char *eb = reinterpret_cast<const unsigned char *>(ebase) - GT::STG_ARR;
+                const unsigned char *zb = reinterpret_cast<const unsigned char *>(zbase) - 2 * GT::STG_ARR;
+                const unsigned char *mb_ = reinterpret_cast<const unsigned char *>(mbase) - GT::STG_MASK;
+                if (zstrad) {                   // zabs of the straddling tile: clamped pixels, 4 slots per request
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q4 = 4 * i + g;
+                        glds4a(zbase, 4u * (slot_row(q4) * (unsigned)Nb + (unsigned)min(16 * wt + lo, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+                    }
+                }
+                if (zblue && !zstrad)
+                    asm volatile("s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+                                 "global_load_lds_dwordx4 %0, %4 offset:1024\n\tglobal_load_lds_dwordx4 %1, %5 offset:2048\n\t"
+                                 "global_load_lds_dword %2, %6 offset:3072"
+                                 ::"v"(vo), "v"(vz), "v"(o), "s"(dbase), "s"(eb), "s"(zb), "s"(mb_), "s"(dst) : "memory");
+                else
+                    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                                 "global_load_lds_dwordx4 %0, %3 offset:1024\n\tglobal_load_lds_dword %1, %4 offset:3072"
+                                 ::"v"(vo), "v"(o), "s"(dbase), "s"(eb), "s"(mb_), "s"(dst) : "memory");
+            } else {
+                // 16-byte pieces: a row of the wave tile is 4 TPW lanes, a request 16 / TPW slots
+                constexpr int LPR = 4 * TPW, SPI = 64 / LPR;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int q = SPI * i + lane / LPR;
+                    const unsigned row = slot_row(q);
+                    const unsigned pc = (unsigned)(PXW * wt) + 4u * (unsigned)(lane % LPR);
+                    glds16a(dbase, 4u * (row * (unsigned)Npix + pc), dst + i * 1024);
+                    glds16a(ebase, 4u * (row * (unsigned)Npix + pc), dst + GT::STG_ARR + i * 1024);
+                    if (zblue && !zstrad) glds16a(zbase, 4u * (row * (unsigned)Nb + pc), dst + 2 * GT::STG_ARR + i * 1024);
+                }
+                if (zstrad) {
+#pragma unroll
+                    for (int i = 0; i < 4 * TPW; ++i) {
+                        const int e = 64 * i + lane, q = e / PXW, pl = e % PXW;
+                        glds4a(zbase, 4u * (slot_row(q) * (unsigned)Nb + (unsigned)min(PXW * wt + pl, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+                    }
                 }
             }
-            if (zblue && !zstrad)
-                asm volatile("s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
-                             "global_load_lds_dwordx4 %0, %4 offset:1024\n\tglobal_load_lds_dwordx4 %1, %5 offset:2048\n\t"
-                             "global_load_lds_dword %2, %6 offset:3072"
-                             ::"v"(vo), "v"(vz), "v"(o), "s"(dbase), "s"(eb), "s"(zb), "s"(mb_), "s"(dst) : "memory");
-            else
-                asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                             "global_load_lds_dwordx4 %0, %3 offset:1024\n\tglobal_load_lds_dword %1, %4 offset:3072"
-                             ::"v"(vo), "v"(o), "s"(dbase), "s"(eb), "s"(mb_), "s"(dst) : "memory");
             return;
         }
-        // ragged tile (the last one of a pixel axis that is no multiple of 16): 4-byte pieces with the pixel clamped per lane
-        // (4 slots per request); the masks as one request of 4-byte pieces whose start is clamped to Npix - 4 (mask_lo below
-        // is where the lane then finds its byte) -- everything on the counted path
+        // ragged tile (the last one of a pixel axis that is no multiple of PXW): 4-byte pieces with the pixel clamped per lane;
+        // the masks (above) as 4-byte pieces whose start is clamped to Npix - 4 (mask_pos below is where the lane then finds
+        // its byte) -- everything on the counted path
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = 4 * i + g;
-            const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
-            const int pxx = 16 * tl + lo;
+        for (int i = 0; i < 4 * TPW; ++i) {
+            const int e = 64 * i + lane, q = e / PXW, pl = e % PXW;
+            const unsigned row = slot_row(q);
+            const int pxx = PXW * wt + pl;
             const unsigned o = row * (unsigned)Npix + (unsigned)min(pxx, Npix - 1);
             glds4a(dbase, 4u * o, dst + i * 256);
             glds4a(ebase, 4u * o, dst + GT::STG_ARR + i * 256);
             if (zblue) glds4a(zbase, 4u * (row * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
         }
-        {
-            const int q = lane >> 2;
-            const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
-            const int st0 = max(0, min(16 * tl + 4 * (lane & 3), Npix - 4));
-            glds4a(mbase, row * (unsigned)Npix + (unsigned)st0, dst + GT::STG_MASK);
-        }
     };
-    // where the lane's mask byte sits inside its slot's 16 staged bytes (fast tiles: byte lo)
-    const int mask_lo = (slow && !QFA_TRACKED_LOADS)
-                            ? 4 * (lo >> 2) + min(3, 16 * tl + lo - max(0, min(16 * tl + 4 * (lo >> 2), Npix - 4))) : lo;
+    // where the mask byte of the lane's pixel of tile j sits inside a slot's staged bytes: half, then byte of the half
+    int mask_pos[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int pl = TPW * lo + j, h = pl >> 4, pi = pl & 15;
+        mask_pos[j] = h * 256 + ((slow && !QFA_TRACKED_LOADS) ? 4 * (pi >> 2) + min(3, PXW * wt + pl - mask_start(h, pi >> 2)) : pi);
+    }
 
     // ---- the state parts: a contiguous run of 1-KiB pieces per wave.  A request costs the issuing wave ~80 - 100 cycles, and
     // the waves with a blue tile are the critical path of a step (stage 2 of a blue group is 1 200 cycles against 800): the
@@ -305,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #pragma unroll
         for (int w = 0; w < GT::NW; ++w) {
             const int tw = pb + gp.PB * w;
-            const bool d = !(tw < gp.T16 && 16 * tw < Nb);
+            const bool d = !(tw < gp.T16 && PXW * tw < Nb);
             if (w < wv8 && d) ++rk;
             if (d) ++nd;
         }
@@ -315,12 +374,12 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const int s1_q = GT::S1_PCS / nduty, s1_r = GT::S1_PCS % nduty, z_q = GT::Z_PCS / nduty, z_r = GT::Z_PCS % nduty;
     const int s1_first = drank * s1_q + min(drank, s1_r), z_first = drank * z_q + min(drank, z_r);
     const int s1_req = duty ? s1_q + (drank < s1_r ? 1 : 0) : 0, z_req = duty ? z_q + (drank < z_r ? 1 : 0) : 0;     // <= 4, <= 7
-    auto issue_S1 = [&](int t) {
+    auto issue_S1 = [&](int t) __attribute__((always_inline)) {
         const unsigned char *src = uniform_ptr(PST + (size_t)(g0 + t) * GT::STATE_B + s1_first * 1024);
         const unsigned dst = wave_uniform(lds_addr(lds + GT::L_S1 + (t & 1) * GT::S1P_B + s1_first * 1024));
         for (int j = 0; j < s1_req; ++j) glds16a(src + 1024 * j, (unsigned)lane * 16u, dst + 1024 * j);
     };
-    auto issue_Z = [&](int t) {
+    auto issue_Z = [&](int t) __attribute__((always_inline)) {
         const unsigned char *src = uniform_ptr(PST + (size_t)(g0 + t) * GT::STATE_B + GT::S1P_B + z_first * 1024);
         const unsigned dst = wave_uniform(lds_addr(lds + GT::L_Z + (t & 1) * GT::ZP_B + z_first * 1024));
         for (int j = 0; j < z_req; ++j) glds16a(src + 1024 * j, (unsigned)lane * 16u, dst + 1024 * j);
@@ -334,25 +393,28 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         unsigned dst;
         int cnt;
     };
-    auto part_S1 = [&](int t) {          // (t >= n: nothing to issue)
+    auto part_S1 = [&](int t) __attribute__((always_inline)) {          // (t >= n: nothing to issue)
         return Part{uniform_ptr(PST + (size_t)(g0 + min(t, n - 1)) * GT::STATE_B + s1_first * 1024),
                     (unsigned)wave_uniform(lds_addr(lds + GT::L_S1 + (t & 1) * GT::S1P_B + s1_first * 1024)), t < n ? s1_req : 0};
     };
-    auto part_Z = [&](int t) {
+    auto part_Z = [&](int t) __attribute__((always_inline)) {
         return Part{uniform_ptr(PST + (size_t)(g0 + min(t, n - 1)) * GT::STATE_B + GT::S1P_B + z_first * 1024),
                     (unsigned)wave_uniform(lds_addr(lds + GT::L_Z + (t & 1) * GT::ZP_B + z_first * 1024)), t < n ? z_req : 0};
     };
     // (all pieces of a part as ONE run behind one write of M0 at the first slot: no different, tools/ab_pass2.sh)
-    auto piece = [&](const Part &pt, int j) {
+    auto piece = [&](const Part &pt, int j) __attribute__((always_inline)) {
         if (j < pt.cnt) glds16a_nc(pt.src + 1024 * j, (unsigned)lane * 16u, pt.dst + 1024 * j);
     };
 
-    // ---- stage 1 of group t (its results wait in afy / aq for stage 2, one half-step later)
-    f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
-    auto stage1 = [&](int t, const Part &pt) {
+    // ---- stage 1 of group t (its results wait in afy / aq for stage 2, one half-step later); the operands of a K block are
+    // read once for the wave's TPW tiles
+    f32x4 afy[TPW], aq[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) afy[j] = aq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage1 = [&](int t, const Part &pt) __attribute__((always_inline)) {
         const unsigned char *sp = lds + GT::L_S1 + (t & 1) * GT::S1P_B + lane * 16;
-        afy = f32x4{0.f, 0.f, 0.f, 0.f};
-        aq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) afy[j] = aq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x4 aop[2][3];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) aop[0][pc] = *reinterpret_cast<const u32x4 *>(sp + pc * 1024);
@@ -365,30 +427,50 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             }
             piece(pt, ks);
             const u32x4 &ah = aop[ks & 1][0], &am = aop[ks & 1][1], &al = aop[ks & 1][2];
-            if (ks < GT::NKQ) aq = xdl6(ah, am, al, IBh[ks], IBm[ks], IBl[ks], aq);
-            else afy = xdl6(ah, am, al, IBh[GT::NKQ - 1], IBm[GT::NKQ - 1], IBl[GT::NKQ - 1], afy);     // the y block
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (ks < GT::NKQ) aq[j] = xdl6(ah, am, al, IBh[j][ks], IBm[j][ks], IBl[j][ks], aq[j]);
+                else afy[j] = xdl6(ah, am, al, IBh[j][GT::NKQ - 1], IBm[j][GT::NKQ - 1], IBl[j][GT::NKQ - 1], afy[j]);     // the y block
+            }
         }
         GTS(5)
     };
-    // ---- the lane's four elements of group t out of the staging buffer (spectra 4 g + r at pixel lo); stage 2 pins sigma and
-    // the mask behind its wait: left to itself hipcc reads sigma under a branch on the mask, one LDS round trip after the
-    // other (3 600 cycles for stage 2 of a blue group, tools/gt_stamps.sh).  (Volatile reads wait one by one: 2 200 cycles.
-    // Issued a stage ahead, in front of the MFMAs of stage 1, they made stage 1 2 400 cycles long instead of 1 100.)
-    float dv[4] = {0.f, 0.f, 0.f, 0.f}, sgv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned mk[4] = {0u, 0u, 0u, 0u};
-    auto take = [&](int t) {
+    // ---- the lane's 4 TPW elements of group t out of the staging buffer (spectra 4 g + r at the lane's pixels); stage 2 pins
+    // sigma and the mask behind its wait: left to itself hipcc reads sigma under a branch on the mask, one LDS round trip after
+    // the other (3 600 cycles for stage 2 of a blue group, tools/gt_stamps.sh).  (Volatile reads wait one by one: 2 200
+    // cycles.  Issued a stage ahead, in front of the MFMAs of stage 1, they made stage 1 2 400 cycles long instead of 1 100.)
+    float dv[TPW][4], sgv[TPW][4], zv[TPW][4];
+    unsigned mk[TPW][4];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dv[j][r] = sgv[j][r] = zv[j][r] = 0.f; mk[j][r] = 0u; }
+    auto take = [&](int t) __attribute__((always_inline)) {
         const unsigned char *sb = stg + (t & 1) * GT::STG_B;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = (4 * g + r) ^ (g & 1);
-            dv[r] = *reinterpret_cast<const float *>(sb + (q * 16 + lo) * 4);
-            sgv[r] = *reinterpret_cast<const float *>(sb + GT::STG_ARR + (q * 16 + lo) * 4);
-            if (!ZF && blueTile) zv[r] = *reinterpret_cast<const float *>(sb + 2 * GT::STG_ARR + (q * 16 + lo) * 4);
-            mk[r] = sb[GT::STG_MASK + q * 16 + mask_lo];
+            if constexpr (TPW == 1) {
+                dv[0][r] = *reinterpret_cast<const float *>(sb + (q * 16 + lo) * 4);
+                sgv[0][r] = *reinterpret_cast<const float *>(sb + GT::STG_ARR + (q * 16 + lo) * 4);
+                if (!ZF && blueTile) zv[0][r] = *reinterpret_cast<const float *>(sb + 2 * GT::STG_ARR + (q * 16 + lo) * 4);
+            } else {                                       // the lane's two adjacent pixels: one 8-byte read per array
+                typedef float f32x2t __attribute__((ext_vector_type(2)));
+                const f32x2t d2 = *reinterpret_cast<const f32x2t *>(sb + (q * PXW + TPW * lo) * 4);
+                const f32x2t s2 = *reinterpret_cast<const f32x2t *>(sb + GT::STG_ARR + (q * PXW + TPW * lo) * 4);
+                dv[0][r] = d2[0]; dv[TPW - 1][r] = d2[1];
+                sgv[0][r] = s2[0]; sgv[TPW - 1][r] = s2[1];
+                if (!ZF && blueTile) {
+                    const f32x2t z2 = *reinterpret_cast<const f32x2t *>(sb + 2 * GT::STG_ARR + (q * PXW + TPW * lo) * 4);
+                    zv[0][r] = z2[0]; zv[TPW - 1][r] = z2[1];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) mk[j][r] = sb[GT::STG_MASK + q * 16 + mask_pos[j]];
         }
     };
     // ---- stage 2 of group t
-    auto stage2_t = [&](auto blue_tag, int t, const Part &pt) {
+    auto stage2_t = [&](auto blue_tag, int t, const Part &pt) __attribute__((always_inline)) {
         constexpr bool BLUE = decltype(blue_tag)::value;       // (the tile has blue pixels: wave-uniform, one branch per stage)
         const int s0 = 16 * (g0 + t);
         take(t);
@@ -403,10 +485,14 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staging buffer read: it may be overwritten now
 #pragma unroll
-        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(sgv[r]), "+v"(mk[r]));
+        for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(sgv[j][r]), "+v"(mk[j][r]));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sgv[r] = mk[r] ? fabsf(sgv[r]) : -1.f;
+        for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sgv[j][r] = mk[j][r] ? fabsf(sgv[j][r]) : -1.f;
         GTS(6)
         if (t + 2 < n) stage_spectra(t + 2, t & 1);
         piece(pt, 0);
@@ -415,62 +501,67 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         GTS(2)
         float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
 #pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool wv_ = inb & (s0 + 4 * g + r < B) & (__float_as_int(sgv[r]) >= 0);
-            const float dd = wv_ ? dv[r] : 0.f;
-            const float sg = sgv[r];
+            const bool wv_ = inb[j] & (s0 + 4 * g + r < B) & (__float_as_int(sgv[j][r]) >= 0);
+            const float dd = wv_ ? dv[j][r] : 0.f;
+            const float sg = sgv[j][r];
             if (BLUE) {
                 float l2, pw, Ab, re;
                 if (ZF) {                                                                         // qfa_common.h, ZFac
-                    l2 = zqz[r] + l2i;
-                    pw = zqy[r] * pwi;
-                    Ab = fast_exp2(fmaf(zqx[r], ti, k.offp));                                    // QFA/model.py:125
+                    l2 = zqz[r] + l2i[j];
+                    pw = zqy[r] * pwi[j];
+                    Ab = fast_exp2(fmaf(zqx[r], ti[j], k.offp));                                  // QFA/model.py:125
                     re = k.omc0 - fast_exp2(k.k1 * pw);                                           // QFA/utils.py:91
                 } else {
-                    l2 = fast_log2(1.0f + zv[r]);
+                    l2 = fast_log2(1.0f + zv[j][r]);
                     pw = fast_exp2(k.beta * l2);
                     const float tauv = k.t_amp * fast_exp2(k.t_expo * (l2 + k.t_lscale)) + k.t_off;   // QFA/utils.py:105-141
                     Ab = fast_exp2(-tauv * QFA_LOG2E);                                            // QFA/model.py:125
                     re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);                       // QFA/utils.py:91
                 }
-                if (HASA) Ab = bt.A_blue[(size_t)min(s0 + 4 * g + r, B - 1) * Nb + (unsigned)min(px, Nb - 1)];   // custom tau callable
-                const float Av = blue ? Ab : 1.f;
-                const float zd = blue ? re * re : 0.f;
+                if (HASA) Ab = bt.A_blue[(size_t)min(s0 + 4 * g + r, B - 1) * Nb + (unsigned)min(px[j], Nb - 1)];   // custom tau callable
+                const float Av = blue[j] ? Ab : 1.f;
+                const float zd = blue[j] ? re * re : 0.f;
                 const float A2 = Av * Av;
-                const float D = A2 * Psi + om * zd + sg * sg;
+                const float D = A2 * Psi[j] + om[j] * zd + sg * sg;
                 const float wD = wv_ ? fast_rcp(D) : 0.f;
                 const float wDA = wD * Av;
-                const float uu = wD * (dd - Av * afy[r]);                   // (Sigma^-1 delta)_i
-                const float dS = wD - wDA * wDA * aq[r];                    // diag(Sigma^-1)_i
+                const float uu = wD * (dd - Av * afy[j][r]);                // (Sigma^-1 delta)_i
+                const float dS = wD - wDA * wDA * aq[j][r];                 // diag(Sigma^-1)_i
                 const float dG = 0.5f * (dS - uu * uu);                     // QFA/model.py:136,138
-                gPsi += A2 * dG;                                            // :139
-                gOm += dG * zd;                                             // :140
+                gPsi[j] += A2 * dG;                                         // :139
+                gOm[j] += dG * zd;                                          // :140
                 const float root = 1.0f - k.tau0 * pw - k.c0;               // :141
-                const float e = dG * (om * zd) * zd * 2.0f * root;
+                const float e = dG * (om[j] * zd) * zd * 2.0f * root;
                 t_tau0 -= e * pw;                                           // :142
                 t_beta -= e * (k.tau0 * pw * (l2 * QFA_LN2));               // :143
                 t_c0 -= e;                                                  // :144
-                cnt += wv_ ? 1.f : 0.f;
-                betaR[r] = wDA * Av;
-                sA += betaR[r] * Av;
-                gamR[r] = Av * uu;
+                cnt[j] += wv_ ? 1.f : 0.f;
+                betaR[j][r] = wDA * Av;
+                sA[j] += betaR[j][r] * Av;
+                gamR[j][r] = Av * uu;
             } else {                                                        // red tile: A = 1, zd = 0
-                const float D = Psi + sg * sg;
+                const float D = Psi[j] + sg * sg;
                 const float wD = wv_ ? fast_rcp(D) : 0.f;
-                const float uu = wD * (dd - afy[r]);
-                const float dS = wD - wD * wD * aq[r];
-                gPsi += 0.5f * (dS - uu * uu);
-                cnt += wv_ ? 1.f : 0.f;
-                betaR[r] = wD;
-                sA += wD;
-                gamR[r] = uu;
+                const float uu = wD * (dd - afy[j][r]);
+                const float dS = wD - wD * wD * aq[j][r];
+                gPsi[j] += 0.5f * (dS - uu * uu);
+                cnt[j] += wv_ ? 1.f : 0.f;
+                betaR[j][r] = wD;
+                sA[j] += wD;
+                gamR[j][r] = uu;
             }
             if (r & 1) {                                       // two elements at a time: bounds the live temporaries
                 __builtin_amdgcn_sched_barrier(0);
-                piece(pt, r == 1 ? 2 : 4);
-                piece(pt, r == 1 ? 3 : 5);
-                if (r == 3) piece(pt, 6);
+                if (j == TPW - 1) {                            // (the state pieces of this stage: behind the wave's last pairs)
+                    piece(pt, r == 1 ? 2 : 4);
+                    piece(pt, r == 1 ? 3 : 5);
+                    if (r == 3) piece(pt, 6);
+                }
             }
+        }
         }
         if (BLUE) {                                            // float32 inside a group, float64 across the walk
             d_tau0 += (double)t_tau0;
@@ -478,18 +569,23 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             d_beta += (double)t_beta;
         }
     };
-    auto stage2 = [&](int t, const Part &pt) {
+    auto stage2 = [&](int t, const Part &pt) __attribute__((always_inline)) {
         if (blueTile) stage2_t(std::true_type{}, t, pt);
         else stage2_t(std::false_type{}, t, pt);
     };
 
-    // ---- stage 3 of group t: W[a] += Z pieces x the lane's own beta pieces (K = spectrum), the gamma term likewise
-    auto stage3 = [&](int t, const Part &pt) {
+    // ---- stage 3 of group t: W[a] += Z pieces x the lane's own beta pieces (K = spectrum), the gamma term likewise; the Z
+    // operands of a column tile are read once for the wave's TPW tiles
+    auto stage3 = [&](int t, const Part &pt) __attribute__((always_inline)) {
         const unsigned char *zp = lds + GT::L_Z + (t & 1) * GT::ZP_B + lane * 16;
-        unsigned h01, m01, l01, h23, m23, l23;
-        split2(betaR[0], betaR[1], h01, m01, l01);
-        split2(betaR[2], betaR[3], h23, m23, l23);
-        const u32x4 bhl = {h01, h23, l01, l23}, bmm = {m01, m23, m01, m23}, bhh = {h01, h23, h01, h23};
+        u32x4 bhl[TPW], bmm[TPW], bhh[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            unsigned h01, m01, l01, h23, m23, l23;
+            split2(betaR[j][0], betaR[j][1], h01, m01, l01);
+            split2(betaR[j][2], betaR[j][3], h23, m23, l23);
+            bhl[j] = u32x4{h01, h23, l01, l23}; bmm[j] = u32x4{m01, m23, m01, m23}; bhh[j] = u32x4{h01, h23, h01, h23};
+        }
         u32x4 zop[2][2];
         zop[0][0] = *reinterpret_cast<const u32x4 *>(zp);
         zop[0][1] = *reinterpret_cast<const u32x4 *>(zp + 1024);
@@ -498,20 +594,25 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #ifndef QFA_GT_ABL
 #define QFA_GT_ABL 0       // timing experiments (wrong results): 1 = stage 3 without its LDS reads, 2 = stage 3 without its DMA pieces
 #endif
-            if (QFA_GT_ABL & 1) { zop[(a + 1) & 1][0] = IBh[a % GT::NKQ]; zop[(a + 1) & 1][1] = IBm[a % GT::NKQ]; }
+            if (QFA_GT_ABL & 1) { zop[(a + 1) & 1][0] = IBh[0][a % GT::NKQ]; zop[(a + 1) & 1][1] = IBm[0][a % GT::NKQ]; }
             else {
             zop[(a + 1) & 1][0] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048);          // (a + 1 == NWT: the p operands)
             zop[(a + 1) & 1][1] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048 + 1024);
             }
             if (a % 2 == 0 && !(QFA_GT_ABL & 2)) piece(pt, a / 2);
             const u32x4 &Z1 = zop[a & 1][0], &Z2 = zop[a & 1][1];
-            W[a] = xdl(Z2, bhh, xdl(Z2, bmm, xdl(Z1, bhl, W[a])));
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) W[j][a] = xdl(Z2, bhh[j], xdl(Z2, bmm[j], xdl(Z1, bhl[j], W[j][a])));
         }
-        split2(gamR[0], gamR[1], h01, m01, l01);
-        split2(gamR[2], gamR[3], h23, m23, l23);
-        const u32x4 ghl = {h01, h23, l01, l23}, gmm = {m01, m23, m01, m23}, ghh = {h01, h23, h01, h23};
         const u32x4 &P1 = zop[GT::NWT & 1][0], &P2 = zop[GT::NWT & 1][1];
-        gacc = xdl(P2, ghh, xdl(P2, gmm, xdl(P1, ghl, gacc)));                                      // sum_s p_s[b] gamma[s][px]
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            unsigned h01, m01, l01, h23, m23, l23;
+            split2(gamR[j][0], gamR[j][1], h01, m01, l01);
+            split2(gamR[j][2], gamR[j][3], h23, m23, l23);
+            const u32x4 ghl = {h01, h23, l01, l23}, gmm = {m01, m23, m01, m23}, ghh = {h01, h23, h01, h23};
+            gacc[j] = xdl(P2, ghh, xdl(P2, gmm, xdl(P1, ghl, gacc[j])));                            // sum_s p_s[b] gamma[s][px]
+        }
     };
 
     // ---- the walk: ONE barrier per group, and the two waves of a SIMD (w, w + 4) a stage apart in the same rotation:
@@ -588,57 +689,61 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 
     // ---- the end of the walk: F enters, the sums leave
     if (active) {
-        const float *fr = reinterpret_cast<const float *>(tile + GT::OFF_F) + lo * KP;
-        f32x4 acc = gacc;
-        if constexpr (GT::APT == 1) {
 #pragma unroll
-            for (int a4 = 0; a4 < KP / 4; ++a4) {
-                const float4 f4 = *reinterpret_cast<const float4 *>(fr + 4 * a4);
-                const float fa[4] = {f4.x, f4.y, f4.z, f4.w};
+        for (int j = 0; j < TPW; ++j) {
+            const float *fr = reinterpret_cast<const float *>(tile[j] + GT::OFF_F) + lo * KP;
+            f32x4 acc = gacc[j];
+            if constexpr (GT::APT == 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int a4 = 0; a4 < KP / 4; ++a4) {
+                    const float4 f4 = *reinterpret_cast<const float4 *>(fr + 4 * a4);
+                    const float fa[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa[j], W[4 * a4 + j][r], acc[r]);
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa[jj], W[j][4 * a4 + jj][r], acc[r]);
+                }
+            } else {
+                // KP = 8: the lane's rows 4 g + r of tile wtile are (a = 2 wtile + (g >> 1), b = 4 (g & 1) + r); the two a of a tile
+                // sit in the lanes g and g ^ 2, summed across them below
+#pragma unroll
+                for (int wtile = 0; wtile < GT::NWT; ++wtile) {
+                    const float fa = fr[2 * wtile + (g >> 1)];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa, W[j][wtile][r], acc[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], 32);
             }
-        } else {
-            // KP = 8: the lane's rows 4 g + r of tile wt are (a = 2 wt + (g >> 1), b = 4 (g & 1) + r); the two a of a tile sit in
-            // the lanes g and g ^ 2, summed across them below
+            if (inb[j] && (GT::APT == 1 || g < 2)) {
 #pragma unroll
-            for (int wt = 0; wt < GT::NWT; ++wt) {
-                const float fa = fr[2 * wt + (g >> 1)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = fmaf(fa, W[wt][r], acc[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], 32);
-        }
-        if (inb && (GT::APT == 1 || g < 2)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = (GT::APT == 1 ? 4 * g : 4 * (g & 1)) + r;
-                if (b < Nh) {
-                    float *q = accF + (size_t)px * Nh + b;
-                    if (det) *q = acc[r];
-                    else atomicAdd(q, acc[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int b = (GT::APT == 1 ? 4 * g : 4 * (g & 1)) + r;
+                    if (b < Nh) {
+                        float *q = accF + (size_t)px[j] * Nh + b;
+                        if (det) *q = acc[r];
+                        else atomicAdd(q, acc[r]);
+                    }
                 }
             }
-        }
-        // per-pixel sums over the lanes lo + 16 g'
+            // per-pixel sums over the lanes lo + 16 g'
+            float vsA = sA[j], vgPsi = gPsi[j], vgOm = gOm[j], vcnt = cnt[j];
 #pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            sA += __shfl_xor(sA, o);
-            gPsi += __shfl_xor(gPsi, o);
-            gOm += __shfl_xor(gOm, o);
-            cnt += __shfl_xor(cnt, o);
-        }
-        if (inb) {
-            // quantity g of the pixel: sumA | gPsi | gOmega (blue pixels) | cnt
-            const float v = g == 0 ? sA : (g == 1 ? gPsi : (g == 2 ? gOm : cnt));
-            const bool ok = g != 2 || px < Nb;
-            float *q = accA + (g == 0 ? px : (g == 1 ? Npix + px : (g == 2 ? 2 * Npix + px : 2 * Npix + Nb + px)));
-            if (ok) {
-                if (det) *q = v;
-                else atomicAdd(q, v);
+            for (int o = 16; o <= 32; o <<= 1) {
+                vsA += __shfl_xor(vsA, o);
+                vgPsi += __shfl_xor(vgPsi, o);
+                vgOm += __shfl_xor(vgOm, o);
+                vcnt += __shfl_xor(vcnt, o);
+            }
+            if (inb[j]) {
+                // quantity g of the pixel: sumA | gPsi | gOmega (blue pixels) | cnt
+                const float v = g == 0 ? vsA : (g == 1 ? vgPsi : (g == 2 ? vgOm : vcnt));
+                const bool ok = g != 2 || px[j] < Nb;
+                float *q = accA + (g == 0 ? px[j] : (g == 1 ? Npix + px[j] : (g == 2 ? 2 * Npix + px[j] : 2 * Npix + Nb + px[j])));
+                if (ok) {
+                    if (det) *q = v;
+                    else atomicAdd(q, v);
+                }
             }
         }
     }

@@ -10,9 +10,10 @@ size_t qfa_gt_state_bytes(int KP, int B) {
 }
 // tiles, pixel blocks of 8 tiles, ranges of spectra groups: about one workgroup per CU; a multiple of 8 ranges (the
 // workgroups of a range then share an XCD, block = pb R + r) where the batch has the groups for it
-static GtPlan gt_plan(int B, int Npix, int max_ranges) {
+static GtPlan gt_plan(int KP, int B, int Npix, int max_ranges) {
     GtPlan g;
-    g.T16 = (Npix + 15) / 16;
+    const int pxw = KP == 8 ? GTT<8>::PXW : GTT<16>::PXW;       // pixels per wave
+    g.T16 = (Npix + pxw - 1) / pxw;
     g.PB = (g.T16 + 7) / 8;
     const int G = (B + 15) / 16, ncu = cu_count();
     // ranges: the workgroups run one per CU in rounds, so R is chosen for full rounds -- the smallest R whose
@@ -32,12 +33,13 @@ static GtPlan gt_plan(int B, int Npix, int max_ranges) {
     g.R = (G + g.gpr - 1) / g.gpr;
     return g;
 }
-int qfa_gt_items(int B, int Npix, int max_ranges) { return gt_plan(B, Npix, max_ranges).items(); }
+int qfa_gt_items(int KP, int B, int Npix, int max_ranges) { return gt_plan(KP, B, Npix, max_ranges).items(); }
 // the per-tile images (beside the other parameter images of the call) and the per-group operand images (behind the solve)
 void qfa_gt_prep_image(int KP, const qfa_params_t &p, const float *ZP, int Npix, int Nb, int Nh, unsigned char *PGT, hipStream_t st) {
     const float4 *zp = reinterpret_cast<const float4 *>(ZP);
-    if (KP == 8) k_prep_pgt<8><<<(Npix + 15) / 16, 256, 0, st>>>(p.F, p.Psi, p.omega, zp, Npix, Nb, Nh, PGT);
-    else k_prep_pgt<16><<<(Npix + 15) / 16, 256, 0, st>>>(p.F, p.Psi, p.omega, zp, Npix, Nb, Nh, PGT);
+    // (one block per 16-pixel tile: TPW per wave tile)
+    if (KP == 8) k_prep_pgt<8><<<(Npix + GTT<8>::PXW - 1) / GTT<8>::PXW * GTT<8>::TPW, 256, 0, st>>>(p.F, p.Psi, p.omega, zp, Npix, Nb, Nh, PGT);
+    else k_prep_pgt<16><<<(Npix + GTT<16>::PXW - 1) / GTT<16>::PXW * GTT<16>::TPW, 256, 0, st>>>(p.F, p.Psi, p.omega, zp, Npix, Nb, Nh, PGT);
 }
 void qfa_gt_prep_state(int KP, const float *SOL, int B, int Nh, unsigned char *PST, hipStream_t st) {
     if (KP == 8) k_prep_pst<8><<<(B + 15) / 16, 256, 0, st>>>(SOL, B, Nh, PST);
@@ -58,7 +60,7 @@ static void gt_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau
 void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int max_ranges, const unsigned char *PGT, const unsigned char *PST, const float *ZS, float *accum,
                    float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st, int *ranges_out) {
-    const GtPlan g = gt_plan(B, Npix, max_ranges);
+    const GtPlan g = gt_plan(KP, B, Npix, max_ranges);
     if (ranges_out) *ranges_out = g.R;
     const float4 *zs = reinterpret_cast<const float4 *>(ZS);
     if (KP == 8) gt_launch<8>(p, b, tau, B, Npix, Nb, Nh, g, PGT, PST, zs, accum, slab, slabS, slab_stride, sc64, st);

@@ -30,13 +30,19 @@ struct GTT {
     static constexpr int Z_B = NWT * 2 * 1024;               // [tile][operand 1, 2][lane (g, lo = row m)][4 dwords]
     static constexpr int ZP_B = Z_B + 2 * 1024;              // + the p operands (gamma term)
     static constexpr int STATE_B = S1P_B + ZP_B;
-    static constexpr int NW = 8;                             // waves = tiles per workgroup
+    static constexpr int NW = 8;                             // waves per workgroup
+    // A wave owns TPW 16-pixel tiles = PXW pixels; tile j holds the pixels PXW wt + TPW lo + j (lo = the tile's column): a
+    // lane's TPW pixels are adjacent, so are the bytes it reads from the staging buffer.  KP = 8: two tiles per wave -- the
+    // image and W of a tile are 24 + 16 registers there, and every operand read, state piece and barrier serves two tiles
+    static constexpr int TPW = KP == 8 ? 2 : 1;
+    static constexpr int PXW = 16 * TPW;
     // a part moves as 1-KiB pieces, contiguous runs of them per wave (k_grads_t decides which waves)
     static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34 (KP = 8: 9, 10)
     static_assert((Z_PCS + 4) / 5 <= 7 && (S1_PCS + 4) / 5 <= 6, "pieces per wave and stage: 7 slots in stage 2, 8 in stage 3, 6 in stage 1");
     // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
     // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
-    static constexpr int STG_ARR = 1024, STG_MASK = 3 * STG_ARR, STG_B = 3 * STG_ARR + 256;
+    // (TPW = 2: [16 slots][32 px] float x 3, mask bytes as two halves [2][16 slots][16])
+    static constexpr int STG_ARR = 1024 * TPW, STG_MASK = 3 * STG_ARR, STG_B = 3 * STG_ARR + 256 * TPW;
     static constexpr int L_S1 = 0;                           // [2][S1P_B]
     static constexpr int L_Z = L_S1 + 2 * S1P_B;             // [2][ZP_B]
     static constexpr int L_STG = L_Z + 2 * ZP_B;             // [NW][2][STG_B]

@@ -21,7 +21,7 @@ void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
 // the pixel-resident form of the all-XDL pass 2 (qfa_grads_t.h, built in qfa_gx.hip; N_h = 9..16): QFA_F_PASS2_PIXRES
 struct GtPlan;
 size_t qfa_gt_state_bytes(int KP, int B);
-int qfa_gt_items(int B, int Npix, int max_ranges);
+int qfa_gt_items(int KP, int B, int Npix, int max_ranges);
 void qfa_gt_prep_image(int KP, const qfa_params_t &p, const float *ZP, int Npix, int Nb, int Nh, unsigned char *PGT, hipStream_t st);
 void qfa_gt_prep_state(int KP, const float *SOL, int B, int Nh, unsigned char *PST, hipStream_t st);
 void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
@@ -200,9 +200,10 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
 //   k_grads_t once the batch gives every workgroup a walk long enough to pay for its prologue and epilogue:
 //     N_h = 9..16 from 96 spectra per CU (24 576) on: N_pix = 4000: 0.146 / 0.166 at 1 000 spectra, 0.42 / 0.44 at 8 000,
 //       1.43 / 1.35 at 32 000, 4.31 / 3.98 at 100 000 (k_grads_x / k_grads_t); N_pix = 640: 0.161 / 0.183 at 8 000, 1.085 / 0.971 at 100 000;
-//     N_h <= 8 from 96 spectra per CU on, and from 36 per CU (9 216) on for 1024 <= N_pix <= 4096: N_pix = 2000: 0.192 / 0.195 at
-//       8 000, 0.281 / 0.234 at 10 000, 0.522 / 0.432 at 24 000, 1.21 / 0.95 at 64 000; N_pix = 640: 0.116 / 0.141 at 8 000,
-//       0.274 / 0.260 at 32 000, 0.83 / 0.62 at 100 000; N_pix = 9243: 0.635 / 0.700 at 8 000, 1.78 / 1.79 at 24 000, 3.02 / 2.88 at 40 000.
+//     N_h <= 8 (a wave owns two 16-pixel tiles there) from 96 spectra per CU on, and from 36 per CU (9 216) on for N_pix >= 1024:
+//       N_pix = 2000: 0.191 / 0.187 at 8 000, 0.278 / 0.215 at 10 000, 0.530 / 0.389 at 24 000, 1.21 / 0.85 at 64 000;
+//       N_pix = 9243: 0.635 / 0.672 at 8 000, 1.83 / 1.63 at 24 000, 2.85 / 2.45 at 40 000; N_pix = 640: 0.116 / 0.141 at 8 000,
+//       0.274 / 0.260 at 32 000, 0.83 / 0.62 at 100 000 (k_grads_x<8> / k_grads_t<8>).
 // QFA_F_PASS2_F32 / QFA_F_PASS2_XDL / QFA_F_PASS2_PIXRES in the call's `flags` force one form (A/B timing and the cross-checks of
 // the forms in tests/).
 inline bool pass2_use_xdl(int KP, int B, unsigned flags) {
@@ -216,7 +217,7 @@ inline bool pass2_use_pixres(int KP, int B, int Npix, unsigned flags) {
     if (flags & QFA_F_PASS2_XDL) return false;
     const int ncu = cu_count();
     if (B >= 96 * ncu) return true;
-    return KP == 8 && B >= 36 * ncu && Npix >= 1024 && Npix <= 4096;
+    return KP == 8 && B >= 36 * ncu && Npix >= 1024;
 }
 
 // launch errors of the calls just made; with QFA_F_SYNC also the asynchronous ones (the stream is drained first)
@@ -298,7 +299,7 @@ struct DetLayout {
 inline DetLayout det_layout(int B, int Npix, int Nb, int Nh) {
     const Layout L = make_layout(B, Npix, Nh);
     size_t items = (size_t)(L.wp2.items() > L.wp2x.items() ? L.wp2.items() : L.wp2x.items());
-    if (L.KP == 16 || L.KP == 8) items = std::max(items, 2 * (size_t)qfa_gt_items(B, Npix, (int)det_rows(B)));   // (8 waves per item there)
+    if (L.KP == 16 || L.KP == 8) items = std::max(items, 2 * (size_t)qfa_gt_items(L.KP, B, Npix, (int)det_rows(B)));   // (8 waves per item there)
     DetLayout D;
     D.NF = det_rows_floats(Npix, Nb, Nh);
     D.stride = det_row_stride(Npix, Nb, Nh);
@@ -370,7 +371,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         qfa_gt_launch(KP, p, b, tau, B, Npix, Nb, Nh, slab ? (int)det_rows(B) : (1 << 30),
                       reinterpret_cast<unsigned char *>(ws + L.oPGX), reinterpret_cast<unsigned char *>(ws + L.oPST),
                       reinterpret_cast<const float *>(zt.ZS), accum, slab, slabS, (int)D.stride, sc64, st, &ranges);
-        if (slab) launch_reduce_slab(slab, D, B, qfa_gt_items(B, Npix, (int)det_rows(B)) * 8, accum, st, ranges);
+        if (slab) launch_reduce_slab(slab, D, B, qfa_gt_items(KP, B, Npix, (int)det_rows(B)) * 8, accum, st, ranges);
         mark(4);
         return hip_status(st, flags);
     }
