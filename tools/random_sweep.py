@@ -19,7 +19,7 @@ bad = 0
 for case in range(ncase):
     nh = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 11, 13, 16, 17, 20, 24, 31, 32]))
     npix = int(rng.integers(40, 1300)) if nh <= 16 else int(rng.integers(40, 700))
-    B = int(rng.choice([1, 2, 5, 15, 16, 17, 33, 63, 64, 65, 100, 130, 200]))
+    B = int(rng.choice([1, 2, 5, 15, 16, 17, 33, 63, 64, 65, 100, 130, 200] + ([300, 513, 1000] if os.environ.get("SWEEP_BIG") else [])))
     wav, nb, nr = synthetic.wavelength_grid(npix)
     p, mu = synthetic.mock_parameters(npix, nb, nh, seed=case)
     b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=1000 + case, masks=bool(rng.integers(0, 2)))
