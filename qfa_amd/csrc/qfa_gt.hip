@@ -34,6 +34,7 @@ static GtPlan gt_plan(int KP, int B, int Npix, int max_ranges) {
     return g;
 }
 int qfa_gt_items(int KP, int B, int Npix, int max_ranges) { return gt_plan(KP, B, Npix, max_ranges).items(); }
+int qfa_gt_ranges(int KP, int B, int Npix, int max_ranges) { return gt_plan(KP, B, Npix, max_ranges).R; }
 // the per-tile images (beside the other parameter images of the call) and the per-group operand images (behind the solve)
 void qfa_gt_prep_image(int KP, const qfa_params_t &p, const float *ZP, int Npix, int Nb, int Nh, unsigned char *PGT, hipStream_t st) {
     const float4 *zp = reinterpret_cast<const float4 *>(ZP);

@@ -22,6 +22,7 @@ void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
 struct GtPlan;
 size_t qfa_gt_state_bytes(int KP, int B);
 int qfa_gt_items(int KP, int B, int Npix, int max_ranges);
+int qfa_gt_ranges(int KP, int B, int Npix, int max_ranges);
 void qfa_gt_prep_image(int KP, const qfa_params_t &p, const float *ZP, int Npix, int Nb, int Nh, unsigned char *PGT, hipStream_t st);
 void qfa_gt_prep_state(int KP, const float *SOL, int B, int Nh, unsigned char *PST, hipStream_t st);
 void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
@@ -104,7 +105,7 @@ struct Layout {
     int spb1;                                          // spectra per block of pass 1's plan (128 for the 8-wave k_moments_x)
     WorkPlan wp2x;                                     // pass 2 on the XDL pipe (k_grads_x: 32-pixel tiles, 1 workgroup per CU)
     WorkPlan wpp;                                      // posterior writer on the XDL pipe (k_predict_x, N_h <= 16)
-    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, oZS, oZP, oPST, total;   // float offsets
+    size_t oPF, oPFT, oPFX, oPGX, oPXI, oMOM, oSOL, oNLL, oNBL, oRED, oBG, oZS, oZP, oPST, oISLAB, total;   // float offsets
     int bg_stride;                                     // beta / gamma hand-over of pass 2 at N_h = 17..32 ([2][Bpad][NpixPad])
 };
 
@@ -155,6 +156,15 @@ Layout make_layout_t(int B, int Npix) {
                                                             // float64 scalar-gradient sums of pass 2 (Scal64)
     L.oPST = 0;                                         // pixel-resident pass 2: the per-group state images (qfa_grads_t.h)
     if constexpr (KP == 8 || KP == 16) L.oPST = take(qfa_gt_state_bytes(KP, B) / 4);
+    // pixel-resident pass 2 without a caller's slab: its per-range sums go through rows of the workspace and the fixed-order
+    // reducer as well (no atomics: the default accumulation of a large batch is bit-reproducible too).  Sized for N_b = N_pix,
+    // N_h = KP: rows | scalar records | float64 partial sums of the reducer
+    L.oISLAB = 0;
+    if constexpr (KP == 8 || KP == 16) {
+        const size_t rows = (size_t)qfa_gt_ranges(KP, B, Npix, 1 << 30), items8 = 8 * (size_t)qfa_gt_items(KP, B, Npix, 1 << 30);
+        const size_t nf = (size_t)Npix * KP + 4 * (size_t)Npix, stride = (nf + 3) / 4 * 4 + 64;
+        L.oISLAB = take(rows * stride + (items8 * 3 * 2 + 8) + 2 * ((rows + 31) / 32) * nf + 16);
+    }
     L.oBG = 0;
     L.bg_stride = round_up(Npix, 32);
     if constexpr (KP == 32) L.oBG = take(2 * (size_t)round_up(B, 64) * L.bg_stride);
@@ -368,10 +378,24 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     mark(3);
     if (pixres) {
         int ranges = 0;
-        qfa_gt_launch(KP, p, b, tau, B, Npix, Nb, Nh, slab ? (int)det_rows(B) : (1 << 30),
-                      reinterpret_cast<unsigned char *>(ws + L.oPGX), reinterpret_cast<unsigned char *>(ws + L.oPST),
-                      reinterpret_cast<const float *>(zt.ZS), accum, slab, slabS, (int)D.stride, sc64, st, &ranges);
-        if (slab) launch_reduce_slab(slab, D, B, qfa_gt_items(KP, B, Npix, (int)det_rows(B)) * 8, accum, st, ranges);
+        // the sums of a range leave as one slab row: the caller's slab (deterministic mode), else rows of the workspace
+        float *rowsb = slab;
+        DetLayout Dr = D;
+        const int maxr = slab ? (int)det_rows(B) : (1 << 30);
+        if (!slab) {
+            const size_t rows = (size_t)qfa_gt_ranges(KP, B, Npix, maxr), items8 = 8 * (size_t)qfa_gt_items(KP, B, Npix, maxr);
+            rowsb = ws + L.oISLAB;
+            Dr.NF = det_rows_floats(Npix, Nb, Nh);
+            Dr.stride = det_row_stride(Npix, Nb, Nh);
+            Dr.oS = (rows * Dr.stride * sizeof(float) + 15) / 16 * 16;
+            Dr.oPart = Dr.oS + (items8 * 3 * sizeof(double) + 15) / 16 * 16;
+            Dr.bytes = 0;
+        }
+        double *rowsS = reinterpret_cast<double *>(reinterpret_cast<char *>(rowsb) + Dr.oS);
+        qfa_gt_launch(KP, p, b, tau, B, Npix, Nb, Nh, maxr, reinterpret_cast<unsigned char *>(ws + L.oPGX),
+                      reinterpret_cast<unsigned char *>(ws + L.oPST), reinterpret_cast<const float *>(zt.ZS), accum, rowsb, rowsS,
+                      (int)Dr.stride, sc64, st, &ranges);
+        launch_reduce_slab(rowsb, Dr, B, qfa_gt_items(KP, B, Npix, maxr) * 8, accum, st, ranges);
         mark(4);
         return hip_status(st, flags);
     }

@@ -649,6 +649,22 @@ def test_deterministic_mode_is_bit_reproducible(dev, npix, nh, B, flags):
             assert rel_l2(a, r) < 5e-5, (name, rel_l2(a, r))
 
 
+@pytest.mark.parametrize("npix,nh,B", [(4000, 16, 30000), (2000, 8, 12000)])
+def test_default_accumulation_of_a_large_batch_is_bit_reproducible(dev, npix, nh, B):
+    """From 96 spectra per CU on (N_h <= 8: 36) pass 2 runs in its pixel-resident form (k_grads_t), whose per-range sums leave
+    through slab rows and the fixed-order reducer even without a caller's slab: no float atomics anywhere in the step, so the
+    DEFAULT mode is bit-reproducible there, like QFA.deterministic = True is at every size."""
+    import torch
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=nh + 3)
+    batch = synthetic.make_batch_torch(p, mu, wav, nb, B, 4321 + nh, dev, masks=True)
+    m = make_model(dev, p, mu)
+    runs = [m.accumulate(*batch).clone() for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    assert torch.isfinite(runs[0]).all()
+
+
 @pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 7, 33), (1000, 12, 130), (1913, 8, 50), (33, 3, 17),
                                        (450, 32, 70), (1000, 20, 130), (31, 17, 5), (2100, 27, 64)])
 def test_predict_writer_xdl_matches_f32_writer(dev, npix, nh, B, monkeypatch):
