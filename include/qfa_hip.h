@@ -130,7 +130,10 @@ int qfa_nll_grad_events_f32(const qfa_params_t *p, const qfa_batch_t *b, const q
  * are added to `accum` with float32 atomics, whose arrival order -- and so the last bits of the sums -- changes
  * from run to run.  With a slab of qfa_det_slab_bytes() bytes every block writes its tile partials to its own
  * row of the slab (plain stores) and a reducer adds the rows to `accum` in block order: two runs on the same
- * inputs (and the same B, which fixes the work plan) are bit-identical.  slab == NULL is qfa_nll_grad_events_f32. */
+ * inputs (and the same B, which fixes the work plan) are bit-identical.  slab == NULL is qfa_nll_grad_events_f32.
+ * (Where pass 2 runs in its pixel-resident form -- from 96 spectra per CU on, 36 at N_h <= 8, or QFA_F_PASS2_PIXRES --
+ * the per-range sums always leave through such rows, inside the workspace when slab == NULL: no float atomics
+ * there in either mode.) */
 size_t qfa_det_slab_bytes(int B, int Npix, int Nb, int Nh);
 int qfa_nll_grad_det_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_tau_t *tau,
                          int B, int Npix, int Nb, int Nh,

@@ -81,6 +81,7 @@ class QFA(object):
         self._dp_checked = False
         # deterministic=True: per-block slab + fixed-order reducer instead of float32 atomics in pass 2
         # (qfa_nll_grad_det_f32): bit-identical sums from run to run, at the price of a (B/64) x accum-sized slab
+        # (8..64 rows where pass 2 is pixel-resident -- large batches; there the default has no atomics either)
         self.deterministic = False
         # kernel-form switches of the *_ex_f32 entry points (_lib.F_*; 0 = defaults): A/B timing, cross-checks in tests/
         self.flags = 0
