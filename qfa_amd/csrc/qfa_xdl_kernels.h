@@ -274,6 +274,15 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
     c = xdl(ah, bm, c);
     return xdl(ah, bh, c);
 }
+#ifndef QFA_P1_PIPE
+#define QFA_P1_PIPE 1          // MFMA phase of pass 1 (N_h <= 16) as an explicit pipeline over the column tiles (mfmas_pipe)
+#endif
+#ifndef QFA_P1_PIPE_RED
+#define QFA_P1_PIPE_RED 1      // groups requested ahead on a red tile (a group = two column tiles, 12 MFMAs) ...
+#endif
+#ifndef QFA_P1_PIPE_BLUE
+#define QFA_P1_PIPE_BLUE 2     // ... and on a blue tile (a group = one column tile, 12 MFMAs)
+#endif
 #ifndef QFA_P1_STAMPS
 #define QFA_P1_STAMPS 0    // diagnostic build (tools/p1_stamps.sh): s_memtime shares of the tile steps of one wave of pass 1
 #endif
@@ -402,8 +411,8 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         };
 
         // ---- phase 1 of a tile: per-element weights on the VALU (QFA/model.py:125-131), split into bf16 pieces
-        auto weights = [&](int tg, const SpecRegsX &cur, const unsigned char *tile, Pieces &w) {
-            const float *pp = reinterpret_cast<const float *>(tile + X::OFF_PSI) + 8 * g;
+        auto weights = [&](int tg, const SpecRegsX &cur, const unsigned char *rows, Pieces &w) {
+            const float *pp = reinterpret_cast<const float *>(rows) + 8 * g;      // the tile's parameter rows (OFF_PSI of its image)
             float psi[8], om[8], muv[8], ti[8], pwi[8];
             if (BLUE && ZF) {
                 const float4 a = *reinterpret_cast<const float4 *>(pp + 96), b = *reinterpret_cast<const float4 *>(pp + 100),
@@ -515,6 +524,81 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             }
         };
 
+        // The same phase for a whole tile in LDS (N_h <= 16) as an explicit software pipeline: the B operand of column
+        // tile t + D - 1 is requested before the MFMAs of column tile t are issued (hipcc's own order asks for a column
+        // tile right in front of its first MFMA: ~100 cycles of LDS latency in the open per column tile, 2 090 cycles for
+        // 960 of XDL work on a red tile), and the requests of the step -- the image tile c + 1 piece by piece, then the
+        // spectra of tile c + 2 -- are issued between the column tiles, in the issue slots the MFMAs leave free.
+        auto mfmas_pipe = [&](const unsigned char *tile, const Pieces &w, bool do_stage, int tg_next, int buf_next,
+                              bool reload, int tg_spec, SpecRegsX &cur) __attribute__((always_inline)) {
+            // column tiles in groups of GS whose MFMA chains alternate (a chain of six on one accumulator issues every
+            // ~19 cycles, two alternating chains every 16): red tiles pair two column tiles, blue tiles the C-side and
+            // the T-side chain of one; PFG groups are requested ahead
+            constexpr int NCT = X::NCT, PS = X::pstr(0), GS = BLUE ? 1 : 2, PFG = BLUE ? QFA_P1_PIPE_BLUE : QFA_P1_PIPE_RED;
+            constexpr int D = GS * (PFG + 1), NG = (NCT + GS - 1) / GS;
+            constexpr int NR = (X::NCHUNK + NW - 1) / NW;                        // DMA requests per wave
+            constexpr int RPG = (NR + NG - 2) / (NG - 1);                        // ... per group
+            const unsigned char *bcol = tile + lane * 16;
+            u32x4 bh[D], bm[D], bl[D];
+            auto rd = [&](int ct) __attribute__((always_inline)) {
+                bh[ct % D] = *reinterpret_cast<const u32x4 *>(bcol + ct * 1024);
+                bm[ct % D] = *reinterpret_cast<const u32x4 *>(bcol + PS + ct * 1024);
+                bl[ct % D] = *reinterpret_cast<const u32x4 *>(bcol + 2 * PS + ct * 1024);
+            };
+            auto acc_of = [&](int t, bool second) -> f32x4 & {
+                return t < C::NFT ? (second ? accb2[t] : accb[t]) : (second ? accT[t - C::NFT] : accC[t - C::NFT]);
+            };
+            // six_terms' order, two chains alternating
+            auto six2 = [&](const u32x4 &ah, const u32x4 &am, const u32x4 &al, int q0, f32x4 &c0, const u32x4 &eh,
+                            const u32x4 &em, const u32x4 &el, int q1, f32x4 &c1) __attribute__((always_inline)) {
+                c0 = xdl(ah, bl[q0], c0); c1 = xdl(eh, bl[q1], c1);
+                c0 = xdl(al, bh[q0], c0); c1 = xdl(el, bh[q1], c1);
+                c0 = xdl(am, bm[q0], c0); c1 = xdl(em, bm[q1], c1);
+                c0 = xdl(am, bh[q0], c0); c1 = xdl(em, bh[q1], c1);
+                c0 = xdl(ah, bm[q0], c0); c1 = xdl(eh, bm[q1], c1);
+                c0 = xdl(ah, bh[q0], c0); c1 = xdl(eh, bh[q1], c1);
+            };
+#pragma unroll
+            for (int t = 0; t < GS * PFG; ++t)
+                if (t < NCT) rd(t);
+            bool spec_done = false;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+                for (int j = 0; j < GS; ++j)
+                    if (GS * (gi + PFG) + j < NCT) rd(GS * (gi + PFG) + j);
+                __builtin_amdgcn_sched_barrier(0);
+                const int t = GS * gi;
+                if (BLUE) {
+                    if (t < C::NFT) six2(w.w3h, w.w3m, w.w3l, t % D, acc_of(t, false), w.w4h, w.w4m, w.w4l, t % D, acc_of(t, true));
+                    else six2(w.w1h, w.w1m, w.w1l, t % D, acc_of(t, false), w.w2h, w.w2m, w.w2l, t % D, acc_of(t, true));
+                } else if (t + 1 < NCT) {
+                    const bool f0 = t < C::NFT, f1 = t + 1 < C::NFT;
+                    six2(f0 ? w.w3h : w.w1h, f0 ? w.w3m : w.w1m, f0 ? w.w3l : w.w1l, t % D, acc_of(t, false),
+                         f1 ? w.w3h : w.w1h, f1 ? w.w3m : w.w1m, f1 ? w.w3l : w.w1l, (t + 1) % D, acc_of(t + 1, false));
+                } else {
+                    f32x4 &c0 = acc_of(t, false);
+                    c0 = t < C::NFT ? xdl6(w.w3h, w.w3m, w.w3l, bh[t % D], bm[t % D], bl[t % D], c0)
+                                    : xdl6(w.w1h, w.w1m, w.w1l, bh[t % D], bm[t % D], bl[t % D], c0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = gi * RPG; i < (gi + 1) * RPG; ++i) {
+                    if (i < NR && do_stage) {
+                        const int ch = wv + NW * i;
+                        if (ch < X::NCHUNK)
+                            glds16a_nc(PFX + (size_t)tg_next * X::TILE_B + ch * 1024, (unsigned)lane * 16u,
+                                       wave_uniform(lds_addr(&lds[buf_next][ch * 1024])));
+                    }
+                }
+                if (!spec_done && (gi + 1) * RPG >= NR) {
+                    spec_done = true;
+                    if (reload) load_spec(tg_spec, cur);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
         // One tile.  Phase 1 consumes the spectra registers of tile c; phase 2 starts the LDS-DMA of image tile
         // c+1 and reloads the same registers with tile c+2 (those loads have the MFMA phase of this step and the
         // whole next step to land, so HBM requests are in flight all the time); phase 3 issues the MFMAs.  The
@@ -534,13 +618,17 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                     w.w2h[q] = w.w2m[q] = w.w2l[q] = __float_as_uint(cur.d1[q]);
                     w.w4h[q] = w.w4m[q] = w.w4l[q] = __float_as_uint(cur.s1[q]);
                 }
-            } else if (active) weights(ta + c, cur, lds[buf], w);
+            } else if (active) weights(ta + c, cur, lds[buf] + X::OFF_PSI, w);
             __builtin_amdgcn_sched_barrier(0);
             P1S(2)
+            const bool reload = active & (c + 2 < n) & !(QFA_P1_ABL & 1);
+            if (QFA_P1_PIPE && KP == 16 && QFA_P1_CT_TERMS == 6 && !QFA_P1_ABL && !QFA_P1_EARLY_DMA) {
+                if (active) mfmas_pipe(lds[buf], w, c + 1 < n, ta + c + 1, buf ^ 1, reload, ta + c + 2, cur);
+                else if (c + 1 < n) stage(ta + c + 1, buf ^ 1);
+            } else {
             if (!QFA_P1_EARLY_DMA && c + 1 < n && !(QFA_P1_ABL & 8)) stage(ta + c + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             P1S(7)
-            const bool reload = active & (c + 2 < n) & !(QFA_P1_ABL & 1);
             if (reload) load_spec(ta + c + 2, cur);
             __builtin_amdgcn_sched_barrier(0);
             P1S(3)
@@ -548,6 +636,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 asm volatile("" ::"v"(w.w1h), "v"(w.w1m), "v"(w.w1l), "v"(w.w3h), "v"(w.w3m), "v"(w.w3l));
                 if (BLUE) asm volatile("" ::"v"(w.w2h), "v"(w.w2m), "v"(w.w2l), "v"(w.w4h), "v"(w.w4m), "v"(w.w4l));
             } else if (active) mfmas(lds[buf], w, std::integral_constant<int, 0>{});
+            }
             P1S(4)
             // retire everything up to and including the DMA: it was issued before the 5 (red: 2 delta, 2 sigma,
             // 1 mask) / 7 (blue: + 2 zabs) spectra loads of this step (the ragged-end path issues more, smaller ones)
@@ -566,7 +655,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         auto step2 = [&](int c, SpecRegsX &cur) {
             Pieces w;
             land<BLUE && !ZF>(cur);
-            if (active) weights(ta + c, cur, lds[0], w);
+            if (active) weights(ta + c, cur, lds[0] + X::OFF_PSI, w);
             __builtin_amdgcn_sched_barrier(0);
             stage_sub(ta + c, std::integral_constant<int, X::NSW - 1>{}, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -602,7 +691,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             // (one weights site and one set of piece registers for both groups)
             if (grpB && active && c > 0) mfmas(lds[pslot], wB, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
-            if (active) weights(ta + c, cur, lds[slot], wB);
+            if (active) weights(ta + c, cur, lds[slot] + X::OFF_PSI, wB);
             __builtin_amdgcn_sched_barrier(0);
             if (reload) load_spec(ta + c + 2, cur);
             __builtin_amdgcn_sched_barrier(0);

@@ -20,4 +20,4 @@ for i, l in enumerate(body):
         if tot < 40: continue
         valu = sum(n for k, n in c.items() if k.startswith('v_') and 'mfma' not in k)
         print(f"loop {a}-{i}: {tot} instrs, mfma {sum(n for k, n in c.items() if 'mfma' in k)}, valu {valu} (v_mov {c['v_mov_b32_e32'] + c['v_mov_b64_e32']}, pk {sum(n for k, n in c.items() if k.startswith('v_pk_'))}, trans {sum(n for k, n in c.items() if k.startswith(('v_exp', 'v_log', 'v_rcp')))}), "
-              f"ds {sum(n for k, n in c.items() if k.startswith('ds_'))}, salu {sum(n for k, n in c.items() if k.startswith('s_') and not k.startswith(('s_waitcnt', 's_nop')))}, waitcnt {c['s_waitcnt']}, nop {c['s_nop']}, vmem {sum(n for k, n in c.items() if k.startswith(('global_', 'scratch_')))}")
+              f"saveexec {sum(n for k, n in c.items() if 'saveexec' in k)}, ds {sum(n for k, n in c.items() if k.startswith('ds_'))}, salu {sum(n for k, n in c.items() if k.startswith('s_') and not k.startswith(('s_waitcnt', 's_nop')))}, waitcnt {c['s_waitcnt']}, nop {c['s_nop']}, vmem {sum(n for k, n in c.items() if k.startswith(('global_', 'scratch_')))}")
