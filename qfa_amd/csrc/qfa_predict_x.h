@@ -139,30 +139,33 @@ __global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void
         }
     };
     auto land_mu = [&]() { asm volatile("" : "+v"(mn0), "+v"(mn1)); };
+    // NP 1-KiB pieces of an image by the four waves: each wave a CONTIGUOUS run behind one write of M0 (waves below NP % 4 one
+    // piece more: (NP - wv + 3) / 4 pieces, the count the waits below assume).  Piece by piece with its own M0 every request
+    // waited until the texture path had accepted the one before (glds16_run, qfa_xdl_kernels.h), and a piece count that is
+    // no multiple of 4 cost a scalar branch per piece.
+    auto move_pieces = [&](auto np_tag, const unsigned char *sbase, const unsigned char *dst) {
+        constexpr int NP = decltype(np_tag)::value, LO = NP / 4, EX = NP % 4;
+        static_assert(LO >= 1, "at least one piece per wave");
+        const int first = wv * LO + min(wv, EX);
+        const unsigned char *src = sbase + first * 1024;
+        const unsigned d = wave_uniform(lds_addr(dst + first * 1024));
+        if (EX && wv < EX) glds16_runs<LO + 1>(src, (unsigned)lane * 16u, d);
+        else glds16_runs<LO>(src, (unsigned)lane * 16u, d);
+    };
     auto get_tile = [&](int c) {
         const unsigned char *src = PXI + (size_t)(t0 + c) * X::TILE_B;
         const unsigned long long a = reinterpret_cast<unsigned long long>(src);
         const unsigned char *sbase = reinterpret_cast<const unsigned char *>(
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32) |
             (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
-#pragma unroll
-        for (int i = 0; i < (X::NCHUNK + 3) / 4; ++i) {
-            const int ch = wv + 4 * i;
-            if (ch < X::NCHUNK)
-                glds16a(sbase + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(lds + (c & 1) * X::TILE_B + ch * 1024)));
-        }
+        move_pieces(std::integral_constant<int, X::NCHUNK>{}, sbase, lds + (c & 1) * X::TILE_B);
     };
     if constexpr (HR) {
         if (n <= 0) return;
         constexpr int NCH = X::S1_HALF / 1024;
         auto get_half = [&](int u) {
             const unsigned char *sbase = uniform_ptr(PXI + (size_t)(t0 + (u >> 1)) * X::TILE_B + (u & 1) * X::S1_HALF);
-#pragma unroll
-            for (int i = 0; i < (NCH + 3) / 4; ++i) {
-                const int ch = wv + 4 * i;
-                if (ch < NCH)
-                    glds16a(sbase + ch * 1024, (unsigned)lane * 16u, wave_uniform(lds_addr(lds + (u & 1) * X::S1_HALF + ch * 1024)));
-            }
+            move_pieces(std::integral_constant<int, NCH>{}, sbase, lds + (u & 1) * X::S1_HALF);
         };
         // Schedule of the requests (round 3).  The eight stores of a tile need an HBM write round trip; in the round-2
         // order the image DMA of the next half-step was issued BEHIND them, and since vmcnt retires in issue order the wait

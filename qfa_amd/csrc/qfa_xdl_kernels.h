@@ -135,6 +135,14 @@ __device__ __forceinline__ void glds16_run(const void *sbase, unsigned voff, uns
                      "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sb), "s"(d) : "memory");
 #endif
 }
+template <int N>      // any number of consecutive pieces: runs of at most five
+__device__ __forceinline__ void glds16_runs(const void *sbase, unsigned voff, unsigned lds_dst) {
+    if constexpr (N <= 5) glds16_run<N>(sbase, voff, lds_dst);
+    else {
+        glds16_run<5>(sbase, voff, lds_dst);
+        glds16_runs<N - 5>(reinterpret_cast<const unsigned char *>(sbase) + 5120, voff, lds_dst + 5120);
+    }
+}
 // s_waitcnt vmcnt(k) for a wave-uniform run-time k (0..63): all but the k youngest vector-memory requests retired
 __device__ __forceinline__ void dma_wait_n(int k) {
 #if QFA_TRACKED_LOADS
@@ -351,14 +359,13 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
     // (sub-image j of tile tg into ring slot buf; NSW = 1: the whole tile)
     auto stage_sub = [&](int tg, auto jtag, int buf) {
         constexpr int J = decltype(jtag)::value;
-        constexpr int NCH = X::sub_bytes(J) / 1024;
-#pragma unroll
-        for (int i = 0; i < (NCH + NW - 1) / NW; ++i) {
-            const int ch = wv + NW * i;
-            if (ch < NCH)
-                glds16a(PFX + (size_t)tg * X::TILE_B + X::sub_off(J) + ch * 1024, (unsigned)lane * 16u,
-                        wave_uniform(lds_addr(&lds[buf][ch * 1024])));
-        }
+        constexpr int NCH = X::sub_bytes(J) / 1024, LO = NCH / NW, EX = NCH % NW;
+        // each wave a contiguous run of pieces behind one write of M0 per five (glds16_run); waves below EX one piece more
+        const int first = wv * LO + min(wv, EX);
+        const unsigned char *src = PFX + (size_t)tg * X::TILE_B + X::sub_off(J) + first * 1024;
+        const unsigned d = wave_uniform(lds_addr(&lds[buf][first * 1024]));
+        if (EX && wv < EX) glds16_runs<LO + 1>(src, (unsigned)lane * 16u, d);
+        else glds16_runs<LO>(src, (unsigned)lane * 16u, d);
     };
     auto stage = [&](int tg, int buf) { stage_sub(tg, std::integral_constant<int, 0>{}, buf); };
 
@@ -584,9 +591,10 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = gi * RPG; i < (gi + 1) * RPG; ++i) {
-                    if (i < NR && do_stage) {
-                        const int ch = wv + NW * i;
-                        if (ch < X::NCHUNK)
+                    if (i < NR && do_stage) {                    // the wave's pieces: the contiguous run stage_sub moves
+                        constexpr int LO = X::NCHUNK / NW, EX = X::NCHUNK % NW;
+                        const int ch = wv * LO + min(wv, EX) + i;
+                        if (i < LO || wv < EX)
                             glds16a_nc(PFX + (size_t)tg_next * X::TILE_B + ch * 1024, (unsigned)lane * 16u,
                                        wave_uniform(lds_addr(&lds[buf_next][ch * 1024])));
                     }
