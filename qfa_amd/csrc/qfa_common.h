@@ -73,6 +73,14 @@ __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m *
 // walk the whole pixel axis (they fill whole rounds of the resident-workgroup slots, one prologue each); the
 // remaining `rem` blocks are cut into `nseg` pixel segments so that the last round is short (tail quantisation)
 // and small batches use every CU.  One launch, items in this order.
+#ifndef QFA_PX_SPW
+#define QFA_PX_SPW 2      // posterior writer at N_h = 9..16: groups of 16 spectra per wave (k_predict_x; the plan's blocks are 64 SPW spectra)
+                          // 2: every B-operand read from LDS feeds two MFMA chains -- 1.04 -> 0.90 ms at c3 (same box); at N_h <= 8
+                          // (18 MFMAs per half) the same change costs 13 %
+#endif
+#ifndef QFA_PX_SPW8
+#define QFA_PX_SPW8 1     // the same at N_h <= 8
+#endif
 struct WorkPlan {
     int full, rem, nseg, seg_tiles;
     __host__ __device__ int items() const { return full + rem * nseg; }

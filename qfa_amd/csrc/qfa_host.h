@@ -143,7 +143,7 @@ Layout make_layout_t(int B, int Npix) {
     L.wpp = WorkPlan{0, 0, 1, 0};
     if constexpr (KP <= 16) {
         L.oPXI = take(qfa_px_image_bytes(KP, L.ntiles32) / 4);
-        L.wpp = plan_work(B, L.ntiles32, 1, 2 * NCU);
+        L.wpp = plan_work(B, L.ntiles32, 1, 2 * NCU, 64 * (KP == 16 ? QFA_PX_SPW : QFA_PX_SPW8));
     }
     // moment records: segment 0 for every row, segments 1.. for the rows of the segmented blocks only
     L.oMOM = take(((size_t)L.Bpad + (size_t)(L.wp1.nseg - 1) * (L.Bpad - (size_t)L.spb1 * (size_t)L.wp1.full)) * C::NMOM);

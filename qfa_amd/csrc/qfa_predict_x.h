@@ -76,8 +76,8 @@ struct __attribute__((packed, aligned(4))) pxf2 { float v[2]; };       // 4-byte
 #ifndef QFA_PX_SINGLE_B
 #define QFA_PX_SINGLE_B 1
 #endif
-template <int KP>
-__global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
+template <int KP, int SPW = 1>          // SPW: groups of 16 spectra per wave (2: every B-operand read serves two MFMA chains)
+__global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
                                                       WorkPlan wp, const unsigned char *__restrict__ PXI,
                                                       const float *__restrict__ SOL, float *__restrict__ cont,
                                                       float *__restrict__ unc) {
@@ -85,21 +85,23 @@ __global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void
     using X = PX<KP>;
     // KP = 16: the ring holds two HALVES of a tile (36 KiB instead of 72: four workgroups per CU instead of two; 118 VGPRs
     // allow it) and a tile step is two half-steps with a barrier each; KP = 8: two whole tiles (36 KiB)
-    constexpr bool HR = KP == 16;
+    constexpr bool HR = KP == 16 && SPW == 1;
     __shared__ __attribute__((aligned(16))) unsigned char lds[HR ? 2 * X::S1_HALF : 2 * X::TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);
     int blk, seg, t0, t1;
     plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
     const int n = t1 - t0;
-    const int s0 = (blk * 4 + wv) * 16;
+    const int s0 = (blk * 4 + wv) * 16 * SPW;
     const bool active = s0 < B;
     const int lo = lane & 15, g = lane >> 4;
-    // A operand: spectrum s0 + lo, k = 32 ks + 8 g + j
+    // A operand: spectrum s0 + lo, k = 32 ks + 8 g + j  (SPW = 2: a second set for the spectra s0 + 16 + lo)
     u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::NKS];
-    {
-        const bool v = active && (s0 + lo) < B;
-        const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+    u32x4 T1h[SPW == 2 ? X::NKS : 1], T1m[SPW == 2 ? X::NKS : 1], T1l[SPW == 2 ? X::NKS : 1];
+#pragma unroll
+    for (int grp = 0; grp < SPW; ++grp) {
+        const bool v = active && (s0 + 16 * grp + lo) < B;
+        const float *sol = SOL + (size_t)(v ? s0 + 16 * grp + lo : 0) * C::NSOL;
 #pragma unroll
         for (int ks = 0; ks < X::NKS; ++ks) {
             float x[8];
@@ -119,11 +121,12 @@ __global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void
             for (int q = 0; q < 4; ++q) {
                 unsigned a, b, c;
                 split2(x[2 * q], x[2 * q + 1], a, b, c);
-                S1h[ks][q] = a; S1m[ks][q] = b; S1l[ks][q] = c;
+                if (grp == 0) { S1h[ks][q] = a; S1m[ks][q] = b; S1l[ks][q] = c; }
+                else { T1h[SPW == 2 ? ks : 0][q] = a; T1m[SPW == 2 ? ks : 0][q] = b; T1l[SPW == 2 ? ks : 0][q] = c; }
             }
         }
     }
-    const bool full_wave = active && s0 + 16 <= B;
+    const bool full_wave = active && s0 + 16 * SPW <= B;
     // mu of the lane's two pixels of tile tg, requested one tile ahead by asm loads IN FRONT of the image DMA of that tile:
     // the counted wait that retires the DMA retires them (as ordinary loads in the loop they made hipcc wait vmcnt(0) in
     // the middle of the step -- for the DMA just issued and the previous tile's stores)
@@ -289,11 +292,11 @@ __global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void
         if (active) {
             const int tg = t0 + c;
             const unsigned char *img = lds + (c & 1) * X::TILE_B;
-            float co[2][4], un[2][4];
+            float co[2][4], un[2][4], co2[2][4], un2[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const unsigned char *bp = img + h * X::S1_HALF + lane * 16;
-                f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+                f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f}, afy2 = {0.f, 0.f, 0.f, 0.f}, aq2 = {0.f, 0.f, 0.f, 0.f};
                 u32x4 bq[2][3];
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
@@ -305,7 +308,15 @@ __global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void
                             bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
                     }
                     const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
-                    if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
+                    if constexpr (SPW == 2) {           // two chains alternating (six_terms' order)
+                        f32x4 &c0 = ks == 0 ? afy : aq, &c1 = ks == 0 ? afy2 : aq2;
+                        c0 = xdl(S1h[ks], bl, c0); c1 = xdl(T1h[ks], bl, c1);
+                        c0 = xdl(S1l[ks], bh, c0); c1 = xdl(T1l[ks], bh, c1);
+                        c0 = xdl(S1m[ks], bm, c0); c1 = xdl(T1m[ks], bm, c1);
+                        c0 = xdl(S1m[ks], bh, c0); c1 = xdl(T1m[ks], bh, c1);
+                        c0 = xdl(S1h[ks], bm, c0); c1 = xdl(T1h[ks], bm, c1);
+                        c0 = xdl(S1h[ks], bh, c0); c1 = xdl(T1h[ks], bh, c1);
+                    } else if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
                     else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
                 }
                 const float m = mc[h];
@@ -313,33 +324,48 @@ __global__ __launch_bounds__(256, KP == 16 ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void
                 for (int r = 0; r < 4; ++r) {
                     co[h][r] = afy[r] + m;
                     un[h][r] = __builtin_amdgcn_sqrtf(aq[r]);
+                    if (SPW == 2) {
+                        co2[h][r] = afy2[r] + m;
+                        un2[h][r] = __builtin_amdgcn_sqrtf(aq2[r]);
+                    }
                 }
             }
             const int px = 32 * tg + 2 * lo;
-            if (full_wave && 32 * tg + 31 < Npix) {          // wave-uniform: exactly eight store instructions
+            if (full_wave && 32 * tg + 31 < Npix) {          // wave-uniform: exactly 8 SPW store instructions
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t o = (size_t)(s0 + 4 * g + r) * Npix + px;
                     *reinterpret_cast<pxf2 *>(cont + o) = pxf2{{co[0][r], co[1][r]}};
                     *reinterpret_cast<pxf2 *>(unc + o) = pxf2{{un[0][r], un[1][r]}};
                 }
+                if (SPW == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const size_t o = (size_t)(s0 + 16 + 4 * g + r) * Npix + px;
+                        *reinterpret_cast<pxf2 *>(cont + o) = pxf2{{co2[0][r], co2[1][r]}};
+                        *reinterpret_cast<pxf2 *>(unc + o) = pxf2{{un2[0][r], un2[1][r]}};
+                    }
+                }
                 counted = true;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s = s0 + 4 * g + r;
+                for (int grp = 0; grp < SPW; ++grp) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (s < B && px + h < Npix) {
-                            cont[(size_t)s * Npix + px + h] = co[h][r];
-                            unc[(size_t)s * Npix + px + h] = un[h][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = s0 + 16 * grp + 4 * g + r;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (s < B && px + h < Npix) {
+                                cont[(size_t)s * Npix + px + h] = grp ? co2[h][r] : co[h][r];
+                                unc[(size_t)s * Npix + px + h] = grp ? un2[h][r] : un[h][r];
+                            }
                         }
                     }
                 }
             }
         }
-        // the image pieces of tile c + 1 were issued before this step's stores: all but the eight stores must be done
-        if (counted) dma_wait<8>();
+        // the image pieces of tile c + 1 were issued before this step's stores: all but the 8 SPW stores must be done
+        if (counted) dma_wait<8 * SPW>();
         else dma_wait<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wg_barrier();

@@ -5,7 +5,7 @@ f = sorted(glob.glob(os.path.join(d, "*", "*kernel_trace.csv")), key=os.path.get
 b = json.load(open(benchjson))
 w = b["warmup"]
 print(f"# {os.path.basename(f)}; bench: steps {b['steps']}, warmup {w}; stage_ms (HIP events, timed steps only): {b['stage_ms']}")
-for key in ("k_moments_x<16, false", "k_moments_x<8, false", "k_moments<", "k_solve<16, false", "k_solve<8, false", "k_solve<32, false", "k_grads_x", "k_grads<"):
+for key in ("k_moments_x<16, false", "k_moments_x<8, false", "k_moments<", "k_solve<16, false", "k_solve<8, false", "k_solve<32, false", "k_grads_t<16, false, false", "k_grads_t<8, false, false", "k_grads_x", "k_grads<"):
     rows = [r for r in csv.DictReader(open(f)) if key in r["Kernel_Name"]]
     if not rows:
         continue
