@@ -73,6 +73,9 @@ struct __attribute__((packed, aligned(4))) pxf2 { float v[2]; };       // 4-byte
 
 // One work item = (block of 64 spectra, range of 32-pixel tiles); SOL as k_solve<KP, true> leaves it
 // ([hmean | hcov' with doubled off-diagonals]).
+#ifndef QFA_PX_ABL
+#define QFA_PX_ABL 0        // timing-only ablations of the whole-tile path: 1 no stores, 2 no MFMAs, 4 no image DMA behind the first
+#endif
 #ifndef QFA_PX_SINGLE_B
 #define QFA_PX_SINGLE_B 1
 #endif
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
         const float mc[2] = {mn0, mn1};
         if (c + 1 < n) {
             load_mu(t0 + c + 1);
-            get_tile(c + 1);
+            if (!(QFA_PX_ABL & 4)) get_tile(c + 1);
         }
         bool counted = false;
         if (active) {
@@ -308,7 +311,9 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
                             bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
                     }
                     const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
-                    if constexpr (SPW == 2) {           // two chains alternating (six_terms' order)
+                    if (QFA_PX_ABL & 2) {
+                        afy[0] += __uint_as_float(bh[0] ^ bm[1] ^ bl[2]);
+                    } else if constexpr (SPW == 2) {    // two chains alternating (six_terms' order)
                         f32x4 &c0 = ks == 0 ? afy : aq, &c1 = ks == 0 ? afy2 : aq2;
                         c0 = xdl(S1h[ks], bl, c0); c1 = xdl(T1h[ks], bl, c1);
                         c0 = xdl(S1l[ks], bh, c0); c1 = xdl(T1l[ks], bh, c1);
@@ -331,7 +336,12 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
                 }
             }
             const int px = 32 * tg + 2 * lo;
-            if (full_wave && 32 * tg + 31 < Npix) {          // wave-uniform: exactly 8 SPW store instructions
+            if (QFA_PX_ABL & 1) {
+                float acc_ = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_ += co[0][r] + co[1][r] + un[0][r] + un[1][r] + (SPW == 2 ? co2[0][r] + co2[1][r] + un2[0][r] + un2[1][r] : 0.f);
+                if (acc_ == 1.2345e-30f) cont[0] = acc_;
+            } else if (full_wave && 32 * tg + 31 < Npix) {          // wave-uniform: exactly 8 SPW store instructions
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t o = (size_t)(s0 + 4 * g + r) * Npix + px;
