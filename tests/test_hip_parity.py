@@ -666,7 +666,8 @@ def test_default_accumulation_of_a_large_batch_is_bit_reproducible(dev, npix, nh
 
 
 @pytest.mark.parametrize("npix,nh,B", [(200, 16, 70), (97, 7, 33), (1000, 12, 130), (1913, 8, 50), (33, 3, 17),
-                                       (450, 32, 70), (1000, 20, 130), (31, 17, 5), (2100, 27, 64)])
+                                       (450, 32, 70), (1000, 20, 130), (31, 17, 5), (2100, 27, 64), (640, 16, 300), (333, 13, 129),
+                                       (4000, 16, 1100)])
 def test_predict_writer_xdl_matches_f32_writer(dev, npix, nh, B, monkeypatch):
     """cont / unc come from k_predict_x (N_h <= 16) / k_predict_x32 (N_h = 17..32): split-bf16 products on the XDL
     pipe; QFA.flags = F_PREDICT_F32 selects the float32-MFMA writer k_predict_out: same values to float32 rounding on ragged
