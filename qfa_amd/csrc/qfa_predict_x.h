@@ -7,7 +7,8 @@
 // (v_mfma_f32_16x16x32_bf16, both operands static: [hmean | hcov'] of 16 spectra in 72 / 36 VGPRs, the tile image
 // [F^T | pair products] staged by LDS-DMA): 36 / 18 MFMAs of 16 cycles per 16 x 16 outputs.
 //   lane (lo = lane & 15, g = lane >> 4) owns pixels 32 t + 2 lo + h (h = 0, 1) of the spectra s0 + 4 g + r: one 8-byte
-//   store per spectrum row and array, 128 contiguous bytes per row and wave instruction.
+//   store per spectrum row and array, 128 contiguous bytes per row and wave instruction.  A wave serves SPW groups of 16
+//   spectra (template argument; the work plan's blocks are 64 SPW spectra, qfa_host.h).
 #pragma once
 #include "qfa_common.h"
 #include "qfa_xdl_kernels.h"
@@ -86,8 +87,11 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
                                                       float *__restrict__ unc) {
     using C = Cfg<KP>;
     using X = PX<KP>;
-    // KP = 16: the ring holds two HALVES of a tile (36 KiB instead of 72: four workgroups per CU instead of two; 118 VGPRs
-    // allow it) and a tile step is two half-steps with a barrier each; KP = 8: two whole tiles (36 KiB)
+    // Shipped forms: KP = 16 with SPW = 2 (QFA_PX_SPW) -- a wave holds the operands of TWO groups of 16 spectra (232 VGPRs), a
+    // workgroup = 128 spectra, two per CU, ring of two whole tiles (72 KiB), one barrier per tile, every B read from LDS feeds
+    // two alternating MFMA chains (c3: 1.04 -> 0.90 ms); KP = 8 with SPW = 1: ring of two whole tiles (36 KiB), four per CU.
+    // KP = 16 with SPW = 1 (the form before): the ring holds two HALVES of a tile (36 KiB instead of 72: four workgroups per
+    // CU instead of two; 118 VGPRs allow it) and a tile step is two half-steps with a barrier each.
     constexpr bool HR = KP == 16 && SPW == 1;
     __shared__ __attribute__((aligned(16))) unsigned char lds[HR ? 2 * X::S1_HALF : 2 * X::TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
