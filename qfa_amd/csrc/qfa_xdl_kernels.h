@@ -371,6 +371,10 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
 
     auto run = [&](auto blue_tag, int ta, int tb) {
         constexpr bool BLUE = decltype(blue_tag)::value;
+        // the T-side moments (T, b2: weights wD A^3, wD A^2 d) feed the gradients only -- the prediction instantiation
+        // (k_solve<KP, true> reads C, b and the scalars) leaves them out: half the MFMAs and two of four splits on a blue tile
+        // (N_h <= 8 keeps them: the tile step is VALU-bound there and without them pass 1 measured 2.5 % slower, DESI shape)
+        constexpr bool TSIDE = BLUE && !(PREDICT && KP >= 16);
         const int n = tb - ta;
         if (n <= 0) return;                                       // block-uniform
 
@@ -471,9 +475,11 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                         d = wv_ ? d : 0.f;
                         const float wDA = wD * A;
                         c2[h2] = wDA * A;
-                        c3[h2] = c2[h2] * A;
                         cb[h2] = wDA * d;
-                        cb2[h2] = c2[h2] * d;
+                        if (TSIDE) {
+                            c3[h2] = c2[h2] * A;
+                            cb2[h2] = c2[h2] * d;
+                        }
                         cblue += (wv_ & blue) ? 1.f : 0.f;
                     } else {                                                 // red side: A = 1, no omega term
                         D = psi[e] + sg * sg;
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = l;
                 split2(cb[0], cb[1], h, m, l);
                 w.w3h[q] = h; w.w3m[q] = m; w.w3l[q] = l;
-                if (BLUE) {
+                if (TSIDE) {
                     split2(c3[0], c3[1], h, m, l);
                     w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = l;
                     split2(cb2[0], cb2[1], h, m, l);
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 if (t >= CT0 && t < CTE) {
                     const u32x4 bh = rdB(0, t), bm = rdB(1, t), bl = rdB(2, t);
                     accb[t] = xdl6(w.w3h, w.w3m, w.w3l, bh, bm, bl, accb[t]);
-                    if (BLUE) accb2[t] = xdl6(w.w4h, w.w4m, w.w4l, bh, bm, bl, accb2[t]);
+                    if (TSIDE) accb2[t] = xdl6(w.w4h, w.w4m, w.w4l, bh, bm, bl, accb2[t]);
                 }
             }
 #pragma unroll
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 if (C::NFT + t >= CT0 && C::NFT + t < CTE) {
                     const u32x4 bh = rdB(0, C::NFT + t), bm = rdB(1, C::NFT + t), bl = rdB(2, C::NFT + t);
                     accC[t] = xdl_ct(w.w1h, w.w1m, w.w1l, bh, bm, bl, accC[t]);
-                    if (BLUE) accT[t] = xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
+                    if (TSIDE) accT[t] = xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
                 }
             }
         };
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             // column tiles in groups of GS whose MFMA chains alternate (a chain of six on one accumulator issues every
             // ~19 cycles, two alternating chains every 16): red tiles pair two column tiles, blue tiles the C-side and
             // the T-side chain of one; PFG groups are requested ahead
-            constexpr int NCT = X::NCT, PS = X::pstr(0), GS = BLUE ? 1 : 2, PFG = BLUE ? QFA_P1_PIPE_BLUE : QFA_P1_PIPE_RED;
+            constexpr int NCT = X::NCT, PS = X::pstr(0), GS = TSIDE ? 1 : 2, PFG = TSIDE ? QFA_P1_PIPE_BLUE : QFA_P1_PIPE_RED;
             constexpr int D = GS * (PFG + 1), NG = (NCT + GS - 1) / GS;
             constexpr int NR = (X::NCHUNK + NW - 1) / NW;                        // DMA requests per wave
             constexpr int RPG = (NR + NG - 2) / (NG - 1);                        // ... per group
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                     if (GS * (gi + PFG) + j < NCT) rd(GS * (gi + PFG) + j);
                 __builtin_amdgcn_sched_barrier(0);
                 const int t = GS * gi;
-                if (BLUE) {
+                if (TSIDE) {
                     if (t < C::NFT) six2(w.w3h, w.w3m, w.w3l, t % D, acc_of(t, false), w.w4h, w.w4m, w.w4l, t % D, acc_of(t, true));
                     else six2(w.w1h, w.w1m, w.w1l, t % D, acc_of(t, false), w.w2h, w.w2m, w.w2l, t % D, acc_of(t, true));
                 } else if (t + 1 < NCT) {
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             P1S(3)
             if (QFA_P1_ABL & 2) {            // timing only: no MFMAs (the pieces stay live)
                 asm volatile("" ::"v"(w.w1h), "v"(w.w1m), "v"(w.w1l), "v"(w.w3h), "v"(w.w3m), "v"(w.w3l));
-                if (BLUE) asm volatile("" ::"v"(w.w2h), "v"(w.w2m), "v"(w.w2l), "v"(w.w4h), "v"(w.w4m), "v"(w.w4l));
+                if (TSIDE) asm volatile("" ::"v"(w.w2h), "v"(w.w2m), "v"(w.w2l), "v"(w.w4h), "v"(w.w4m), "v"(w.w4l));
             } else if (active) mfmas(lds[buf], w, std::integral_constant<int, 0>{});
             }
             P1S(4)
@@ -737,10 +743,13 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         __syncthreads();
     };
     run(std::false_type{}, max(t0, nbt), t1);
+    constexpr bool SKIPT = PREDICT && KP >= 16;
+    if (!SKIPT) {
 #pragma unroll
-    for (int t = 0; t < C::NT; ++t) accT[t] = accC[t];
+        for (int t = 0; t < C::NT; ++t) accT[t] = accC[t];
 #pragma unroll
-    for (int t = 0; t < C::NFT; ++t) accb2[t] = accb[t];
+        for (int t = 0; t < C::NFT; ++t) accb2[t] = accb[t];
+    }
     run(std::true_type{}, t0, min(t1, nbt));
 
 #if QFA_P1_STAMPS
@@ -758,12 +767,12 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 m[16 * t] = accC[t][r];
-                m[C::MOM_T + 16 * t] = accT[t][r];
+                if (!SKIPT) m[C::MOM_T + 16 * t] = accT[t][r];         // (prediction, N_h > 8: T and b2 are neither computed nor read)
             }
 #pragma unroll
             for (int t = 0; t < C::NFT; ++t) {
                 m[C::MOM_B + 16 * t] = accb[t][r];
-                m[C::MOM_B2 + 16 * t] = accb2[t][r];
+                if (!SKIPT) m[C::MOM_B2 + 16 * t] = accb2[t][r];
             }
         }
     }
