@@ -282,6 +282,9 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
     c = xdl(ah, bm, c);
     return xdl(ah, bh, c);
 }
+#ifndef QFA_P1_SKIPT_KP
+#define QFA_P1_SKIPT_KP 16     // prediction leaves out the T-side moments from this KP on (8: measured equal to 2.5 % slower, with or without an occupancy cap)
+#endif
 #ifndef QFA_P1_PIPE
 #define QFA_P1_PIPE 1          // MFMA phase of pass 1 (N_h <= 16) as an explicit pipeline over the column tiles (mfmas_pipe)
 #endif
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         // the T-side moments (T, b2: weights wD A^3, wD A^2 d) feed the gradients only -- the prediction instantiation
         // (k_solve<KP, true> reads C, b and the scalars) leaves them out: half the MFMAs and two of four splits on a blue tile
         // (N_h <= 8 keeps them: the tile step is VALU-bound there and without them pass 1 measured 2.5 % slower, DESI shape)
-        constexpr bool TSIDE = BLUE && !(PREDICT && KP >= 16);
+        constexpr bool TSIDE = BLUE && !(PREDICT && KP >= QFA_P1_SKIPT_KP);
         const int n = tb - ta;
         if (n <= 0) return;                                       // block-uniform
 
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         __syncthreads();
     };
     run(std::false_type{}, max(t0, nbt), t1);
-    constexpr bool SKIPT = PREDICT && KP >= 16;
+    constexpr bool SKIPT = PREDICT && KP >= QFA_P1_SKIPT_KP;
     if (!SKIPT) {
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) accT[t] = accC[t];
