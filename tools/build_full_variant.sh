@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../qfa_amd/csrc"
 name=$1; shift
 B="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-math-errno -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
-/opt/rocm/bin/hipcc $B "$@" -c qfa_capi.hip -o /tmp/qfa_capi_$name.o &
+/opt/rocm/bin/hipcc $B -fno-slp-vectorize "$@" -c qfa_capi.hip -o /tmp/qfa_capi_$name.o &
 /opt/rocm/bin/hipcc $B -mllvm -amdgpu-sched-strategy=iterative-maxocc "$@" -c qfa_gx.hip -o /tmp/qfa_gx_$name.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/qfa_capi_$name.o build/qfa_k32.o build/qfa_gt.o /tmp/qfa_gx_$name.o -o ../libqfa_$name.so
