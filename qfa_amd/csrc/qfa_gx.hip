@@ -70,7 +70,10 @@ void qfa_px_launch(int KP, const float *F, const float *mu, int B, int Npix, int
                    unsigned char *PXI, const float *SOL, float *cont, float *unc, hipStream_t st) {
     if (KP == 8) {
         k_prep_px<8><<<ntiles32, 256, 0, st>>>(F, Npix, Nh, PXI);
-        k_predict_x<8, QFA_PX_SPW8><<<wp.items(), 256, 0, st>>>(mu, B, Npix, ntiles32, wp, PXI, SOL, cont, unc);
+        if (QFA_PX_SPW8 == 1 && px_realign(KP, Npix, cont, unc))
+            k_predict_x<8, 1, true><<<wp.items(), 256, 0, st>>>(mu, B, Npix, ntiles32, wp, PXI, SOL, cont, unc);
+        else
+            k_predict_x<8, QFA_PX_SPW8><<<wp.items(), 256, 0, st>>>(mu, B, Npix, ntiles32, wp, PXI, SOL, cont, unc);
     } else {
         k_prep_px<16><<<ntiles32, 256, 0, st>>>(F, Npix, Nh, PXI);
         k_predict_x<16, QFA_PX_SPW><<<wp.items(), 256, 0, st>>>(mu, B, Npix, ntiles32, wp, PXI, SOL, cont, unc);

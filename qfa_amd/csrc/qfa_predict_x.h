@@ -70,6 +70,9 @@ __global__ __launch_bounds__(256) void k_prep_px(const float *__restrict__ F, in
     }
 }
 
+#ifndef QFA_PX_REALIGN
+#define QFA_PX_REALIGN 1    // N_h <= 8: stores of whole aligned lines when the rows of cont / unc do not start on one
+#endif
 struct __attribute__((packed, aligned(4))) pxf2 { float v[2]; };       // 4-byte aligned 8-byte store
 
 // One work item = (block of 64 spectra, range of 32-pixel tiles); SOL as k_solve<KP, true> leaves it
@@ -80,8 +83,15 @@ struct __attribute__((packed, aligned(4))) pxf2 { float v[2]; };       // 4-byte
 #ifndef QFA_PX_SINGLE_B
 #define QFA_PX_SINGLE_B 1
 #endif
-template <int KP, int SPW = 1>          // SPW: groups of 16 spectra per wave (2: every B-operand read serves two MFMA chains)
-__global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 : 3) : 2) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
+// host side of the re-aligned store path's condition (see k_predict_x): rows that do not start on a 64-byte boundary
+inline bool px_realign(int KP, int Npix, const void *cont, const void *unc) {
+    const size_t ca = reinterpret_cast<size_t>(cont), ua = reinterpret_cast<size_t>(unc);
+    return KP == 8 && QFA_PX_REALIGN && ((ca ^ ua) & 127) == 0 && ((ca & 63) != 0 || (Npix & 15) != 0);
+}
+template <int KP, int SPW = 1, bool RA = false>   // SPW: groups of 16 spectra per wave (2: every B-operand read from LDS feeds two
+                                                  // MFMA chains); RA: re-aligned stores (N_h <= 8; its own instantiation: 156
+                                                  // registers against 92 would cost the aligned shapes their fourth workgroup per CU)
+__global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 : 3) : ((KP == 8 && SPW == 1) ? 4 : 2)) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
                                                       WorkPlan wp, const unsigned char *__restrict__ PXI,
                                                       const float *__restrict__ SOL, float *__restrict__ cont,
                                                       float *__restrict__ unc) {
@@ -288,6 +298,57 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
     dma_wait<0>();
     wg_barrier();
     asm volatile("" ::: "memory");
+    // ---- re-aligned stores (N_h <= 8, one group per wave).  A tile's 32 pixels of a row are 128 bytes that straddle two lines
+    // unless the row starts on a line: with N_pix = 1913 or 9243 (the reference's models) every store instruction writes eight
+    // partial lines, and the writer runs at 2.8-3.4 TB/s where rows of 1920 or 2000 pixels reach 4.1-4.2 (tools/writer_align.py).
+    // Here step t stores, per row, the ALIGNED line that contains the tile's first pixel: pixels 32 t - phi + x, x = 0..31, with
+    // phi = the row's offset into its line in pixels -- the last phi pixels of tile t - 1 (kept in registers) and the first
+    // 32 - phi of tile t.  Lane lo writes x = 2 lo, 2 lo + 1: the values come from the row group's other lanes by two
+    // ds_bpermute (the SOURCE lane picks current or previous tile and which of its two pixels serves a first / second dword:
+    // every value of a lane is consumed exactly once).  One more step behind the last tile flushes the tails.
+    static_assert(!RA || (KP == 8 && SPW == 1), "re-aligned stores: N_h <= 8, one group per wave");
+    const size_t ca = reinterpret_cast<size_t>(cont);
+    constexpr bool realign = RA;                                  // (the host picks the instantiation: px_realign)
+    float cop[2][4], unp[2][4];                                   // the previous tile's values
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cop[0][r] = cop[1][r] = unp[0][r] = unp[1][r] = 0.f;
+    // the line offset of row s0 + 4 g + r in pixels is (phi0 + r N_pix) & 31 (recomputed per use: registers)
+    const int phi0 = (int)(((ca >> 2) + (size_t)(s0 + 4 * g) * (size_t)Npix) & 31);
+    const int Pbeg = 32 * t0, Pend = min(32 * t1, Npix);
+    // returns true when exactly eight 8-byte stores were issued (wave-uniform)
+    auto realign_store = [&](int t, bool have_cur, const float (*co)[4], const float (*un)[4]) {
+        const bool fast = have_cur && full_wave && t > t0 && 32 * t + 32 <= Pend;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ph = (phi0 + r * Npix) & 31, s = s0 + 4 * g + r;
+            const bool odd = ph & 1, c0now = 2 * lo + ph <= 31, c1now = 2 * lo + 1 + ph <= 31;
+            const int L0 = ((2 * lo - ph) & 31) >> 1, L1 = ((2 * lo + 1 - ph) & 31) >> 1;
+            const int P0 = 32 * t - ph + 2 * lo;
+#pragma unroll
+            for (int arr = 0; arr < 2; ++arr) {
+                const float cur0 = arr ? un[0][r] : co[0][r], cur1 = arr ? un[1][r] : co[1][r];
+                const float prv0 = arr ? unp[0][r] : cop[0][r], prv1 = arr ? unp[1][r] : cop[1][r];
+                const float send0 = c0now ? cur0 : prv0, send1 = c1now ? cur1 : prv1;
+                const float slot0 = odd ? send1 : send0, slot1 = odd ? send0 : send1;
+                const float d0 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (16 * g + L0), __float_as_int(slot0)));
+                const float d1 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (16 * g + L1), __float_as_int(slot1)));
+                float *q = (arr ? unc : cont) + ((size_t)s * (size_t)Npix + (size_t)(long)P0);
+                if (fast) *reinterpret_cast<pxf2 *>(q) = pxf2{{d0, d1}};
+                else {
+                    if (s < B && P0 >= Pbeg && P0 < Pend) q[0] = d0;
+                    if (s < B && P0 + 1 >= Pbeg && P0 + 1 < Pend) q[1] = d1;
+                }
+            }
+        }
+        if (have_cur) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cop[0][r] = co[0][r]; cop[1][r] = co[1][r];
+                unp[0][r] = un[0][r]; unp[1][r] = un[1][r];
+            }
+        }
+        return fast;
+    };
     for (int c = 0; c < n; ++c) {
         land_mu();
         const float mc[2] = {mn0, mn1};
@@ -340,7 +401,9 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
                 }
             }
             const int px = 32 * tg + 2 * lo;
-            if (QFA_PX_ABL & 1) {
+            if (RA && realign) {
+                counted = realign_store(tg, true, co, un);
+            } else if (QFA_PX_ABL & 1) {
                 float acc_ = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc_ += co[0][r] + co[1][r] + un[0][r] + un[1][r] + (SPW == 2 ? co2[0][r] + co2[1][r] + un2[0][r] + un2[1][r] : 0.f);
@@ -385,4 +448,5 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
         wg_barrier();
         asm volatile("" ::: "memory");
     }
+    if (RA && realign && active && n > 0) realign_store(t1, false, cop, unp);      // the tails of the last tile's rows
 }

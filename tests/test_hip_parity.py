@@ -692,6 +692,34 @@ def test_predict_writer_xdl_matches_f32_writer(dev, npix, nh, B, monkeypatch):
         assert rel_l2(unc[s], o[4]) < 1e-4
 
 
+@pytest.mark.parametrize("npix,nh,B,off_c,off_u", [(1913, 8, 70, 0, 0), (1913, 8, 70, 1, 33), (333, 5, 129, 7, 7), (1920, 8, 40, 3, 35),
+                                                   (2000, 8, 40, 0, 16), (97, 3, 17, 5, 6), (640, 16, 70, 1, 1)])
+def test_predict_into_views_at_any_alignment(dev, npix, nh, B, off_c, off_u):
+    """The N_h <= 8 writer stores whole aligned lines when the rows of cont / unc do not start on a line (k_predict_x<8, 1, true>:
+    the tail of a row's 128 bytes waits in registers for the next tile, the values reach their lane by ds_bpermute); the choice
+    depends on the ADDRESSES of the output arrays.  Views into a larger buffer at float offsets (off_c, off_u) -- congruent
+    modulo a line or not -- must give exactly the arrays of a fresh allocation, and nothing around them may be touched."""
+    import torch
+    from qfa_amd import synthetic
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=npix + nh)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=9 * npix + nh)
+    m = make_model(dev, p, mu)
+    bt = batch_t(b, dev, "flux")
+    ll, hm, hc, cont, unc = m.predict(*bt)
+    n = B * npix
+    big = torch.full((2 * n + 256,), -7.0, dtype=torch.float32, device=dev)
+    c_v = big[off_c: off_c + n].view(B, npix)
+    u_v = big[n + 64 + off_u: n + 64 + off_u + n].view(B, npix)
+    out = (torch.empty_like(ll), torch.empty_like(hm), torch.empty_like(hc), c_v, u_v)
+    m.predict(*bt, out=out)
+    assert torch.equal(c_v, cont) and torch.equal(u_v, unc)
+    guard = torch.ones_like(big, dtype=torch.bool)
+    guard[off_c: off_c + n] = False
+    guard[n + 64 + off_u: n + 64 + off_u + n] = False
+    assert bool((big[guard] == -7.0).all())
+
+
 def test_g13_desi_model(dev):
     """The reference's DESI model (N_pix = 9243, N_b = 2238, N_h = 8; data/model_parameters_desi.npz) through the HIP path
     against the imported reference's outputs (golden g13): prediction_for_single_spectra with the full mask and with the
