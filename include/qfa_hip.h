@@ -158,7 +158,9 @@ int qfa_finalize_grads_f32(const float *accum, const float *F, int Npix, int Nb,
 
 /* Replaces QFA.prediction_for_single_spectra (reference QFA/model.py:160-180) for a batch:
  * b->delta holds the raw flux.  Outputs: ll (B,), hmean (B,Nh), hcov (B,Nh,Nh), cont (B,Npix),
- * unc (B,Npix). */
+ * unc (B,Npix): contiguous, any 4-byte alignment.  (The writer is fastest when the rows of cont / unc start on
+ * 64-byte boundaries; at N_h <= 8 it stores whole aligned lines for any N_pix as long as cont and unc are
+ * congruent modulo 128 bytes, as two allocations are.) */
 int qfa_predict_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t *b,
                     const qfa_tau_t *tau, int B, int Npix, int Nb, int Nh,
                     float *ll, float *hmean, float *hcov, float *cont, float *unc,
