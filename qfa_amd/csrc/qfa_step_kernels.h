@@ -390,8 +390,11 @@ static __global__ void k_sum_segments(float4 *__restrict__ mom, const float4 *__
 // pivot column inside the lane group (DPP row broadcast at KP = 16, wavefront shuffles otherwise).  The pivots are the squared Cholesky diagonal, so
 // log det C = sum log(pivot) (finite where the reference's float32 det overflows, QFA/utils.py:54).
 // ------------------------------------------------------------------------------------------------
+#ifndef QFA_SOLVE_OCC4
+#define QFA_SOLVE_OCC4 1      // four waves per SIMD at N_h <= 16 (the state-writing instantiation sat at 130 VGPRs: 126 now, no scratch; c3 solve 0.179 -> 0.163 ms)
+#endif
 template <int KP, bool PREDICT, bool STATE = false>
-__global__ __launch_bounds__(256, 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
+__global__ __launch_bounds__(256, (KP <= 16 && QFA_SOLVE_OCC4) ? 4 : 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
                                                float *__restrict__ nll_out, float *__restrict__ nblue_out, int B,
                                                int Nh, float *__restrict__ hmean, float *__restrict__ hcov,
                                                unsigned *__restrict__ ticket = nullptr,
