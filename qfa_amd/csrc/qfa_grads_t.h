@@ -27,6 +27,13 @@
 // ragged tiles (the last tile of a pixel axis that is no multiple of 16, the tile that straddles the end of the blue side in
 // the zabs form) stage 4-byte pieces and wait for everything.
 #pragma once
+#ifndef QFA_GT_SETPRIO
+#define QFA_GT_SETPRIO 2   // s_setprio around the MFMA stages of k_grads_t: the wave of a SIMD that is in stage 3 (or 1) issues ahead of its
+                           // partner's VALU stage -- pass 2 at c3 2.24 -> 2.16 ms, DESI shape 1.23 -> 1.19 (levels 1..3 alike; stage 3 carries it)
+#endif
+#ifndef QFA_GT_PRIO_STAGES
+#define QFA_GT_PRIO_STAGES 3   // bit 0: stage 1, bit 1: stage 3
+#endif
 #include "qfa_common.h"
 #include "qfa_xdl_kernels.h"
 #include "qfa_gt_layout.h"        // GTT, build_state
@@ -412,6 +419,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #pragma unroll
     for (int j = 0; j < TPW; ++j) afy[j] = aq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto stage1 = [&](int t, const Part &pt) __attribute__((always_inline)) {
+        if constexpr (QFA_GT_SETPRIO != 0 && (QFA_GT_PRIO_STAGES & 1) != 0) __builtin_amdgcn_s_setprio(QFA_GT_SETPRIO);
         const unsigned char *sp = lds + GT::L_S1 + (t & 1) * GT::S1P_B + lane * 16;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) afy[j] = aq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -434,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             }
         }
         GTS(5)
+        if constexpr (QFA_GT_SETPRIO != 0 && (QFA_GT_PRIO_STAGES & 1) != 0) __builtin_amdgcn_s_setprio(0);
     };
     // ---- the lane's 4 TPW elements of group t out of the staging buffer (spectra 4 g + r at the lane's pixels); stage 2 pins
     // sigma and the mask behind its wait: left to itself hipcc reads sigma under a branch on the mask, one LDS round trip after
@@ -577,6 +586,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     // ---- stage 3 of group t: W[a] += Z pieces x the lane's own beta pieces (K = spectrum), the gamma term likewise; the Z
     // operands of a column tile are read once for the wave's TPW tiles
     auto stage3 = [&](int t, const Part &pt) __attribute__((always_inline)) {
+        if constexpr (QFA_GT_SETPRIO != 0 && (QFA_GT_PRIO_STAGES & 2) != 0) __builtin_amdgcn_s_setprio(QFA_GT_SETPRIO);
         const unsigned char *zp = lds + GT::L_Z + (t & 1) * GT::ZP_B + lane * 16;
         u32x4 bhl[TPW], bmm[TPW], bhh[TPW];
 #pragma unroll
@@ -613,6 +623,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             const u32x4 ghl = {h01, h23, l01, l23}, gmm = {m01, m23, m01, m23}, ghh = {h01, h23, h01, h23};
             gacc[j] = xdl(P2, ghh, xdl(P2, gmm, xdl(P1, ghl, gacc[j])));                            // sum_s p_s[b] gamma[s][px]
         }
+        if constexpr (QFA_GT_SETPRIO != 0 && (QFA_GT_PRIO_STAGES & 2) != 0) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- the walk: ONE barrier per group, and the two waves of a SIMD (w, w + 4) a stage apart in the same rotation:
