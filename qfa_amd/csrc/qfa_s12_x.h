@@ -679,6 +679,9 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
 // beta-scaling reads) and the two F pieces (1 KiB each).  A wave's queue holds those four requests per tile and its one
 // flush request; the wait at the start of a tile leaves the ten youngest in flight.
 // ------------------------------------------------------------------------------------------------
+#ifndef QFA_S3_SETPRIO
+#define QFA_S3_SETPRIO 2     // s_setprio around the products of a tile in k_grads_s3 (c5 pass 2 3.11 / 3.18 -> 3.08 / 3.14 ms, same box)
+#endif
 #ifndef QFA_S3_ABL
 #define QFA_S3_ABL 0         // timing-only ablations of k_grads_s3: 1 no flush, 2 no input DMA, 4 no beta-scaled products (gamma term only)
 #endif
@@ -787,6 +790,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
                         Fm = *reinterpret_cast<const u32x4 *>(in + 3072 + lane * 16);
 
             float *part = ldspart[pbuf][wv];
+            if constexpr (QFA_S3_SETPRIO != 0) __builtin_amdgcn_s_setprio(QFA_S3_SETPRIO);
             unsigned h0, m0, l0, h1, m1, l1;
             split2(gam[(4 * g + 0) * 16 + lo], gam[(4 * g + 1) * 16 + lo], h0, m0, l0);
             split2(gam[(4 * g + 2) * 16 + lo], gam[(4 * g + 3) * 16 + lo], h1, m1, l1);
@@ -807,6 +811,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = acc[rr];
+            if constexpr (QFA_S3_SETPRIO != 0) __builtin_amdgcn_s_setprio(0);
         }
         // The wave's inputs of tile c + 1 must have landed before it goes round; behind them in its queue are the
         // flush of tile c - 1 and the requests of tile c + 2, which stay in flight.
