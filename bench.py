@@ -405,7 +405,7 @@ def main():
         # ... and pass2_use_pixres: the pixel-resident form (k_grads_t) from 96 spectra per CU on (N_h <= 8, N_pix >= 1024: 36)
         auto_t = B >= 96 * ncu or (nh <= 8 and B >= 36 * ncu and npix >= 1024)
         pixres = xdl_form and npix >= 16 and not (fl & (0x1 | 0x10 | 0x4)) and (bool(fl & 0x40) or (not (fl & 0x2) and auto_t))
-        p2_name = ("k_grads_t" if pixres else ("k_grads_w" if (fl & 0x10) else "k_grads_x")) if xdl_form else "k_grads"
+        p2_name = ("k_grads_t" if pixres else "k_grads_x") if xdl_form else "k_grads"
     dominant = p2_name if ms_p2 >= ms_p1 else "k_moments_x"
     dom_ms, dom_flops = (ms_p2, f2) if dominant == p2_name else (ms_p1, f1)
     # The contractions are ISSUED as bf16 piece products on the XDL pipe: per spectrum
@@ -415,7 +415,7 @@ def main():
     # `roofline` prices the issued bf16 flops of the dominant kernel against the dense bf16 MFMA peak.
     nk2 = npix * nh * nh
     s3 = 3 if fast else (6 if nh <= 16 else 4)
-    if dominant in ("k_grads_x", "k_grads_t", "k_grads_w", "k_s12_x+2*k_grads_s3"):
+    if dominant in ("k_grads_x", "k_grads_t", "k_s12_x+2*k_grads_s3"):
         xdl_flops = (6 * 1 + s3 * 2) * nk2
     elif dominant == "k_moments_x":
         xdl_flops = 6 * 4 * nk2
@@ -429,7 +429,7 @@ def main():
             tj = json.load(open(tfile))
             if tj.get("B") == B:
                 traffic = tj.get(dominant.replace("k_moments_x", "k_moments") + "_hbm_bytes_per_launch")
-                p2key = {"k_grads_w": "k_grads_x"}.get(p2_name, p2_name)
+                p2key = p2_name
                 parts = [tj.get(kk + "_hbm_bytes_per_launch") for kk in ("k_moments", "k_solve", p2key)]
                 traffic_step = sum(parts) if all(x is not None for x in parts) else None
                 p2z = p2key + "_zfac"

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define QFA_ABI_VERSION 2   /* v2: qfa_batch_t carries the factored-z input form; *_ex_f32 entry points with `flags` */
+#define QFA_ABI_VERSION 3   /* v2: qfa_batch_t carries the factored-z input form; *_ex_f32 entry points with `flags`;
+                             * v3: qfa_batch_t carries the resident, indexed input form (rows, row_stride)          */
 
 #define QFA_E_NULL      (-1)   /* a required pointer is NULL            */
 #define QFA_E_SIZE      (-2)   /* B/Npix/Nb/Nh out of range              */
@@ -69,6 +70,17 @@ typedef struct {
      * zabs.  Not combined with A_blue (a custom tau callable is evaluated on zabs by the caller). */
     const float   *zq1;        /* optional (B,)  */
     const float   *pix_ratio;  /* optional (Nb,) */
+    /* Resident, indexed input form (ABI v3).  The reference materialises every batch on the host
+     * (QFA/dataloader.py:124-138) and shuffles by permuting the whole data set (:154-167).  Here the data set can stay
+     * where it is in HBM: spectrum s of the batch is row  r = rows ? rows[s] : s  of delta / error / mask -- rows
+     * `row_stride` ELEMENTS apart (4 row_stride bytes for delta and error, row_stride bytes for the mask) -- and of zabs
+     * (rows Nb apart) and zq1, so that a batch is B indices into arrays that are built once and a shuffled epoch is one
+     * permutation on the device.  row_stride = 0 means Npix (contiguous rows); a loader that pads its rows to a multiple of
+     * 32 elements (128 bytes) gives every row the alignment the kernels' 128-byte row segments like (N_pix = 1913, 9243:
+     * 4 - 12 % of passes 1 and 2).  Pixels [Npix, row_stride) of a row are never read.  Outputs (nll, ll, hmean, hcov,
+     * cont, unc) are in batch order and contiguous.  Not combined with A_blue. */
+    const int32_t *rows;       /* optional (B,) device array of row indices, each >= 0 */
+    int64_t        row_stride; /* 0 = Npix; else >= Npix */
 } qfa_batch_t;
 
 /* `flags` of the *_ex_f32 entry points (0 = the defaults; A/B timing and the cross-checks in tests/). */
@@ -86,8 +98,8 @@ typedef struct {
                                   * QFA_F_PASS2_* flag the library picks between k_grads_x (small batches) and this form
                                   * (from 96 spectra per CU on; N_h <= 8 and N_pix >= 1024: from 36 per CU on) --
                                   * qfa_host.h, pass2_use_pixres                                                      */
-#define QFA_F_PASS2_WFORM  0x10u /* N_h <= 16: the one-wave-per-SIMD form of the all-XDL pass 2 (k_grads_w: stage 3
-                                    re-associated as a K = spectrum GEMM; same results, slower -- DESIGN.md)    */
+/* (0x10: the one-wave-per-SIMD form k_grads_w of round 3, removed from the library in round 4 -- same results, 5.4 against
+ *  2.15 ms at c3; the measurement is kept in profiles/r3_ablation_pass2.txt) */
 
 int qfa_abi_version(void);
 
@@ -224,27 +236,42 @@ int qfa_omega_func_f32(const float *z, const float *tau0, const float *beta, con
 
 /* Device-side batch builder.  Replaces what Dataloader.next_batch / __init__ do
  * on the host with numpy (reference QFA/dataloader.py:29,102,124-138 and tau_total, QFA/utils.py:174-203):
- * for row r of the batch, spectrum s = idx ? idx[r] : r of the resident (N, Npix) flux/error arrays,
+ * for row r of the batch, spectrum s = idx ? idx[r] : r of the resident flux/error arrays (N rows, row_stride elements
+ * apart; 0 = Npix),
  *   zabs  = (1+zqso) wav_blue / 1215.67 - 1,  delta = flux - mu * exp(-tau_total) (blue) | flux - mu (red),
  *   mask  = (flux != -999) & (error != -999),  error_out = error[s].
- * float64 arithmetic like numpy, outputs rounded to float32 once.  wav0 = wav[0] (host copy). */
+ * float64 arithmetic like numpy, outputs (contiguous, batch order) rounded to float32 once.  wav0 = wav[0] (host copy). */
 int qfa_build_batch_f32(const float *flux, const float *error, const double *zqso, const int *idx,
                         const double *wav, double wav0, const double *mu, int which, int nrow, int Npix,
-                        int Nb, float *delta, float *error_out, float *zabs, uint8_t *mask, void *stream);
+                        int Nb, int64_t row_stride, float *delta, float *error_out, float *zabs, uint8_t *mask,
+                        void *stream);
+
+/* The resident form of a whole data set, built ONCE per loader instead of once per batch (ABI v3; the reference
+ * recomputes delta for every batch, QFA/dataloader.py:135-136, although it depends on mu and tau only): for every
+ * row r < nrow of flux / error (rows row_stride >= Npix elements apart)
+ *   delta[r] = flux - mu * exp(-tau_total) (blue) | flux - mu (red),  mask[r] = (flux != -999) & (error != -999),
+ * written with the SAME row stride (pad pixels: 0 / masked), and zq1[r] = (float)(1 + zqso[r]).  The same arithmetic as
+ * qfa_build_batch_f32: a batch of the resident form -- qfa_batch_t{delta, error, mask, zq1, pix_ratio, rows, row_stride} --
+ * holds bit for bit the numbers the materialised batch of the same rows holds. */
+int qfa_build_resident_f32(const float *flux, const float *error, const double *zqso, const double *wav, double wav0,
+                           const double *mu, int which, int64_t nrow, int Npix, int Nb, int64_t row_stride,
+                           float *delta, uint8_t *mask, float *zq1, void *stream);
 
 /* Replaces the continuum-mean estimate of Dataloader.__init__ (reference QFA/dataloader.py:110-112):
  * mu_raw = sum_s flux exp(+tau_total) mask / #(flux != -999); mu_smooth = reflect-padded boxcar of
- * window_len (QFA/utils.py:206-219; may be NULL).  scratch: 2*Npix doubles. */
+ * window_len (QFA/utils.py:206-219; may be NULL).  scratch: 2*Npix doubles.  flux / error rows row_stride elements apart
+ * (0 = Npix). */
 int qfa_mu_estimate_f64(const float *flux, const float *error, const double *zqso, const double *wav,
-                        double wav0, int which, int B, int Npix, int Nb, int window_len, double *scratch,
-                        double *mu_raw, double *mu_smooth, void *stream);
+                        double wav0, int which, int B, int Npix, int Nb, int64_t row_stride, int window_len,
+                        double *scratch, double *mu_raw, double *mu_smooth, void *stream);
 
 /* The two halves of qfa_mu_estimate_f64 for a data-parallel loader (each rank holds a shard of the
  * spectra): qfa_mu_sums_f64 ADDS this shard's per-pixel sums to scratch = [num Npix | den Npix]
  * (caller zeroes it), the caller all-reduces scratch over the ranks, qfa_mu_finish_f64 divides and
  * smooths.  Same arithmetic as the one-call form. */
 int qfa_mu_sums_f64(const float *flux, const float *error, const double *zqso, const double *wav,
-                    double wav0, int which, int B, int Npix, int Nb, double *scratch, void *stream);
+                    double wav0, int which, int B, int Npix, int Nb, int64_t row_stride, double *scratch,
+                    void *stream);
 int qfa_mu_finish_f64(const double *scratch, int Npix, int window_len, double *mu_raw, double *mu_smooth,
                       void *stream);
 

@@ -16,13 +16,13 @@ EXPORTS = (
     "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_nll_grad_det_f32", "qfa_nll_grad_ex_f32", "qfa_predict_ex_f32", "qfa_det_slab_bytes", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_predict_events_f32",
     "qfa_adam_clip_f32",
     "qfa_adam_clip_multi_f32", "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32", "qfa_build_batch_f32", "qfa_mu_estimate_f64",
-    "qfa_mu_sums_f64", "qfa_mu_finish_f64",
+    "qfa_mu_sums_f64", "qfa_mu_finish_f64", "qfa_build_resident_f32",
 )
 
 TAU_IDS = {"becker": 0, "fg": 1, "kamble": 2, "mock": 3}
-ABI_VERSION = 2
+ABI_VERSION = 3
 # `flags` of qfa_nll_grad_ex_f32 / qfa_predict_ex_f32 (include/qfa_hip.h QFA_F_*)
-F_PASS2_F32, F_PASS2_XDL, F_S3_FAST, F_PREDICT_F32, F_PASS2_WFORM, F_SYNC = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+F_PASS2_F32, F_PASS2_XDL, F_S3_FAST, F_PREDICT_F32, F_SYNC = 0x1, 0x2, 0x4, 0x8, 0x20
 F_PASS2_PIXRES = 0x40
 
 
@@ -48,7 +48,9 @@ class AdamMulti(C.Structure):       # qfa_adam_multi_t
 
 
 class Batch(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("delta", "error", "zabs", "mask", "A_blue", "zq1", "pix_ratio")]
+    # qfa_batch_t (ABI v3: rows / row_stride = the resident, indexed input form)
+    _fields_ = [(n, C.c_void_p) for n in ("delta", "error", "zabs", "mask", "A_blue", "zq1", "pix_ratio", "rows")] + \
+               [("row_stride", C.c_int64)]
 
 
 _lib = None
@@ -67,7 +69,7 @@ def lib():
         h = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise QFAHipError(f"cannot load {LIB_PATH}: {e}") from e
-    p, i, f, d, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+    p, i, f, d, sz, i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_int64
     sigs = {
         "qfa_abi_version": (i, []),
         "qfa_tau_model": (i, [i, i, C.POINTER(TauModel)]),
@@ -96,9 +98,10 @@ def lib():
         "qfa_tauhi_f32": (i, [p, p, p, p, sz, p]),
         "qfa_omega_func_f32": (i, [p, p, p, p, p, sz, p]),
         "qfa_woodbury_f32": (i, [p, p, i, i, p, p, p, sz, p]),
-        "qfa_build_batch_f32": (i, [p, p, p, p, p, d, p, i, i, i, i, p, p, p, p, p]),
-        "qfa_mu_estimate_f64": (i, [p, p, p, p, d, i, i, i, i, i, p, p, p, p]),
-        "qfa_mu_sums_f64": (i, [p, p, p, p, d, i, i, i, i, p, p]),
+        "qfa_build_batch_f32": (i, [p, p, p, p, p, d, p, i, i, i, i, i64, p, p, p, p, p]),
+        "qfa_build_resident_f32": (i, [p, p, p, p, d, p, i, i64, i, i, i64, p, p, p, p]),
+        "qfa_mu_estimate_f64": (i, [p, p, p, p, d, i, i, i, i, i64, i, p, p, p, p]),
+        "qfa_mu_sums_f64": (i, [p, p, p, p, d, i, i, i, i, i64, p, p]),
         "qfa_mu_finish_f64": (i, [p, i, i, p, p, p]),
     }
     for name, (res, args) in sigs.items():

@@ -97,15 +97,16 @@ int qfa_nll_grad_ex_f32(const qfa_params_t *p, const qfa_batch_t *b, const qfa_t
                         size_t slab_bytes, unsigned flags, void *stream, void *const *events) {
     if (!p || !b || !tau || !accum || !workspace) return QFA_E_NULL;
     if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
-    if (int e = check_batch(*b, Nb)) return e;
+    if (int e = check_batch(*b, Npix, Nb)) return e;
     if (int e = check_shape(B, Npix, Nb, Nh)) return e;
     if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
     if (slab && slab_bytes < det_slab_bytes(B, Npix, Nb, Nh)) return QFA_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
-    if (kp_for(Nh) == 16) return run_nll_grad<16>(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
-    return qfa_k32_nll_grad(*p, *b, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
+    const qfa_batch_t bb = norm_batch(*b, Npix);
+    if (kp_for(Nh) == 8) return run_nll_grad<8>(*p, bb, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
+    if (kp_for(Nh) == 16) return run_nll_grad<16>(*p, bb, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
+    return qfa_k32_nll_grad(*p, bb, *tau, B, Npix, Nb, Nh, nll, accum, ws, st, events, slab, flags);
 }
 
 int qfa_finalize_grads_f32(const float *accum, const float *F, int Npix, int Nb, int Nh, int normalize, float *gF,
@@ -138,14 +139,15 @@ int qfa_predict_ex_f32(const qfa_params_t *p, const float *mu, const qfa_batch_t
                        void *workspace, size_t workspace_bytes, unsigned flags, void *stream, void *const *events) {
     if (!p || !b || !tau || !mu || !ll || !hmean || !hcov || !cont || !unc || !workspace) return QFA_E_NULL;
     if (!p->F || !p->Psi || !p->tau0 || !p->c0 || !p->beta || (Nb > 0 && !p->omega)) return QFA_E_NULL;
-    if (int e = check_batch(*b, Nb)) return e;
+    if (int e = check_batch(*b, Npix, Nb)) return e;
     if (int e = check_shape(B, Npix, Nb, Nh)) return e;
     if (workspace_bytes < qfa_workspace_bytes(B, Npix, Nh)) return QFA_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (kp_for(Nh) == 8) return run_predict<8>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
-    if (kp_for(Nh) == 16) return run_predict<16>(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
-    return qfa_k32_predict(*p, mu, *b, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
+    const qfa_batch_t bb = norm_batch(*b, Npix);
+    if (kp_for(Nh) == 8) return run_predict<8>(*p, mu, bb, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
+    if (kp_for(Nh) == 16) return run_predict<16>(*p, mu, bb, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
+    return qfa_k32_predict(*p, mu, bb, *tau, B, Npix, Nb, Nh, ll, hmean, hcov, cont, unc, ws, st, events, flags);
 }
 
 int qfa_adam_clip_f32(const float *p, const float *g, float *m, float *v, float *p_out, size_t n, double lr, double b1,
@@ -241,44 +243,60 @@ static int fill_lyman(int which, double wav0, LymanTable *t) {
 }
 
 int qfa_build_batch_f32(const float *flux, const float *error, const double *zqso, const int *idx, const double *wav,
-                        double wav0, const double *mu, int which, int nrow, int Npix, int Nb, float *delta,
-                        float *error_out, float *zabs, uint8_t *mask, void *stream) {
+                        double wav0, const double *mu, int which, int nrow, int Npix, int Nb, int64_t row_stride,
+                        float *delta, float *error_out, float *zabs, uint8_t *mask, void *stream) {
     if (!flux || !error || !zqso || !wav || !mu || !delta || !error_out || !mask || (Nb > 0 && !zabs)) return QFA_E_NULL;
-    if (nrow < 1 || Npix < 1 || Nb < 0 || Nb > Npix) return QFA_E_SIZE;
+    if (nrow < 1 || Npix < 1 || Nb < 0 || Nb > Npix || (row_stride != 0 && row_stride < Npix)) return QFA_E_SIZE;
     LymanTable tab;
     if (int e = fill_lyman(which, wav0, &tab)) return e;
     const size_t tot = (size_t)nrow * Npix;
-    k_build_batch<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(flux, error, zqso, idx, wav, mu, tab, nrow,
-                                                                             Npix, Nb, delta, error_out, zabs, mask);
+    k_build_batch<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        flux, error, zqso, idx, wav, mu, tab, nrow, Npix, Nb, (size_t)(row_stride ? row_stride : Npix), delta, error_out, zabs, mask);
+    return hip_status();
+}
+
+int qfa_build_resident_f32(const float *flux, const float *error, const double *zqso, const double *wav, double wav0,
+                           const double *mu, int which, int64_t nrow, int Npix, int Nb, int64_t row_stride, float *delta,
+                           uint8_t *mask, float *zq1, void *stream) {
+    if (!flux || !error || !zqso || !wav || !mu || !delta || !mask || !zq1) return QFA_E_NULL;
+    if (nrow < 1 || Npix < 1 || Nb < 0 || Nb > Npix || row_stride < Npix || row_stride >= (1LL << 31)) return QFA_E_SIZE;
+    LymanTable tab;
+    if (int e = fill_lyman(which, wav0, &tab)) return e;
+    const size_t tot = (size_t)nrow * (size_t)row_stride;
+    if ((tot + 255) / 256 >= (1ull << 31)) return QFA_E_SIZE;
+    k_build_resident<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(flux, error, zqso, wav, mu, tab, (size_t)nrow,
+                                                                                Npix, Nb, (size_t)row_stride, delta, mask, zq1);
     return hip_status();
 }
 
 int qfa_mu_estimate_f64(const float *flux, const float *error, const double *zqso, const double *wav, double wav0,
-                        int which, int B, int Npix, int Nb, int window_len, double *scratch, double *mu_raw,
-                        double *mu_smooth, void *stream) {
+                        int which, int B, int Npix, int Nb, int64_t row_stride, int window_len, double *scratch,
+                        double *mu_raw, double *mu_smooth, void *stream) {
     if (!flux || !error || !zqso || !wav || !scratch || !mu_raw) return QFA_E_NULL;
     if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || window_len < 2 || window_len > Npix) return QFA_E_SIZE;
+    if (row_stride != 0 && row_stride < Npix) return QFA_E_SIZE;
     LymanTable tab;
     if (int e = fill_lyman(which, wav0, &tab)) return e;
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(scratch, 0, 2 * (size_t)Npix * sizeof(double), st);
     const int chunk = 64;
     const dim3 grid((Npix + 255) / 256, (B + chunk - 1) / chunk);
-    k_mu_accumulate<<<grid, 256, 0, st>>>(flux, error, zqso, wav, tab, B, Npix, Nb, chunk, scratch, scratch + Npix);
+    k_mu_accumulate<<<grid, 256, 0, st>>>(flux, error, zqso, wav, tab, B, Npix, Nb, (size_t)(row_stride ? row_stride : Npix), chunk,
+                                          scratch, scratch + Npix);
     k_mu_finish<<<(Npix + 255) / 256, 256, 0, st>>>(scratch, scratch + Npix, Npix, window_len, mu_raw, mu_smooth);
     return hip_status();
 }
 
 int qfa_mu_sums_f64(const float *flux, const float *error, const double *zqso, const double *wav, double wav0, int which,
-                    int B, int Npix, int Nb, double *scratch, void *stream) {
+                    int B, int Npix, int Nb, int64_t row_stride, double *scratch, void *stream) {
     if (!flux || !error || !zqso || !wav || !scratch) return QFA_E_NULL;
-    if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix) return QFA_E_SIZE;
+    if (B < 1 || Npix < 1 || Nb < 0 || Nb > Npix || (row_stride != 0 && row_stride < Npix)) return QFA_E_SIZE;
     LymanTable tab;
     if (int e = fill_lyman(which, wav0, &tab)) return e;
     const int chunk = 64;
     const dim3 grid((Npix + 255) / 256, (B + chunk - 1) / chunk);
-    k_mu_accumulate<<<grid, 256, 0, (hipStream_t)stream>>>(flux, error, zqso, wav, tab, B, Npix, Nb, chunk, scratch,
-                                                           scratch + Npix);
+    k_mu_accumulate<<<grid, 256, 0, (hipStream_t)stream>>>(flux, error, zqso, wav, tab, B, Npix, Nb,
+                                                           (size_t)(row_stride ? row_stride : Npix), chunk, scratch, scratch + Npix);
     return hip_status();
 }
 

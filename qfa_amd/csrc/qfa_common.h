@@ -192,12 +192,24 @@ __device__ __forceinline__ BlueTerms blue_terms_zf(const ZFac &zs, float ti, flo
     t.zd = re * re;
     return t;
 }
-// ZS[s] from zq1[s] = 1 + z_qso;  ZP[i] from pix_ratio[i] = wav_i / 1215.67 (blue pixels)
-static __global__ void k_zfac_spec(const float *__restrict__ zq1, qfa_params_t p, qfa_tau_t tau, int B,
-                                   float4 *__restrict__ ZS) {
+// ---- resident, indexed input form (include/qfa_hip.h, ABI v3): spectrum s of the batch is row rows[s] (or s) of
+// delta / error / mask, rows row_stride elements apart (the host fills in row_stride = Npix when the caller left it 0).
+// The kernels address a row by a wave-uniform pointer (array base + the tile's pixel offset, SGPRs) plus a per-lane 64-bit
+// element offset row * row_stride + pixel: one v_lshl_add_u64 per request, no limit on the size of the resident arrays.
+__device__ __forceinline__ unsigned long long batch_row(const qfa_batch_t &bt, int s) {
+    return bt.rows ? (unsigned long long)(unsigned)bt.rows[s] : (unsigned long long)(unsigned)s;
+}
+template <int SH>      // sbase + (off << SH): SH = 2 for the float arrays, 0 for the mask bytes
+__device__ __forceinline__ const unsigned char *lane_ptr(const void *sbase, unsigned long long off) {
+    return reinterpret_cast<const unsigned char *>(sbase) + (off << SH);
+}
+
+// ZS[s] from zq1[row of s] = 1 + z_qso;  ZP[i] from pix_ratio[i] = wav_i / 1215.67 (blue pixels)
+static __global__ void k_zfac_spec(const float *__restrict__ zq1, const int *__restrict__ rows, qfa_params_t p, qfa_tau_t tau,
+                                   int B, float4 *__restrict__ ZS) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= B) return;
-    const double l2s = log2((double)zq1[s]);
+    const double l2s = log2((double)zq1[rows ? rows[s] : s]);
     const double ts = -1.4426950408889634 * (double)tau.amp * exp2((double)tau.expo * (l2s + log2((double)tau.scale)));
     ZS[s] = float4{(float)ts, (float)exp2((double)*p.beta * l2s), (float)l2s, 0.f};
 }
@@ -319,16 +331,12 @@ __device__ __forceinline__ f32x4 six_terms(F &&mm, const V &ah, const V &am, con
     c = mm(ah, bm, c);
     return mm(ah, bh, c);
 }
-// Stage 3 of pass 2 (G_s = F_tile Z_s, then summed over K and over every spectrum of the batch) issues fewer piece
-// products than the six of a float32-grade product.  With h, m, l the bf16 pieces of an operand (|m| <= 2^-9 |h|,
+// Stage 3 of pass 2 takes the number of piece products as a template argument (TERMS) where fewer than the six of a
+// float32-grade product are on offer (QFA_F_S3_FAST).  With h, m, l the bf16 pieces of an operand (|m| <= 2^-9 |h|,
 // |l| <= 2^-18 |h|):  6 = all products down to 2^-18 (error ~ 2^-24);  4 = ah bh + ah bm + am bh + am bm (drops ah bl and
 // al bh: <= 2 x 2^-18 per product);  3 = ah bh + ah bm + am bh (drops am bm as well: <= 3 x 2^-18 = 1.1e-5 per product).
-// Measured against the float64 oracle the F gradient does not tell them apart (profiles/r2_ablation_k_grads_x.txt:
-// rel-L2 1.9e-5 with 6, 4 and 3 at (4000, 16), 4.9e-6 / 6.8e-6 / 7.3e-6 at (640, 16); the float32 numpy oracle itself
-// is at 1.7e-5 .. 6.3e-5), and three are 0.13 - 0.17 ms faster than four at c3 (2.47 -> 2.30 - 2.34).
-#ifndef QFA_S3_TERMS
-#define QFA_S3_TERMS 3
-#endif
+// Six is the default everywhere (on 20 000 spectra of the headline shape the normalised F gradient is
+// 2.3e-5 from the float64 oracle with six products and 5.5e-5 with three).
 __device__ __forceinline__ f32x4 xdl6(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const u32x4 &bh,
                                       const u32x4 &bm, const u32x4 &bl, f32x4 c) {
     return six_terms([](const u32x4 &a, const u32x4 &b, f32x4 cc) { return xdl(a, b, cc); }, ah, am, al, bh, bm, bl, c);

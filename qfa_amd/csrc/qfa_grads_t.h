@@ -237,25 +237,56 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     // requests per group (the counted waits).  TPW = 1: fast tile 3 (+ 1: zabs or the factors); zabs tile across the boundary
     // 3 + 4; ragged tile 4 + 4 + 1 (+ 4: zabs) (+ 1: the factors).  In general: 16-byte pieces TPW per array, 4-byte pieces
     // 4 TPW per array, the masks TPW
+    // (+ 1 in the indexed form of ABI v3: the row indices of the group two groups later, stage_spectra)
     const int nsp = !active ? 0
                             : (slow ? 9 * TPW + (zblue ? 4 * TPW : 0) + (zfb ? 1 : 0)
-                                    : (zstrad ? 7 * TPW : 3 * TPW + (zblue ? TPW : 0) + (zfb ? 1 : 0)));
+                                    : (zstrad ? 7 * TPW : 3 * TPW + (zblue ? TPW : 0) + (zfb ? 1 : 0))) + (bt.rows ? 1 : 0);
     // first byte of the 4-byte mask piece (half h of the tile, piece pc) in its row; the ragged tile clamps it to Npix - 4
     auto mask_start = [&](int h, int pc) __attribute__((always_inline)) {
         const int st = PXW * wt + 16 * h + 4 * pc;
         return slow ? max(0, min(st, Npix - 4)) : st;
     };
-    // group t of the range: rows s0 .. s0 + 15
-    auto stage_spectra = [&](int t, int bufi) __attribute__((always_inline)) {
+    // Group t of the range: spectra s0 .. s0 + 15 of the batch.  Spectrum s is row batch_row(s) of the batch arrays (ABI v3:
+    // rows / row_stride, qfa_common.h): every request takes a per-lane 64-bit address.  Indexed form: the row indices of a
+    // group are lane-varying values that must be in registers when its requests are formed, two steps before its data are
+    // used -- they ride along: the requests of group t carry the 16 indices of group t + 2 into STG_ROWS of the same
+    // staging buffer (one more request per group, on the counted path), and stage_spectra(t + 2), which re-uses that
+    // buffer, reads them there before its first request.  The first two groups (FIRST) read theirs from global memory.
+    const unsigned RS = (unsigned)bt.row_stride;            // (elements; < 2^31: check_batch)
+    const bool idx = bt.rows != nullptr;                    // (wave-uniform: a kernel argument)
+    // row of the batch arrays <- row `row` of group t, whose indices wait in staging buffer bufi (FIRST: in global memory)
+    auto row_index = [&](int t, int bufi, unsigned row, auto first_tag) __attribute__((always_inline)) -> unsigned {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const unsigned s0 = 16u * (unsigned)(g0 + t);
+        if (!idx) return s0 + row;
+        if (FIRST || QFA_TRACKED_LOADS) return (unsigned)bt.rows[s0 + row];
+        return (unsigned)reinterpret_cast<const int *>(stg + bufi * GT::STG_B + GT::STG_ROWS)[row];
+    };
+    // the rows the lane's requests of a whole tile take (the ragged and the straddling tile read theirs where they need them):
+    // r[i] = row of the 16-byte pieces of request i, m = row of the lane's mask piece.  Read by the caller AHEAD of
+    // stage_spectra, with the LDS reads of the stage it sits in (a read right in front of the requests is ~100 cycles in the open)
+    struct RowIdx {
+        unsigned r[TPW], m;
+    };
+    auto read_rows = [&](int t, int bufi, auto first_tag) __attribute__((always_inline)) {
+        RowIdx ri;
+        const int last_row = min(15, B - 1 - 16 * (g0 + t));
+        auto slot_row = [&](int q) __attribute__((always_inline)) { return (unsigned)min(q ^ ((q >> 2) & 1), last_row); };
+        ri.m = row_index(t, bufi, slot_row(lane >> 2), first_tag);
+        if constexpr (TPW == 1) ri.r[0] = ri.m;
+        else {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) ri.r[i] = row_index(t, bufi, slot_row((64 / (4 * TPW)) * i + lane / (4 * TPW)), first_tag);
+        }
+        return ri;
+    };
+    auto stage_spectra = [&](int t, int bufi, const RowIdx &ri, auto first_tag) __attribute__((always_inline)) {
         if (!active) return;
         const int s0 = 16 * (g0 + t);
         const int last_row = min(15, B - 1 - s0);                                     // wave-uniform, >= 0
-        const float *dbase = uniform_ptr(bt.delta + (size_t)s0 * Npix);
-        const float *ebase = uniform_ptr(bt.error + (size_t)s0 * Npix);
-        const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)s0 * Npix);
-        const float *zbase = zblue ? uniform_ptr(bt.zabs + (size_t)s0 * Nb) : dbase;
         const unsigned dst = wave_uniform(lds_addr(stg + bufi * GT::STG_B));
         auto slot_row = [&](int q) __attribute__((always_inline)) { return (unsigned)min(q ^ ((q >> 2) & 1), last_row); };
+        auto Rof = [&](unsigned row) __attribute__((always_inline)) -> unsigned { return row_index(t, bufi, row, first_tag); };
 #if QFA_TRACKED_LOADS
         {
             float *sf = reinterpret_cast<float *>(stg + bufi * GT::STG_B);
@@ -263,91 +294,112 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #pragma unroll
             for (int i = 0; i < 4 * TPW; ++i) {
                 const int e = 64 * i + lane, q = e / PXW, pl = e % PXW;               // (slot, pixel of the wave tile)
-                const unsigned row = slot_row(q);
+                const unsigned R = Rof(slot_row(q));
                 const int pxx = PXW * wt + pl;
-                const unsigned o = row * (unsigned)Npix + (unsigned)min(pxx, Npix - 1);
-                sf[0 * (GT::STG_ARR / 4) + q * PXW + pl] = dbase[o];
-                sf[1 * (GT::STG_ARR / 4) + q * PXW + pl] = ebase[o];
-                if (zblue) sf[2 * (GT::STG_ARR / 4) + q * PXW + pl] = zbase[row * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)];
-                mb[(pl >> 4) * 256 + q * 16 + (pl & 15)] = pxx < Npix ? mbase[o] : (unsigned char)0;
+                const unsigned long long o = (unsigned long long)R * RS + (unsigned)min(pxx, Npix - 1);
+                sf[0 * (GT::STG_ARR / 4) + q * PXW + pl] = bt.delta[o];
+                sf[1 * (GT::STG_ARR / 4) + q * PXW + pl] = bt.error[o];
+                if (zblue) sf[2 * (GT::STG_ARR / 4) + q * PXW + pl] = bt.zabs[(unsigned long long)R * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)];
+                mb[(pl >> 4) * 256 + q * 16 + (pl & 15)] = pxx < Npix ? bt.mask[o] : (unsigned char)0;
             }
             if (zfb && lane < 16) reinterpret_cast<float4 *>(sf + 2 * (GT::STG_ARR / 4))[lane] = ZS[s0 + min(lane, last_row)];
             (void)dst;
             return;
         }
 #endif
-        // factored-z form: the factors of the 16 spectra (row r at float4 index r of array 2), one request of 16 lanes
-        if (zfb && lane < 16)
-            glds16a(uniform_ptr(ZS + s0), 16u * (unsigned)min(lane, last_row), dst + 2 * GT::STG_ARR);
-        // the masks: per half of 16 pixels one request of 4-byte pieces (lane = (slot, piece))
-#pragma unroll
-        for (int h = 0; h < TPW; ++h) {
-            if (TPW == 1 && !slow) break;                    // (TPW = 1, fast tile: inside the one statement below)
-            const int q = lane >> 2;
-            glds4a(mbase, slot_row(q) * (unsigned)Npix + (unsigned)mask_start(h, lane & 3), dst + GT::STG_MASK + h * 256);
-        }
+        [&]() __attribute__((always_inline)) {
+        // the masks of the forms that do not carry them in their one statement: per half of 16 pixels one request of 4-byte
+        // pieces (lane = (slot, piece)); their row index first, with the other LDS reads of this call
+        const unsigned Rm = ri.m;
         if (!slow) {
             if constexpr (TPW == 1) {
-                const int q = lane >> 2;                                              // staging slot
-                const unsigned row = slot_row(q);
-                const unsigned pc = 16u * (unsigned)wt + 4u * (unsigned)(lane & 3);   // first pixel of the lane's piece
-                const unsigned o = row * (unsigned)Npix + pc;
-                // delta, sigma, (zabs,) the masks (16 rows x 16 bytes as 4-byte pieces): one write of M0, the LDS offsets in the
-                // instructions' immediate fields, taken off the global bases again
-                const unsigned vo = 4u * o, vz = 4u * (row * (unsigned)Nb + pc);
-                const unsigned char *eb = reinterpret_cast<const unsigned char *>(ebase) - GT::STG_ARR;
-                const unsigned char *zb = reinterpret_cast<const unsigned char *>(zbase) - 2 * GT::STG_ARR;
-                const unsigned char *mb_ = reinterpret_cast<const unsigned char *>(mbase) - GT::STG_MASK;
-                if (zstrad) {                   // zabs of the straddling tile: clamped pixels, 4 slots per request
-#pragma unroll
+                const unsigned R = ri.r[0];                                           // staging slot lane >> 2
+                unsigned pc = 16u * (unsigned)wt + 4u * (unsigned)(lane & 3);         // first pixel of the lane's piece
+                asm volatile("" : "+v"(pc));          // (opaque: base + 4 pc per array would otherwise live in registers for the whole walk)
+                const unsigned long long o = (unsigned long long)R * RS + pc;
+                // factored-z form: the factors of the 16 spectra (row r at float4 index r of array 2), one request of 16 lanes
+                if (zfb && lane < 16) glds16a(uniform_ptr(ZS + s0), 16u * (unsigned)min(lane, last_row), dst + 2 * GT::STG_ARR);
+                if (zstrad) {                   // zabs of the straddling tile: clamped pixels, 4 slots per request (one wave: rolled)
+#pragma unroll 1
                     for (int i = 0; i < 4; ++i) {
-                        const int q4 = 4 * i + g;
-                        glds4a(zbase, 4u * (slot_row(q4) * (unsigned)Nb + (unsigned)min(16 * wt + lo, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+                        int pz = min(16 * wt + lo, Nb - 1);
+                        asm volatile("" : "+v"(pz));
+                        glds4p(lane_ptr<2>(bt.zabs, (unsigned long long)Rof(slot_row(4 * i + g)) * (unsigned)Nb + (unsigned)pz), dst + 2 * GT::STG_ARR + i * 256);
                     }
                 }
-                if (zblue && !zstrad)
-                    asm volatile("s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
-                                 "global_load_lds_dwordx4 %0, %4 offset:1024\n\tglobal_load_lds_dwordx4 %1, %5 offset:2048\n\t"
-                                 "global_load_lds_dword %2, %6 offset:3072"
-                                 ::"v"(vo), "v"(vz), "v"(o), "s"(dbase), "s"(eb), "s"(zb), "s"(mb_), "s"(dst) : "memory");
-                else
-                    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                                 "global_load_lds_dwordx4 %0, %3 offset:1024\n\tglobal_load_lds_dword %1, %4 offset:3072"
-                                 ::"v"(vo), "v"(o), "s"(dbase), "s"(eb), "s"(mb_), "s"(dst) : "memory");
+                // delta, sigma, (zabs,) the masks (16 rows x 16 bytes as 4-byte pieces): one write of M0, the LDS offsets in the
+                // instructions' immediate fields, taken off the global addresses again
+                const unsigned char *pd = lane_ptr<2>(bt.delta, o);
+                const unsigned char *pe = lane_ptr<2>(reinterpret_cast<const unsigned char *>(bt.error) - GT::STG_ARR, o);
+                const unsigned char *pm = lane_ptr<0>(bt.mask - GT::STG_MASK, o);
+                if (zblue && !zstrad) {
+                    const unsigned char *pz = lane_ptr<2>(reinterpret_cast<const unsigned char *>(bt.zabs) - 2 * GT::STG_ARR, (unsigned long long)R * (unsigned)Nb + pc);
+                    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %2, off offset:2048\n\t"
+                                 "global_load_lds_dword %3, off offset:3072"
+                                 ::"v"(pd), "v"(pe), "v"(pz), "v"(pm), "s"(dst) : "memory");
+                } else
+                    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dword %2, off offset:3072"
+                                 ::"v"(pd), "v"(pe), "v"(pm), "s"(dst) : "memory");
             } else {
                 // 16-byte pieces: a row of the wave tile is 4 TPW lanes, a request 16 / TPW slots
-                constexpr int LPR = 4 * TPW, SPI = 64 / LPR;
+                constexpr int LPR = 4 * TPW;
+                if (zfb && lane < 16) glds16a(uniform_ptr(ZS + s0), 16u * (unsigned)min(lane, last_row), dst + 2 * GT::STG_ARR);
+#pragma unroll
+                for (int h = 0; h < TPW; ++h) {
+                    unsigned ms = (unsigned)mask_start(h, lane & 3);
+                    asm volatile("" : "+v"(ms));
+                    glds4p(lane_ptr<0>(bt.mask, (unsigned long long)Rm * RS + ms), dst + GT::STG_MASK + h * 256);
+                }
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const int q = SPI * i + lane / LPR;
-                    const unsigned row = slot_row(q);
-                    const unsigned pc = (unsigned)(PXW * wt) + 4u * (unsigned)(lane % LPR);
-                    glds16a(dbase, 4u * (row * (unsigned)Npix + pc), dst + i * 1024);
-                    glds16a(ebase, 4u * (row * (unsigned)Npix + pc), dst + GT::STG_ARR + i * 1024);
-                    if (zblue && !zstrad) glds16a(zbase, 4u * (row * (unsigned)Nb + pc), dst + 2 * GT::STG_ARR + i * 1024);
+                    unsigned pc = (unsigned)(PXW * wt) + 4u * (unsigned)(lane % LPR);
+                    asm volatile("" : "+v"(pc));      // (opaque: base + 4 pc per array would otherwise live in registers for the whole walk)
+                    const unsigned long long o = (unsigned long long)ri.r[i] * RS + pc;
+                    glds16p(lane_ptr<2>(bt.delta, o), dst + i * 1024);
+                    glds16p(lane_ptr<2>(bt.error, o), dst + GT::STG_ARR + i * 1024);
+                    if (zblue && !zstrad) glds16p(lane_ptr<2>(bt.zabs, (unsigned long long)ri.r[i] * (unsigned)Nb + pc), dst + 2 * GT::STG_ARR + i * 1024);
                 }
-                if (zstrad) {
-#pragma unroll
+                if (zstrad) {                   // (one wave of the launch: rolled)
+#pragma unroll 1
                     for (int i = 0; i < 4 * TPW; ++i) {
-                        const int e = 64 * i + lane, q = e / PXW, pl = e % PXW;
-                        glds4a(zbase, 4u * (slot_row(q) * (unsigned)Nb + (unsigned)min(PXW * wt + pl, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+                        const int e = 64 * i + lane;
+                        int pz = min(PXW * wt + e % PXW, Nb - 1);
+                        asm volatile("" : "+v"(pz));
+                        glds4p(lane_ptr<2>(bt.zabs, (unsigned long long)Rof(slot_row(e / PXW)) * (unsigned)Nb + (unsigned)pz), dst + 2 * GT::STG_ARR + i * 256);
                     }
                 }
             }
             return;
         }
         // ragged tile (the last one of a pixel axis that is no multiple of PXW): 4-byte pieces with the pixel clamped per lane;
-        // the masks (above) as 4-byte pieces whose start is clamped to Npix - 4 (mask_pos below is where the lane then finds
-        // its byte) -- everything on the counted path
-#pragma unroll
+        // the masks as 4-byte pieces whose start is clamped to Npix - 4 (mask_pos below is where the lane then finds
+        // its byte) -- everything on the counted path.  (One wave of the launch: rolled loops, nothing kept in registers.)
+        if (zfb && lane < 16) glds16a(uniform_ptr(ZS + s0), 16u * (unsigned)min(lane, last_row), dst + 2 * GT::STG_ARR);
+#pragma unroll 1
+        for (int h = 0; h < TPW; ++h) {
+            unsigned ms = (unsigned)mask_start(h, lane & 3);
+            asm volatile("" : "+v"(ms));
+            glds4p(lane_ptr<0>(bt.mask, (unsigned long long)Rm * RS + ms), dst + GT::STG_MASK + h * 256);
+        }
+#pragma unroll 1
         for (int i = 0; i < 4 * TPW; ++i) {
-            const int e = 64 * i + lane, q = e / PXW, pl = e % PXW;
-            const unsigned row = slot_row(q);
-            const int pxx = PXW * wt + pl;
-            const unsigned o = row * (unsigned)Npix + (unsigned)min(pxx, Npix - 1);
-            glds4a(dbase, 4u * o, dst + i * 256);
-            glds4a(ebase, 4u * o, dst + GT::STG_ARR + i * 256);
-            if (zblue) glds4a(zbase, 4u * (row * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+            const int e = 64 * i + lane, pl = e % PXW;
+            const unsigned R = Rof(slot_row(e / PXW));
+            int pxx = PXW * wt + pl;
+            asm volatile("" : "+v"(pxx));
+            const unsigned long long o = (unsigned long long)R * RS + (unsigned)min(pxx, Npix - 1);
+            glds4p(lane_ptr<2>(bt.delta, o), dst + i * 256);
+            glds4p(lane_ptr<2>(bt.error, o), dst + GT::STG_ARR + i * 256);
+            if (zblue) glds4p(lane_ptr<2>(bt.zabs, (unsigned long long)R * (unsigned)Nb + (unsigned)min(pxx, Nb - 1)), dst + 2 * GT::STG_ARR + i * 256);
+        }
+        }();
+        // indexed form: the row indices of group t + 2 (clamped to the range's last group: the request count stays fixed)
+        // behind the requests whose addresses were formed from this buffer's previous indices
+        if (idx) {
+            const int t2 = min(t + 2, n - 1), s2 = 16 * (g0 + t2);
+            if (lane < 16) glds4a(uniform_ptr(bt.rows + s2), 4u * (unsigned)min(lane, B - 1 - s2), dst + GT::STG_ROWS);
         }
     };
     // where the mask byte of the lane's pixel of tile j sits inside a slot's staged bytes: half, then byte of the half
@@ -492,6 +544,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                 zqx[r] = q.x; zqy[r] = q.y; zqz[r] = q.z;
             }
         }
+        RowIdx ri{};
+        if (t + 2 < n) ri = read_rows(t + 2, t & 1, std::false_type{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staging buffer read: it may be overwritten now
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
@@ -503,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #pragma unroll
             for (int r = 0; r < 4; ++r) sgv[j][r] = mk[j][r] ? fabsf(sgv[j][r]) : -1.f;
         GTS(6)
-        if (t + 2 < n) stage_spectra(t + 2, t & 1);
+        if (t + 2 < n) stage_spectra(t + 2, t & 1, ri, std::false_type{});
         piece(pt, 0);
         piece(pt, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -641,8 +695,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     // The stages sit in straight-line loops: under conditions inside one loop hipcc kept two copies of the 64 accumulator
     // registers of W (result of the first MFMA of a chain in fresh registers, copied back at the end of the step).
     if (n > 0) {
-        stage_spectra(0, 0);
-        if (n > 1) stage_spectra(1, 1);
+        stage_spectra(0, 0, read_rows(0, 0, std::true_type{}), std::true_type{});
+        if (n > 1) stage_spectra(1, 1, read_rows(1, 1, std::true_type{}), std::true_type{});
         issue_S1(0);
         if (n > 1) issue_S1(1);
         issue_Z(0);

@@ -76,7 +76,8 @@ struct GXT {                                             // KP = 16 (N_h = 9..16
     static constexpr int L_SCAL = L_PSUM + 2 * NG * 512;             // [NG waves][3 sums][64 lanes] double (role A)
     static constexpr int L_STG = L_SCAL + NG * 3 * 64 * 8;           // [NG waves][2 tile parity][STG_B]
     static constexpr int L_ZS = L_STG + NG * 2 * STG_B;              // [NG waves][16 spectra] float4: factored-z per-spectrum factors
-    static constexpr int L_TOTAL = L_ZS + NG * 256;
+    static constexpr int L_ROWS = L_ZS + NG * 256;                   // [NG waves][16 spectra] unsigned: rows of the batch arrays (ABI v3)
+    static constexpr int L_TOTAL = L_ROWS + NG * 64;
 };
 static_assert(GXT<16>::L_TOTAL <= 160 * 1024 && GXT<8>::L_TOTAL <= 160 * 1024, "k_grads_x LDS");
 static_assert(32 * GXT<16>::FROW * 4 <= 3072, "F block of the W form fits the F slot");
@@ -301,11 +302,13 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             return (unsigned)min(q + r, last_row);
         };
         auto offB_of = [&](int r) { return row_of(r) * (unsigned)Nb; };
-        const float *dbase = uniform_ptr(bt.delta + (size_t)(active ? s0 : 0) * Npix);
-        const float *ebase = uniform_ptr(bt.error + (size_t)(active ? s0 : 0) * Npix);
-        const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)(active ? s0 : 0) * Npix);
-        const float *zbase = ZF ? dbase : uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
-        const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
+        const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;      // (batch order: not indexed)
+        // Spectrum s0 + r of the batch is row batch_row(s0 + r) of the batch arrays (ABI v3: rows / row_stride, qfa_common.h):
+        // the wave's 16 row numbers wait in LDS (this role has no registers to spare) and every request forms its per-lane
+        // 64-bit address from one of them
+        unsigned *rtab = reinterpret_cast<unsigned *>(lds + GX::L_ROWS + w * 64);
+        if (lane < 16) rtab[lane] = (unsigned)batch_row(bt, (active ? s0 : 0) + min(lane, last_row));
+        const unsigned RS = (unsigned)bt.row_stride;                     // (elements; < 2^31: check_batch)
         // factored-z form: the per-spectrum factors of the wave's 16 spectra in LDS (this role has no registers to spare)
         float4 *zsl = reinterpret_cast<float4 *>(lds + GX::L_ZS + w * 256);
         if (ZF && lane < 16) zsl[lane] = (active && s0 + lane < B) ? ZS[s0 + lane] : float4{0.f, 0.f, 0.f, 0.f};
@@ -332,9 +335,13 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             if (QFA_GX_ABL & 8) tg = t0;
             const bool zblue = !ZF && tg < nbt;                                               // wave-uniform
             const bool fastp = 32 * tg + 31 < Npix, fastz = ZF || !zblue || 32 * tg + 31 < Nb;
-            const float *zb = (zblue && !(QFA_GX_ABL & 16)) ? zbase : dbase;
-            const int zlen = (zblue && !(QFA_GX_ABL & 16)) ? Nb : Npix;
+            // the third array: zabs rows (Nb apart, Nb long) on a blue tile, else the delta rows again
+            const bool zreal = zblue && !(QFA_GX_ABL & 16);
+            const float *zb = zreal ? bt.zabs : bt.delta;
+            const unsigned zpitch = zreal ? (unsigned)Nb : RS;
+            const int zlen = zreal ? Nb : Npix;
             const unsigned dst = wave_uniform(lds_addr(stg + par * GX::STG_B));
+            auto slot_row = [&](int q) __attribute__((always_inline)) { return (unsigned)min(q ^ ((q >> 2) & 1), last_row); };
 #if QFA_TRACKED_LOADS
             {   // test build: ordinary loads and LDS stores for all four arrays (two rows per pass), no counted wait
                 float *sf = reinterpret_cast<float *>(stg + par * GX::STG_B);
@@ -342,54 +349,58 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int q = 2 * i + (lane >> 5), pxl = lane & 31;
-                    const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+                    const unsigned R = rtab[slot_row(q)];
                     const int px = 32 * tg + pxl;
-                    const unsigned o = row * (unsigned)Npix + (unsigned)min(px, Npix - 1);
-                    sf[0 * (GX::STG_ARR / 4) + q * 32 + pxl] = dbase[o];
-                    sf[1 * (GX::STG_ARR / 4) + q * 32 + pxl] = ebase[o];
-                    if (!ZF) sf[2 * (GX::STG_ARR / 4) + q * 32 + pxl] = zb[row * (unsigned)zlen + (unsigned)min(px, zlen - 1)];
-                    mb[q * 32 + pxl] = px < Npix ? mbase[o] : (unsigned char)0;
+                    const unsigned long long o = (unsigned long long)R * RS + (unsigned)min(px, Npix - 1);
+                    sf[0 * (GX::STG_ARR / 4) + q * 32 + pxl] = bt.delta[o];
+                    sf[1 * (GX::STG_ARR / 4) + q * 32 + pxl] = bt.error[o];
+                    if (!ZF) sf[2 * (GX::STG_ARR / 4) + q * 32 + pxl] = zb[(unsigned long long)R * zpitch + (unsigned)min(px, zlen - 1)];
+                    mb[q * 32 + pxl] = px < Npix ? bt.mask[o] : (unsigned char)0;
                 }
                 (void)dst; (void)fastz;
                 return 0;
             }
 #endif
             if (fastp) {
+                unsigned R2[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) R2[i] = rtab[slot_row(8 * i + (lane >> 3))];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int q = 8 * i + (lane >> 3);
-                    const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
-                    const unsigned pc = 4u * (unsigned)(lane & 7);                            // first pixel of the piece
-                    const unsigned o = row * (unsigned)Npix + 32u * (unsigned)tg + pc;
-                    glds16a(dbase, 4u * o, dst + 0 * GX::STG_ARR + i * 1024);
-                    glds16a(ebase, 4u * o, dst + 1 * GX::STG_ARR + i * 1024);
-                    if (!ZF && fastz) glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * GX::STG_ARR + i * 1024);
-                    glds4a(mbase, o, dst + GX::STG_MASK + i * 256);
+                    unsigned pc = 32u * (unsigned)tg + 4u * (unsigned)(lane & 7);             // first pixel of the piece
+                    asm volatile("" : "+v"(pc));
+                    const unsigned long long o = (unsigned long long)R2[i] * RS + pc;
+                    glds16p(lane_ptr<2>(bt.delta, o), dst + 0 * GX::STG_ARR + i * 1024);
+                    glds16p(lane_ptr<2>(bt.error, o), dst + 1 * GX::STG_ARR + i * 1024);
+                    if (!ZF && fastz) glds16p(lane_ptr<2>(zb, (unsigned long long)R2[i] * zpitch + pc), dst + 2 * GX::STG_ARR + i * 1024);
+                    glds4p(lane_ptr<0>(bt.mask, o), dst + GX::STG_MASK + i * 256);
                 }
                 if (fastz) return ZF ? 6 : 8;
             }
-            // 4-byte pieces, 64 lanes = two rows per instruction, the pixel index clamped per lane
-#pragma unroll
+            // 4-byte pieces, 64 lanes = two rows per instruction, the pixel index clamped per lane (at most two tiles of a
+            // work item come here: rolled)
+#pragma unroll 1
             for (int i = 0; i < 8; ++i) {
                 const int q = 2 * i + (lane >> 5);
-                const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
-                const int pxl = lane & 31;
-                if (!ZF) glds4a(zb, 4u * (row * (unsigned)zlen + (unsigned)min(32 * tg + pxl, zlen - 1)), dst + 2 * GX::STG_ARR + i * 256);
+                const unsigned R = rtab[slot_row(q)];
+                int pxl = lane & 31;
+                asm volatile("" : "+v"(pxl));
+                if (!ZF) glds4p(lane_ptr<2>(zb, (unsigned long long)R * zpitch + (unsigned)min(32 * tg + pxl, zlen - 1)), dst + 2 * GX::STG_ARR + i * 256);
                 if (!fastp) {
-                    const unsigned o = row * (unsigned)Npix + (unsigned)min(32 * tg + pxl, Npix - 1);
-                    glds4a(dbase, 4u * o, dst + 0 * GX::STG_ARR + i * 256);
-                    glds4a(ebase, 4u * o, dst + 1 * GX::STG_ARR + i * 256);
+                    const unsigned long long o = (unsigned long long)R * RS + (unsigned)min(32 * tg + pxl, Npix - 1);
+                    glds4p(lane_ptr<2>(bt.delta, o), dst + 0 * GX::STG_ARR + i * 256);
+                    glds4p(lane_ptr<2>(bt.error, o), dst + 1 * GX::STG_ARR + i * 256);
                 }
             }
             if (fastp) return 14;
             // masks of the ragged tile: ordinary loads (hipcc waits for them by itself) and byte stores
             unsigned char *mb = stg + par * GX::STG_B + GX::STG_MASK;
-#pragma unroll
+#pragma unroll 1
             for (int i = 0; i < 8; ++i) {
                 const int q = 2 * i + (lane >> 5);
-                const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+                const unsigned R = rtab[slot_row(q)];
                 const int px = 32 * tg + (lane & 31);
-                mb[q * 32 + (lane & 31)] = px < Npix ? mbase[row * (unsigned)Npix + (unsigned)px] : (unsigned char)0;
+                mb[q * 32 + (lane & 31)] = px < Npix ? bt.mask[(unsigned long long)R * RS + (unsigned)px] : (unsigned char)0;
             }
             return 0;
         };
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
     } else if (QFA_GX_ROLE != 1) {
         // ================================================================ role B: image DMA, flushes, stage 3
         constexpr bool WB = TERMS == 6;        // stage 3 in its W form (float32 grade); TERMS == 3: the G form (QFA_F_S3_FAST)
-        // ---- W form (qfa_grads_w.h has the derivation): accF[px][b] = sum_a F[px][a] W[px][a][b], W = sum_s Z_s[a][b] beta[s][px]
+        // ---- W form: accF[px][b] = sum_a F[px][a] W[px][a][b], W = sum_s Z_s[a][b] beta[s][px]
         // as a K = spectrum GEMM per column tile a: A = static Z pieces (row m = b = lane & 15; k = 8 g + j <-> spectrum
         // 4 g + (j & 3), piece slot j >> 2), B = the lane's own four beta values as {h|l}, {m|m}, {h|h}: three INDEPENDENT
         // short chains per column tile instead of six dependent 32x32x16 MFMAs per spectrum pair -- role B alone ran 2.75 ms

@@ -42,7 +42,9 @@ struct GTT {
     // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
     // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
     // (TPW = 2: [16 slots][32 px] float x 3, mask bytes as two halves [2][16 slots][16])
-    static constexpr int STG_ARR = 1024 * TPW, STG_MASK = 3 * STG_ARR, STG_B = 3 * STG_ARR + 256 * TPW;
+    // ABI v3 (rows): then the row indices of the 16 spectra of the group TWO groups later -- the request that stages group t
+    // carries them, the lanes read them when they form the addresses of group t + 2 (k_grads_t, stage_spectra)
+    static constexpr int STG_ARR = 1024 * TPW, STG_MASK = 3 * STG_ARR, STG_ROWS = STG_MASK + 256 * TPW, STG_B = STG_ROWS + 64;
     static constexpr int L_S1 = 0;                           // [2][S1P_B]
     static constexpr int L_Z = L_S1 + 2 * S1P_B;             // [2][ZP_B]
     static constexpr int L_STG = L_Z + 2 * ZP_B;             // [NW][2][STG_B]

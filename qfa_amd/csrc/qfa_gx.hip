@@ -1,39 +1,15 @@
 // qfa_gx.hip -- pass 2 on the XDL pipe (qfa_grads_x.h) in its own translation unit: the kernel is large and
 // is iterated on separately from the rest of the library.
 #include "qfa_grads_x.h"
-#include "qfa_grads_w.h"
 #include "qfa_grads_t.h"       // (GTT: the image size; the kernel itself is built in qfa_gt.hip)
 #include "qfa_predict_x.h"
 
 #include "qfa_host.h"
 
 size_t qfa_gx_image_bytes(int KP, int ntiles32) {            // the largest of the forms' images (one region serves all)
-    const size_t x = KP == 8 ? GXT<8>::TILE_B : GXT<16>::TILE_B, w = KP == 8 ? GWT<8>::TILE_B : GWT<16>::TILE_B;
+    const size_t x = KP == 8 ? GXT<8>::TILE_B : GXT<16>::TILE_B;
     const size_t t = 2 * (size_t)(KP == 16 ? GTT<16>::TILE_B : GTT<8>::TILE_B);      // (two 16-pixel tiles per 32 pixels)
-    return (size_t)ntiles32 * std::max(t, std::max(x, w));
-}
-
-// pass 2, one-wave-per-SIMD form (qfa_grads_w.h)
-template <int KP>
-static void gw_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                      int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, const float4 *ZS,
-                      const float4 *ZP, float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64,
-                      hipStream_t st) {
-    k_prep_pgw<KP><<<ntiles32, 256, 0, st>>>(p, ZP, Npix, Nb, Nh, PGW);
-    auto go = [&](auto hasa, auto zfac) {
-        k_grads_w<KP, decltype(hasa)::value, decltype(zfac)::value><<<wp.items(), 256, 0, st>>>(
-            p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, ZS, accum, slab, slabS, slab_stride, sc64);
-    };
-    if (b.A_blue) go(std::true_type{}, std::false_type{});
-    else if (ZS) go(std::false_type{}, std::true_type{});
-    else go(std::false_type{}, std::false_type{});
-}
-void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, const float *ZS, const float *ZP,
-                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st) {
-    const float4 *zs = reinterpret_cast<const float4 *>(ZS), *zp = reinterpret_cast<const float4 *>(ZP);
-    if (KP == 8) gw_launch<8>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, zs, zp, accum, slab, slabS, slab_stride, sc64, st);
-    else gw_launch<16>(p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGW, SOL, zs, zp, accum, slab, slabS, slab_stride, sc64, st);
+    return (size_t)ntiles32 * std::max(t, x);
 }
 
 // pass 2, two-role form (qfa_grads_x.h)

@@ -13,11 +13,6 @@ void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, const float *ZS, const float *ZP,
                    float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st);
 
-// the one-wave-per-SIMD form of the all-XDL pass 2 (qfa_grads_w.h, built in qfa_gx.hip): QFA_F_PASS2_WFORM
-void qfa_gw_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
-                   int ntiles32, const WorkPlan &wp, unsigned char *PGW, const float *SOL, const float *ZS, const float *ZP,
-                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st);
-
 // the pixel-resident form of the all-XDL pass 2 (qfa_grads_t.h, built in qfa_gx.hip; N_h = 9..16): QFA_F_PASS2_PIXRES
 struct GtPlan;
 size_t qfa_gt_state_bytes(int KP, int B);
@@ -42,9 +37,6 @@ namespace {
 #endif
 #ifndef QFA_P2_S12
 #define QFA_P2_S12 1        // pass 2 at N_h > 16: 1 = k_s12_x + two k_grads_s3, 0 = k_grads (f32 stage 1) + one k_grads_s3
-#endif
-#ifndef QFA_P1_XDL32
-#define QFA_P1_XDL32 1      // pass 1 at N_h > 16: 1 = k_moments_x (XDL pipe, two column sweeps per tile), 0 = k_moments (f32 MFMA)
 #endif
 
 inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
@@ -123,7 +115,7 @@ Layout make_layout_t(int B, int Npix) {
     // pass 1 runs on the XDL pipe at every N_h (32-pixel tiles; one workgroup per CU at N_h > 16)
     L.spb1 = KP <= 16 ? 16 * QFA_P1_NW : 64;
     L.wp1 = KP <= 16 ? (QFA_P1_NW == 8 ? plan_work(B, L.ntiles32, 1, NCU, 128) : plan_work(B, L.ntiles32, 1, 2 * NCU))
-                     : (QFA_P1_XDL32 ? plan_work(B, L.ntiles32, 1, NCU) : plan_work(B, L.ntiles, 2, 2 * NCU));
+                     : plan_work(B, L.ntiles32, 1, NCU);
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
     L.oPF = take((size_t)L.ntiles * C::TILE_PF);
@@ -182,13 +174,22 @@ Layout make_layout(int B, int Npix, int Nh) {
 
 // the batch's pointers: delta, error, mask always; the blue side needs zabs, or the factored form zq1 + pix_ratio
 // (then zabs may be NULL), which does not combine with a host-supplied A_blue (include/qfa_hip.h)
-inline int check_batch(const qfa_batch_t &b, int Nb) {
+// (ABI v3: rows / row_stride -- the resident, indexed input form; not combined with a host-supplied A_blue either)
+inline int check_batch(const qfa_batch_t &b, int Npix, int Nb) {
     if (!b.delta || !b.error || !b.mask) return QFA_E_NULL;
     const bool fac = b.zq1 || b.pix_ratio;
     if (fac && !(b.zq1 && b.pix_ratio)) return QFA_E_NULL;
     if (fac && b.A_blue) return QFA_E_NULL;
     if (Nb > 0 && !fac && !b.zabs) return QFA_E_NULL;
+    if (b.rows && b.A_blue) return QFA_E_NULL;
+    if (b.row_stride != 0 && (b.row_stride < (int64_t)Npix || b.row_stride >= (1LL << 31))) return QFA_E_SIZE;
     return 0;
+}
+// the batch as the kernels take it: row_stride filled in
+inline qfa_batch_t norm_batch(const qfa_batch_t &b, int Npix) {
+    qfa_batch_t r = b;
+    if (r.row_stride == 0) r.row_stride = Npix;
+    return r;
 }
 
 inline int check_shape(int B, int Npix, int Nb, int Nh) {
@@ -222,7 +223,7 @@ inline bool pass2_use_xdl(int KP, int B, unsigned flags) {
     return KP == 16 || KP == 8;
 }
 inline bool pass2_use_pixres(int KP, int B, int Npix, unsigned flags) {
-    if ((KP != 16 && KP != 8) || Npix < 16 || (flags & (QFA_F_PASS2_F32 | QFA_F_PASS2_WFORM | QFA_F_S3_FAST))) return false;
+    if ((KP != 16 && KP != 8) || Npix < 16 || (flags & (QFA_F_PASS2_F32 | QFA_F_S3_FAST))) return false;
     if (flags & QFA_F_PASS2_PIXRES) return true;
     if (flags & QFA_F_PASS2_XDL) return false;
     const int ncu = cu_count();
@@ -269,28 +270,23 @@ inline ZTables launch_zfac(const qfa_params_t &p, const qfa_batch_t &b, const qf
                            float *ws, hipStream_t st) {
     if (!(b.zq1 && b.pix_ratio) || Nb <= 0) return ZTables{nullptr, nullptr};
     float4 *ZS = reinterpret_cast<float4 *>(ws + L.oZS), *ZP = reinterpret_cast<float4 *>(ws + L.oZP);
-    k_zfac_spec<<<(B + 255) / 256, 256, 0, st>>>(b.zq1, p, tau, B, ZS);
+    k_zfac_spec<<<(B + 255) / 256, 256, 0, st>>>(b.zq1, b.rows, p, tau, B, ZS);
     k_zfac_pix<<<(Nb + 255) / 256, 256, 0, st>>>(b.pix_ratio, p, tau, Nb, ZP);
     return ZTables{ZS, ZP};
 }
 
-// pass 1: N_h <= 16 on the XDL pipe (split-bf16 operands, 32-pixel tiles), wider models on the f32 MFMA
+// pass 1 on the XDL pipe (split-bf16 operands, 32-pixel tiles) at every N_h
 template <int KP, bool PREDICT>
 void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, const float *mu, int B, int Npix,
                    int Nb, int Nh, const Layout &L, const ZTables &zt, float *ws, hipStream_t st) {
     float *MOM = ws + L.oMOM;
-    if constexpr (KP <= 16 || QFA_P1_XDL32) {
-        unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
-        k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, Npix, Nb, Nh, PFX);
-        constexpr int NW = KP <= 16 ? QFA_P1_NW : 4;      // (L.spb1 = 16 NW spectra per block)
-        if (zt.ZS)
-            k_moments_x<KP, PREDICT, NW, true><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, zt.ZS, MOM);
-        else
-            k_moments_x<KP, PREDICT, NW, false><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, nullptr, MOM);
-    } else {
-        static_assert(KP <= 16 || QFA_P1_XDL32, "k_moments (float32 MFMA pass 1) has no factored-z form");
-        k_moments<KP, PREDICT><<<L.wp1.items(), 256, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles, L.wp1, ws + L.oPF, MOM);
-    }
+    unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
+    k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, Npix, Nb, Nh, PFX);
+    constexpr int NW = KP <= 16 ? QFA_P1_NW : 4;      // (L.spb1 = 16 NW spectra per block)
+    if (zt.ZS)
+        k_moments_x<KP, PREDICT, NW, true><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, zt.ZS, MOM);
+    else
+        k_moments_x<KP, PREDICT, NW, false><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, nullptr, MOM);
 }
 
 // deterministic mode: slab = [nblk rows of det_row_stride floats | scalar sums: (max items) x 4 waves x 3 doubles |
@@ -351,7 +347,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP, B, flags);
     mark(0);
     const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
-    // the float32 images PF / PFT serve k_moments (N_h > 16) and k_grads: not needed when both passes run on the XDL pipe
+    // the float32 images PF / PFT serve k_grads: not needed when pass 2 runs on the XDL pipe
     if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, zt.ZP, Npix, Nb, Nh, L, PF, PFT, st);
     const bool pixres = pass2_xdl && pass2_use_pixres(KP, B, Npix, flags);             // (its ragged-tile staging wants N_pix >= 4)
     if (pixres) qfa_gt_prep_image(KP, p, reinterpret_cast<const float *>(zt.ZP), Npix, Nb, Nh, reinterpret_cast<unsigned char *>(ws + L.oPGX), st);
@@ -400,14 +396,9 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         return hip_status(st, flags);
     }
     if (pass2_xdl) {
-        if (!(flags & QFA_F_PASS2_WFORM))
-            qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
-                          reinterpret_cast<const float *>(zt.ZS), reinterpret_cast<const float *>(zt.ZP), accum, slab, slabS,
-                          (int)D.stride, sc64, flags, st);
-        else
-            qfa_gw_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
-                          reinterpret_cast<const float *>(zt.ZS), reinterpret_cast<const float *>(zt.ZP), accum, slab, slabS,
-                          (int)D.stride, sc64, st);
+        qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
+                      reinterpret_cast<const float *>(zt.ZS), reinterpret_cast<const float *>(zt.ZP), accum, slab, slabS,
+                      (int)D.stride, sc64, flags, st);
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
         return hip_status(st, flags);
@@ -473,8 +464,8 @@ int run_predict(const qfa_params_t &p, const float *mu, const qfa_batch_t &b, co
     }
     mark(0);
     const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
-    // (PF / PFT: k_predict_out, and k_moments where pass 1 is not on the XDL pipe)
-    if (!writer_xdl || (KP > 16 && !QFA_P1_XDL32)) launch_prep<KP>(p, nullptr, Npix, Nb, Nh, L, PF, PFT, st);
+    // (PF / PFT: k_predict_out)
+    if (!writer_xdl) launch_prep<KP>(p, nullptr, Npix, Nb, Nh, L, PF, PFT, st);
     launch_moments<KP, true>(p, b, tau, mu, B, Npix, Nb, Nh, L, zt, ws, st);
     mark(1);
     sum_segments<KP>(MOM, L, B, st);

@@ -27,13 +27,13 @@ __device__ __forceinline__ double tau_total_px(const LymanTable &t, double opz_w
 __global__ void k_build_batch(const float *__restrict__ flux, const float *__restrict__ error,
                               const double *__restrict__ zqso, const int *__restrict__ idx,
                               const double *__restrict__ wav, const double *__restrict__ mu, LymanTable tab, int nrow,
-                              int Npix, int Nb, float *__restrict__ delta, float *__restrict__ err_out,
+                              int Npix, int Nb, size_t in_stride, float *__restrict__ delta, float *__restrict__ err_out,
                               float *__restrict__ zabs, uint8_t *__restrict__ mask) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (size_t)nrow * Npix) return;
     const int r = (int)(g / Npix), i = (int)(g % Npix);
     const int s = idx ? idx[r] : r;
-    const float f = flux[(size_t)s * Npix + i], e = error[(size_t)s * Npix + i];
+    const float f = flux[(size_t)s * in_stride + i], e = error[(size_t)s * in_stride + i];
     const double w = wav[i];
     const double opzw = (zqso[s] + 1.0) * w;
     double trans = 1.0;
@@ -46,17 +46,43 @@ __global__ void k_build_batch(const float *__restrict__ flux, const float *__res
     mask[g] = (f != -999.f) && (e != -999.f);                               // dataloader.py:29
 }
 
+// The resident form of a data set (ABI v3; qfa_build_resident_f32): every row of flux / error (rows `stride` elements apart)
+// -> delta and mask rows with the same stride (pad pixels zeroed / masked), zq1 = 1 + z_qso.  Same arithmetic as k_build_batch;
+// zabs is not written (the kernels take the factored form zq1 x pix_ratio).  One thread per (row, pixel of the padded row).
+__global__ void k_build_resident(const float *__restrict__ flux, const float *__restrict__ error,
+                                 const double *__restrict__ zqso, const double *__restrict__ wav,
+                                 const double *__restrict__ mu, LymanTable tab, size_t nrow, int Npix, int Nb, size_t stride,
+                                 float *__restrict__ delta, uint8_t *__restrict__ mask, float *__restrict__ zq1) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nrow * stride) return;
+    const size_t s = g / stride;
+    const int i = (int)(g % stride);
+    if (i >= Npix) {
+        delta[g] = 0.f;
+        mask[g] = 0;
+        return;
+    }
+    const float f = flux[g], e = error[g];
+    const double w = wav[i];
+    const double opzw = (zqso[s] + 1.0) * w;
+    double trans = 1.0;
+    if (i < Nb) trans = exp(-tau_total_px(tab, opzw, w));
+    delta[g] = (float)((double)f - mu[i] * trans);                          // dataloader.py:135-136
+    mask[g] = (f != -999.f) && (e != -999.f);                               // dataloader.py:29
+    if (i == 0) zq1[s] = (float)(zqso[s] + 1.0);
+}
+
 // mu estimate: per pixel, sums over spectra.  grid.x over pixels, grid.y over chunks of spectra.
 __global__ void k_mu_accumulate(const float *__restrict__ flux, const float *__restrict__ error,
                                 const double *__restrict__ zqso, const double *__restrict__ wav, LymanTable tab, int B,
-                                int Npix, int Nb, int chunk, double *__restrict__ num, double *__restrict__ den) {
+                                int Npix, int Nb, size_t in_stride, int chunk, double *__restrict__ num, double *__restrict__ den) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Npix) return;
     const int s0 = blockIdx.y * chunk, s1 = min(B, s0 + chunk);
     const double w = wav[i];
     double a = 0.0, c = 0.0;
     for (int s = s0; s < s1; ++s) {
-        const float f = flux[(size_t)s * Npix + i], e = error[(size_t)s * Npix + i];
+        const float f = flux[(size_t)s * in_stride + i], e = error[(size_t)s * in_stride + i];
         const bool m = (f != -999.f) && (e != -999.f);
         double up = 1.0;
         if (i < Nb) up = exp(tau_total_px(tab, (zqso[s] + 1.0) * w, w));

@@ -188,45 +188,48 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
     // float array, the mask as 4-byte pieces.  Returns the requests issued: 8 (all 32 pixels inside the row and, on a blue
     // tile, inside the blue side), else 0 = "ragged: ordinary loads and LDS stores, wait for everything".
     const int last_row = active ? min(15, B - 1 - s0) : 0;          // wave-uniform
-    const float *dbase = uniform_ptr(bt.delta + (size_t)(active ? s0 : 0) * Npix);
-    const float *ebase = uniform_ptr(bt.error + (size_t)(active ? s0 : 0) * Npix);
-    const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)(active ? s0 : 0) * Npix);
-    const float *zbase = ZF ? dbase : uniform_ptr(bt.zabs + (size_t)(active ? s0 : 0) * Nb);
+    // Spectrum s0 + r of the batch is row batch_row(s0 + r) of the batch arrays (ABI v3: rows / row_stride, qfa_common.h);
+    // the rows of the lane's two 16-byte pieces per array stay in registers (one wave per SIMD: room to spare)
+    const unsigned RS = (unsigned)bt.row_stride;                     // (elements; < 2^31: check_batch)
+    auto slot_row = [&](int q) __attribute__((always_inline)) { return (unsigned)min(q ^ ((q >> 2) & 1), last_row); };
+    unsigned R2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) R2[i] = (unsigned)batch_row(bt, (active ? s0 : 0) + (int)slot_row(8 * i + (lane >> 3)));
     auto stage_tile = [&](int tg, int par) -> int {
         if (QFA_S12_ABL & 2) return 8;
         if (QFA_S12_ABL & 8) tg = t0;                 // timing only: the staging always re-reads the item's first tile (cache hits)
         const bool zblue = !ZF && tg < nbt;                                               // wave-uniform
         const bool fast = (32 * tg + 31 < Npix) && (!zblue || 32 * tg + 31 < Nb) && !QFA_TRACKED_LOADS;
-        const float *zb = zblue ? zbase : dbase;
+        // the third array: zabs rows (Nb apart, Nb long) on a blue tile, else the delta rows again
+        const float *zb = zblue ? bt.zabs : bt.delta;
+        const unsigned zpitch = zblue ? (unsigned)Nb : RS;
         const int zlen = zblue ? Nb : Npix;
         unsigned char *buf = lstg[wv][par];
         if (fast) {
             const unsigned dst = wave_uniform(lds_addr(buf));
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int q = 8 * i + (lane >> 3);
-                const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
-                const unsigned pc = 4u * (unsigned)(lane & 7);                            // first pixel of the piece
-                const unsigned o = row * (unsigned)Npix + 32u * (unsigned)tg + pc;
-                glds16a(dbase, 4u * o, dst + 0 * X::STG_ARR + i * 1024);
-                glds16a(ebase, 4u * o, dst + 1 * X::STG_ARR + i * 1024);
-                if (!ZF) glds16a(zb, 4u * (row * (unsigned)zlen + 32u * (unsigned)tg + pc), dst + 2 * X::STG_ARR + i * 1024);
-                glds4a(mbase, o, dst + X::STG_MASK + i * 256);
+                const unsigned pc = 32u * (unsigned)tg + 4u * (unsigned)(lane & 7);       // first pixel of the piece
+                const unsigned long long o = (unsigned long long)R2[i] * RS + pc;
+                glds16p(lane_ptr<2>(bt.delta, o), dst + 0 * X::STG_ARR + i * 1024);
+                glds16p(lane_ptr<2>(bt.error, o), dst + 1 * X::STG_ARR + i * 1024);
+                if (!ZF) glds16p(lane_ptr<2>(zb, (unsigned long long)R2[i] * zpitch + pc), dst + 2 * X::STG_ARR + i * 1024);
+                glds4p(lane_ptr<0>(bt.mask, o), dst + X::STG_MASK + i * 256);
             }
             return ZF ? 6 : 8;
         }
         float *sf = reinterpret_cast<float *>(buf);
         unsigned char *mb = buf + X::STG_MASK;
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < 8; ++i) {
             const int q = 2 * i + (lane >> 5), pxl = lane & 31;
-            const unsigned row = (unsigned)min(q ^ ((q >> 2) & 1), last_row);
+            const unsigned long long R = batch_row(bt, (active ? s0 : 0) + (int)slot_row(q));
             const int px = 32 * tg + pxl;
-            const unsigned o = row * (unsigned)Npix + (unsigned)min(px, Npix - 1);
-            sf[0 * (X::STG_ARR / 4) + q * 32 + pxl] = dbase[o];
-            sf[1 * (X::STG_ARR / 4) + q * 32 + pxl] = ebase[o];
-            if (!ZF) sf[2 * (X::STG_ARR / 4) + q * 32 + pxl] = zb[row * (unsigned)zlen + (unsigned)min(px, zlen - 1)];
-            mb[q * 32 + pxl] = px < Npix ? mbase[o] : (unsigned char)0;
+            const unsigned long long o = R * RS + (unsigned)min(px, Npix - 1);
+            sf[0 * (X::STG_ARR / 4) + q * 32 + pxl] = bt.delta[o];
+            sf[1 * (X::STG_ARR / 4) + q * 32 + pxl] = bt.error[o];
+            if (!ZF) sf[2 * (X::STG_ARR / 4) + q * 32 + pxl] = zb[R * zpitch + (unsigned)min(px, zlen - 1)];
+            mb[q * 32 + pxl] = px < Npix ? bt.mask[o] : (unsigned char)0;
         }
         return 0;
     };
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
 // beta / gamma k_s12_x (or k_grads) stored:  accF[px][b] += sum_s beta_{s,px} (F_tile Z_s)[px][b] + sum_s gamma_{s,px} p_s[b].
 // Work items and flush as k_grads (16-pixel tiles, 4 waves = 64 spectra, per-wave LDS slots summed in fixed order);
 // lane (px = lane & 15, g = lane >> 4): rows 4 g + r of the products.  Z_s (K = a = 32) as two bf16 pieces of all 16
-// spectra in 128 registers, QFA_S3_TERMS (three) piece products per spectrum; 54 MFMAs and 64 FMAs per tile, no transcendental.
+// spectra in 128 registers, TERMS piece products per spectrum (template argument: four by default, three with QFA_F_S3_FAST); 54 MFMAs and 64 FMAs per tile, no transcendental.
 // Inputs of a tile arrive by LDS-DMA TWO tiles ahead into the wave's own buffers (ring of 3 x 4 KiB): the beta and gamma
 // tiles of its 16 spectra ([s][16 px] float, 64-byte row segments: one instruction each, and already the layout the
 // beta-scaling reads) and the two F pieces (1 KiB each).  A wave's queue holds those four requests per tile and its one

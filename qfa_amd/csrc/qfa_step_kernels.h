@@ -130,245 +130,10 @@ struct TileCopy {
     }
 };
 
-// ------------------------------------------------------------------------------------------------
-// k_moments (pass 1).  Lane (sl = lane&15, j = lane>>4) owns spectrum s0+sl at pixels
-// 16*tile + 4j + e (e = 0..3): exactly the A-operand layout A[i = lane&15][k = lane>>4] of
-// v_mfma_f32_16x16x4_f32 for K-step e; the B operand B[k = j][col = sl] = PF[16*tile + 4j + e][col]
-// comes from the LDS tile (bank-conflict free by the row stride, see Cfg).  A lane's four pixels are
-// contiguous, so each input array costs ONE 16-byte load per lane and tile (64 B per spectrum row).
-// The blue tiles (mean-transmission / absorption-noise terms, 5 transcendentals per pixel) and the
-// red tiles (A = 1, no z-dependence) run in two specialised loops.
-// MOM: [segment][Bpad][NMOM] partial records (k_sum_segments adds them up).
-// ------------------------------------------------------------------------------------------------
+// (Round 1's float32-MFMA pass 1, k_moments, left the library in round 4: k_moments_x (qfa_xdl_kernels.h) runs pass 1 on
+// the XDL pipe at every N_h -- 1.25 against 2.24 ms at c3, 1.9 against 3.2 ms at c5.)
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };       // 4-byte aligned 16-byte load
 struct __attribute__((packed, aligned(1))) u4u { unsigned char v[4]; };
-
-struct SpecRegs1 {
-    float d[4], sg[4], z[4];
-    unsigned m;       // 4 mask bytes
-};
-
-template <int KP, bool PREDICT>
-__global__ __launch_bounds__(256, KP > 16 ? 1 : 2) void k_moments(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau,
-                                                 const float *__restrict__ mu, int B, int Bpad, int Npix, int Nb,
-                                                 int ntiles, WorkPlan wp, const float *__restrict__ PF,
-                                                 float *__restrict__ MOM) {
-    using C = Cfg<KP>;
-    constexpr int NF4 = C::TILE_PF / 4;
-    __shared__ float4 lds4[2][NF4];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = wave_uniform(tid >> 6);
-    int blk, seg, t0, t1;
-    plan_item(wp, blockIdx.x, ntiles, blk, seg, t0, t1);
-    const int s0 = (blk * 4 + wv) * 16;
-    const bool active = s0 < B;                                   // wave-uniform
-    const int nbt = (Nb + 15) >> 4;                               // tiles that contain blue pixels
-    const DevConsts k = load_consts(p, tau);
-    const int sl = lane & 15, j = lane >> 4;
-    const bool svalid = (s0 + sl) < B;
-    const int srow = active ? min(sl, B - 1 - s0) : 0;
-    const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
-    const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
-    const uint8_t *mbase = bt.mask + (size_t)(active ? s0 : 0) * Npix;
-    const float *zbase = bt.zabs + (size_t)(active ? s0 : 0) * Nb;
-    const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
-    const int offN = srow * Npix, offB = srow * Nb;
-    const float4 *PF4 = reinterpret_cast<const float4 *>(PF);
-
-    f32x4 accC[C::NT], accT[C::NT], accb[C::NFT], accb2[C::NFT];
-#pragma unroll
-    for (int t = 0; t < C::NT; ++t) accC[t] = accT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < C::NFT; ++t) accb[t] = accb2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    double qd = 0.0, ld = 0.0;        // float32 inside a 4-pixel group, float64 across groups
-    float cn = 0.f, cblue = 0.f;
-    using TC = TileCopy<NF4>;
-    float4 tv0, tv1 = {0.f, 0.f, 0.f, 0.f}, tv2 = {0.f, 0.f, 0.f, 0.f}, tvx[TC::NX];
-
-    auto run = [&](auto blue_tag, int ta, int tb) {
-        constexpr bool BLUE = decltype(blue_tag)::value;
-        const int n = tb - ta;
-        if (n <= 0) return;                                       // block-uniform
-
-        auto load_spec = [&](int tg, SpecRegs1 &r) {
-            const int pb = 16 * tg + 4 * j;
-            if (pb + 3 < Npix) {
-                const f4u vd = *reinterpret_cast<const f4u *>(dbase + offN + pb);
-                const f4u ve = *reinterpret_cast<const f4u *>(ebase + offN + pb);
-                const u4u vm = *reinterpret_cast<const u4u *>(mbase + offN + pb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { r.d[e] = vd.v[e]; r.sg[e] = ve.v[e]; }
-                r.m = (unsigned)vm.v[0] | ((unsigned)vm.v[1] << 8) | ((unsigned)vm.v[2] << 16) |
-                      ((unsigned)vm.v[3] << 24);
-            } else {                                              // ragged end of the pixel axis
-                r.m = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int px = min(pb + e, Npix - 1);
-                    r.d[e] = dbase[offN + px];
-                    r.sg[e] = ebase[offN + px];
-                    r.m |= (pb + e < Npix && mbase[offN + px] != 0) ? (1u << (8 * e)) : 0u;
-                }
-            }
-            if (BLUE) {
-                if (pb + 3 < Nb) {
-                    const f4u vz = *reinterpret_cast<const f4u *>(zbase + offB + pb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r.z[e] = vz.v[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r.z[e] = zbase[offB + min(pb + e, Nb - 1)];
-                }
-            }
-        };
-
-        auto compute = [&](int tg, const SpecRegs1 &cur, const float *tile) {
-            const float *trow0 = tile + (4 * j) * C::NCPL;
-            // ---- phase 0: issue the LDS reads of K-step 0 and of the per-pixel Psi/omega pairs
-            float fbv[2][C::NFT], pbv[2][C::NT];
-            float2 po[4];
-            auto fetch = [&](int e, int slot) {
-                const float *brow = trow0 + e * C::NCPL + sl;
-#pragma unroll
-                for (int t = 0; t < C::NFT; ++t) fbv[slot][t] = brow[16 * t];
-#pragma unroll
-                for (int t = 0; t < C::NT; ++t) pbv[slot][t] = brow[C::FW + 16 * t];
-            };
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                po[e] = *reinterpret_cast<const float2 *>(trow0 + e * C::NCPL + C::PF_PSI);
-            fetch(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- phase 1: per-element weights on the VALU (the LDS reads above land meanwhile)
-            float c2[4], c3[4], cb[4], cb2[4];
-            float qd4 = 0.f, ld4 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int px = 16 * tg + 4 * j + e;
-                const bool w = svalid & (((cur.m >> (8 * e)) & 0xffu) != 0);
-                float d = cur.d[e];
-                const float sg = cur.sg[e];
-                float D, wD;
-                if (BLUE) {
-                    const bool blue = px < Nb;
-                    const BlueTerms t = blue_terms(cur.z[e], k);
-                    float Ab = t.A;
-                    if (abase) Ab = abase[offB + min(px, Nb - 1)];        // custom tau callable (rare path)
-                    const float A = blue ? Ab : 1.f;
-                    const float zdom = blue ? t.zd * po[e].y : 0.f;
-                    D = A * A * po[e].x + zdom + sg * sg;
-                    if (PREDICT) d = d - mu[min(px, Npix - 1)] * A;      // QFA/model.py:166
-                    wD = w ? fast_rcp(D) : 0.f;
-                    d = w ? d : 0.f;
-                    const float wDA = wD * A;
-                    c2[e] = wDA * A;
-                    c3[e] = c2[e] * A;
-                    cb[e] = wDA * d;
-                    cb2[e] = c2[e] * d;
-                    cblue += (w & blue) ? 1.f : 0.f;
-                } else {                                                 // red side: A = 1, no omega term
-                    D = po[e].x + sg * sg;
-                    if (PREDICT) d = d - mu[min(px, Npix - 1)];
-                    wD = w ? fast_rcp(D) : 0.f;
-                    d = w ? d : 0.f;
-                    c2[e] = wD;
-                    c3[e] = wD;
-                    cb[e] = wD * d;
-                    cb2[e] = cb[e];
-                }
-                qd4 += wD * d * d;
-                ld4 += w ? fast_log(D) : 0.f;
-                cn += w ? 1.f : 0.f;
-            }
-            qd += (double)qd4;
-            ld += (double)ld4;
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- phase 2: MFMAs of K-step e while the B operands of K-step e+1 are in flight
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (e < 3) fetch(e + 1, (e + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < C::NFT; ++t) {
-                    accb[t] = mfma4(cb[e], fbv[e & 1][t], accb[t]);
-                    if (BLUE) accb2[t] = mfma4(cb2[e], fbv[e & 1][t], accb2[t]);
-                }
-#pragma unroll
-                for (int t = 0; t < C::NT; ++t) {
-                    accC[t] = mfma4(c2[e], pbv[e & 1][t], accC[t]);
-                    if (BLUE) accT[t] = mfma4(c3[e], pbv[e & 1][t], accT[t]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-
-        // one tile: prefetch tile c+1 (parameter image -> registers, spectra -> nxt), compute tile c
-        // from LDS buffer `buf`, publish the prefetched image to the other buffer, ONE barrier.
-        auto step = [&](int c, const SpecRegs1 &cur, SpecRegs1 &nxt, int buf) {
-            const bool more = c + 1 < n;
-            if (more) {
-                TC::load(PF4 + (size_t)(ta + c + 1) * NF4, tid, tv0, tv1, tv2, tvx);
-#if QFA_ABL != 2
-                if (active) load_spec(ta + c + 1, nxt);
-#else
-                nxt = cur;
-#endif
-            }
-            if (active) compute(ta + c, cur, reinterpret_cast<const float *>(lds4[buf]));
-            if (more) TC::store(lds4[buf ^ 1], tid, tv0, tv1, tv2, tvx);
-            __syncthreads();
-        };
-
-        SpecRegs1 ra, rb;
-        TC::load(PF4 + (size_t)ta * NF4, tid, tv0, tv1, tv2, tvx);
-        TC::store(lds4[0], tid, tv0, tv1, tv2, tvx);
-        if (active) load_spec(ta, ra);
-        __syncthreads();
-        for (int c = 0; c < n; c += 2) {
-            step(c, ra, rb, 0);
-            if (c + 1 < n) step(c + 1, rb, ra, 1);
-        }
-    };
-    // Red tiles first: there A = 1, so T and b2 receive exactly what C and b receive -- the red loop
-    // issues only the C and b MFMAs (half the matrix work on ~60 % of the pixels) and T, b2 start
-    // the blue loop as copies.
-    run(std::false_type{}, max(t0, nbt), t1);
-#pragma unroll
-    for (int t = 0; t < C::NT; ++t) accT[t] = accC[t];
-#pragma unroll
-    for (int t = 0; t < C::NFT; ++t) accb2[t] = accb[t];
-    run(std::true_type{}, t0, min(t1, nbt));
-
-    if (!active) return;
-    // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4j + r, column 16t + sl
-    float *momseg = mom_segment<C::NMOM>(MOM, wp, seg, Bpad);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ss = s0 + 4 * j + r;
-        if (ss < B) {
-            float *m = momseg + (size_t)ss * C::NMOM + sl;
-#pragma unroll
-            for (int t = 0; t < C::NT; ++t) {
-                m[16 * t] = accC[t][r];
-                m[C::MOM_T + 16 * t] = accT[t][r];
-            }
-#pragma unroll
-            for (int t = 0; t < C::NFT; ++t) {
-                m[C::MOM_B + 16 * t] = accb[t][r];
-                m[C::MOM_B2 + 16 * t] = accb2[t][r];
-            }
-        }
-    }
-    qd += __shfl_xor(qd, 16); qd += __shfl_xor(qd, 32);
-    ld += __shfl_xor(ld, 16); ld += __shfl_xor(ld, 32);
-    cn += __shfl_xor(cn, 16); cn += __shfl_xor(cn, 32);
-    cblue += __shfl_xor(cblue, 16); cblue += __shfl_xor(cblue, 32);
-    if (j == 0 && svalid) {
-        float *m = momseg + (size_t)(s0 + sl) * C::NMOM + C::MOM_S;
-        m[0] = (float)qd; m[1] = (float)ld; m[2] = cn; m[3] = cblue;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_sum_segments : MOM[0] += MOM[1] + ... + MOM[nseg-1] (fixed order), float4-vectorised.
@@ -735,13 +500,14 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
     constexpr int NZR = XS3 ? 1 : 4, NZA = XS3 ? 1 : KP, NZS = XS3 ? 16 : 1;
     float Zr[NZR][NZA], pr[4];
     // (KP = 32: K = a = 32 per MFMA, 8 values per lane and piece, the two leading pieces only -- four products,
-    // <= 2^-17 each (k_grads_x and k_grads_s3 issue three, QFA_S3_TERMS): the third piece would take 16 KB of LDS per wave)
+    // <= 2^-17 each (the template argument TERMS of k_grads_s3; QFA_F_S3_FAST issues three): the third piece would take 16 KB of LDS per wave)
     using ZV = std::conditional_t<KP == 32, u32x4, u32x2>;
     constexpr int NZJ = KP == 32 ? 8 : 4;              // values of Z per lane and spectrum
     ZV Zh[NZS], Zm[NZS];
     u32x2 ph = {0u, 0u}, pm = {0u, 0u}, pl = {0u, 0u};
     bool sv[4];
-    int offN[4], offB[4];
+    unsigned rowi[4];                             // rows of the lane's four spectra in the batch arrays (qfa_common.h, batch_row); the
+    int offB[4];                                  // 64-bit element offsets are formed at the loads (this kernel is at the register limit)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int srel = 4 * g + r;
@@ -755,8 +521,8 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
         }
         pr[r] = v ? sol[C::SOL_P + col] : 0.f;
         const int sc = active ? min(srel, B - 1 - s0) : 0;
-        offN[r] = sc * Npix;
-        offB[r] = sc * Nb;
+        rowi[r] = (unsigned)batch_row(bt, (active ? s0 : 0) + sc);
+        offB[r] = sc * Nb;                          // (A_blue: batch order)
     }
     if constexpr (XS3) {
         unsigned *zl = ldszl[KP == 16 ? wv : 0];
@@ -798,10 +564,6 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
         split2(pr[2], pr[3], h1, m1, l1);
         ph = u32x2{h0, h1}; pm = u32x2{m0, m1}; pl = u32x2{l0, l1};
     }
-    const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
-    const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
-    const uint8_t *mbase = bt.mask + (size_t)(active ? s0 : 0) * Npix;
-    const float *zbase = ZF ? nullptr : bt.zabs + (size_t)(active ? s0 : 0) * Nb;
     const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
     ZFac zs[4];                                   // factored-z form: per-spectrum factors of the lane's four spectra
 #pragma unroll
@@ -835,19 +597,24 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
         };
 
         auto load_spec = [&](int tg, SpecRegs2 &rg) {
-            // unsigned 32-bit element offsets from wave-uniform bases: scalar-base + VGPR-offset loads
             const unsigned px = (unsigned)min(16 * tg + lo, Npix - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned o = (unsigned)offN[r] + px;
-                rg.d[r] = dbase[o];
-                rg.sg[r] = ebase[o];
-                rg.m[r] = mbase[o];
+                unsigned ri = rowi[r];
+                asm volatile("" : "+v"(ri));                            // keep the product out of the loop-invariant set
+                const unsigned long long o = (unsigned long long)ri * (unsigned long long)bt.row_stride + px;
+                rg.d[r] = bt.delta[o];
+                rg.sg[r] = bt.error[o];
+                rg.m[r] = bt.mask[o];
             }
             if (BLUE && !ZF) {
                 const unsigned pz = (unsigned)min(16 * tg + lo, Nb - 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rg.z[r] = zbase[(unsigned)offB[r] + pz];
+                for (int r = 0; r < 4; ++r) {
+                    unsigned ri = rowi[r];
+                    asm volatile("" : "+v"(ri));
+                    rg.z[r] = bt.zabs[(unsigned long long)ri * (unsigned)Nb + pz];
+                }
             }
         };
 

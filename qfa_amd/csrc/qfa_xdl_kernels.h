@@ -104,6 +104,23 @@ __device__ __forceinline__ void glds4a(const void *sbase, unsigned voff, unsigne
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 #endif
 }
+// The same requests from a per-lane 64-bit address (the spectra rows of the batch: qfa_common.h, batch_row / lane_ptr)
+__device__ __forceinline__ void glds16p(const void *ptr, unsigned lds_dst) {
+#if QFA_TRACKED_LOADS
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ptr,
+                                     (__attribute__((address_space(3))) void *)(size_t)__builtin_amdgcn_readfirstlane((int)lds_dst), 16, 0, 0);
+#else
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ptr), "s"(lds_dst) : "memory");
+#endif
+}
+__device__ __forceinline__ void glds4p(const void *ptr, unsigned lds_dst) {
+#if QFA_TRACKED_LOADS
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ptr,
+                                     (__attribute__((address_space(3))) void *)(size_t)__builtin_amdgcn_readfirstlane((int)lds_dst), 4, 0, 0);
+#else
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(ptr), "s"(lds_dst) : "memory");
+#endif
+}
 // N consecutive 1-KiB pieces (global and LDS both contiguous) behind ONE write of M0: the instruction's immediate offset
 // moves the global address and the LDS address together.  (A write of M0 behind an LDS-DMA waits until the texture path has
 // accepted that request -- ~150 cycles per piece when every piece sets M0 itself, tools/gt_stamps.sh.)  The offsets are
@@ -256,6 +273,14 @@ __device__ __forceinline__ void aload16(f32x4 &dst, const void *sbase, unsigned 
 __device__ __forceinline__ void aload8(u32x2 &dst, const void *sbase, unsigned voff) {
     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
+// the same loads from a per-lane 64-bit address (the spectra rows: qfa_common.h, lane_ptr)
+template <int OFF>
+__device__ __forceinline__ void aload16p(f32x4 &dst, const void *ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void aload8p(u32x2 &dst, const void *ptr) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
 __device__ __forceinline__ void aload4(float &dst, const void *sbase, unsigned voff) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
@@ -333,16 +358,14 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
     const int sl = lane & 15, g = lane >> 4;
     const bool svalid = (s0 + sl) < B;
     const int srow = active ? min(sl, B - 1 - s0) : 0;
-    const float *dbase = bt.delta + (size_t)(active ? s0 : 0) * Npix;
-    const float *ebase = bt.error + (size_t)(active ? s0 : 0) * Npix;
-    const uint8_t *mbase = bt.mask + (size_t)(active ? s0 : 0) * Npix;
-    const float *zbase = ZF ? nullptr : bt.zabs + (size_t)(active ? s0 : 0) * Nb;
-    const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;
-    const int offN = srow * Npix, offB = srow * Nb;
+    // the lane's spectrum is row `rowi` of the batch arrays (qfa_common.h, batch_row): per-lane 64-bit element offsets of
+    // its 8 pixels of tile 0; the wave-uniform part of an address is array base + 32 * tile (SGPRs)
+    const unsigned long long rowi = batch_row(bt, (active ? s0 : 0) + srow);
+    const unsigned long long eoN = rowi * (unsigned long long)bt.row_stride + (unsigned)(8 * g);
+    const unsigned long long eoB = ZF ? 0ull : rowi * (unsigned long long)(unsigned)Nb + (unsigned)(8 * g);
+    const float *abase = bt.A_blue ? bt.A_blue + (size_t)(active ? s0 : 0) * Nb : nullptr;      // (batch order: not indexed)
+    const int offB = srow * Nb;
     const ZFac zs = zfac_load(ZS, s0 + sl, ZF && svalid);
-    // per-lane byte offsets of the fast-path loads (base = the wave's row block + 32 * tile, in SGPRs)
-    const unsigned voffN = (unsigned)(offN + 8 * g) * 4u, voffB = (unsigned)(offB + 8 * g) * 4u,
-                   voffM = (unsigned)(offN + 8 * g);
 
 #if QFA_P1_STAMPS
     unsigned st_[16];
@@ -385,20 +408,21 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         auto load_spec = [&](int tg, SpecRegsX &r) {
             const int pb = 32 * tg + 8 * g;
             if (!QFA_TRACKED_LOADS && pb + 7 < Npix) {
-                aload16<0>(r.d0, dbase + 32 * tg, voffN);
-                aload16<16>(r.d1, dbase + 32 * tg, voffN);
-                aload16<0>(r.s0, ebase + 32 * tg, voffN);
-                aload16<16>(r.s1, ebase + 32 * tg, voffN);
-                aload8(r.m, mbase + 32 * tg, voffM);
+                const unsigned char *pd = lane_ptr<2>(bt.delta + 32 * tg, eoN), *pe = lane_ptr<2>(bt.error + 32 * tg, eoN);
+                aload16p<0>(r.d0, pd);
+                aload16p<16>(r.d1, pd);
+                aload16p<0>(r.s0, pe);
+                aload16p<16>(r.s1, pe);
+                aload8p(r.m, lane_ptr<0>(bt.mask + 32 * tg, eoN));
             } else {                                              // ragged end of the pixel axis (ordinary loads)
                 unsigned m0 = 0, m1 = 0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int px = min(pb + e, Npix - 1);
-                    const float dv = dbase[offN + px], sv = ebase[offN + px];
+                    const unsigned long long o = eoN + (unsigned long long)(long long)(min(pb + e, Npix - 1) - 8 * g);
+                    const float dv = bt.delta[o], sv = bt.error[o];
                     if (e < 4) { r.d0[e] = dv; r.s0[e] = sv; }
                     else { r.d1[e - 4] = dv; r.s1[e - 4] = sv; }
-                    const unsigned bit = (pb + e < Npix && mbase[offN + px] != 0) ? (1u << (8 * (e & 3))) : 0u;
+                    const unsigned bit = (pb + e < Npix && bt.mask[o] != 0) ? (1u << (8 * (e & 3))) : 0u;
                     if (e < 4) m0 |= bit;
                     else m1 |= bit;
                 }
@@ -410,12 +434,13 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             }
             if (BLUE && !ZF) {
                 if (!QFA_TRACKED_LOADS && pb + 7 < Nb) {
-                    aload16<0>(r.z0, zbase + 32 * tg, voffB);
-                    aload16<16>(r.z1, zbase + 32 * tg, voffB);
+                    const unsigned char *pz = lane_ptr<2>(bt.zabs + 32 * tg, eoB);
+                    aload16p<0>(r.z0, pz);
+                    aload16p<16>(r.z1, pz);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float zv = zbase[offB + min(pb + e, Nb - 1)];
+                        const float zv = bt.zabs[eoB + (unsigned long long)(long long)(min(pb + e, Nb - 1) - 8 * g)];
                         if (e < 4) r.z0[e] = zv;
                         else r.z1[e - 4] = zv;
                     }

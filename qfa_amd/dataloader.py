@@ -10,6 +10,15 @@ the smoothed mean continuum ``mu`` -- runs in HIP kernels (``qfa_build_batch_f32
 ``qfa_mu_estimate_f64``).  Reading spectra from disk and the catalogue selection (row N3) are host code in ``qfa_amd.io``
 (``from_files`` / ``from_catalog`` below).
 
+The resident, indexed input form (ABI v3, include/qfa_hip.h ``qfa_batch_t.rows`` / ``row_stride``).  The reference
+recomputes ``delta`` and re-uploads four arrays for EVERY batch (QFA/dataloader.py:124-138) although delta depends on
+``mu`` and ``tau`` only, and shuffles an epoch by permuting the whole data set on the host (:154-167).  Here ``delta`` and the
+mask are built ONCE (``qfa_build_resident_f32``; again in ``set_tau``), every row padded to a multiple of 32 pixels (128-byte
+row starts), and an epoch is one permutation uploaded by ``rewind()``: ``next_batch_rows()`` returns a ``ResidentBatch`` --
+the resident arrays plus a slice of that permutation -- which ``QFA.step(batch=...)`` hands to the kernels as it is.  No
+per-step kernel, copy or host transfer; ``QFA.train`` takes this path by itself.  ``next_batch()`` still materialises the
+reference's 4-tuple for callers that want tensors.
+
 Data parallelism (no counterpart in the reference): ``DeviceDataloader(..., rank=r, world=w,
 seed=s)`` keeps only rank r's contiguous shard of the spectra in HBM, draws the epoch order from
 ``qfa_amd.distributed.ShardPlan`` (shared seed, disjoint shards, the SAME number of steps on every rank -- an
@@ -70,8 +79,18 @@ class DeviceDataloader(object):
             flux, error, zqso = flux[lo:hi], error[lo:hi], zqso[lo:hi]
             paths = paths[lo:hi] if paths is not None else None
         self._row0 = lo                                         # global index of the first resident row
-        self.flux = torch.as_tensor(flux, device=self.device).contiguous()
-        self.error = torch.as_tensor(error, device=self.device).contiguous()
+        # resident storage: rows padded to a multiple of 32 pixels, so that every row starts on a 128-byte line (the kernels
+        # move 128-byte row segments; N_pix = 1913 / 9243 -- the reference's two models -- are no multiple of 32)
+        self._stride = (self.Npix + 31) // 32 * 32
+        def padded(a):
+            n = a.shape[0]
+            if self._stride == self.Npix:
+                return torch.as_tensor(np.ascontiguousarray(a), device=self.device)
+            t = torch.zeros((n, self._stride), dtype=f32, device=self.device)
+            t[:, :self.Npix] = torch.as_tensor(np.ascontiguousarray(a), device=self.device)
+            return t
+        self._flux_pad, self._error_pad = padded(flux), padded(error)
+        self.flux, self.error = self._flux_pad[:, :self.Npix], self._error_pad[:, :self.Npix]      # (views)
         self.zqso = zqso
         self.data_size = n_global                               # what QFA.train divides by (model.py:205)
         self.local_size = int(self.flux.shape[0])
@@ -87,10 +106,15 @@ class DeviceDataloader(object):
         self._epoch = -1
         self._steps = None                                      # DP: list of local row arrays of the current epoch
         self._order = np.arange(self.local_size)
+        self._order_dev = None                                  # the epoch's row order on the device (int32), uploaded by rewind()
+        self._step_off = None                                   # DP: offsets of the steps inside _order_dev
         self.cur = 0
         self._window = int(window_length_for_mu)
         self._mu_raw, self._mu = self._estimate_mu(self._window)
         self._mu_dev = torch.as_tensor(self._mu, device=self.device)
+        self._delta_pad = self._mask_pad = None
+        self._build_resident()
+        self._upload_order()
 
     # ------------------------------------------------------------------ from disk (row N3)
     @classmethod
@@ -126,9 +150,9 @@ class DeviceDataloader(object):
         sm = torch.empty(self.Npix, dtype=torch.float64, device=self.device)
         if self.local_size > 0:
             _lib.check(h.qfa_mu_sums_f64(
-                C.c_void_p(self.flux.data_ptr()), C.c_void_p(self.error.data_ptr()), C.c_void_p(self._zq_dev.data_ptr()),
-                C.c_void_p(self._wav_dev.data_ptr()), float(self.wav_grid[0]), self._which, self.local_size, self.Npix,
-                self.Nb, C.c_void_p(scratch.data_ptr()), st), "qfa_mu_sums_f64")
+                C.c_void_p(self._flux_pad.data_ptr()), C.c_void_p(self._error_pad.data_ptr()),
+                C.c_void_p(self._zq_dev.data_ptr()), C.c_void_p(self._wav_dev.data_ptr()), float(self.wav_grid[0]), self._which,
+                self.local_size, self.Npix, self.Nb, self._stride, C.c_void_p(scratch.data_ptr()), st), "qfa_mu_sums_f64")
         if self.world > 1:
             from .distributed import all_reduce_
             all_reduce_(scratch, self.group)
@@ -140,8 +164,74 @@ class DeviceDataloader(object):
     def mu(self):
         return self._mu
 
+    # ------------------------------------------------------------------ resident form
+    def _build_resident(self):
+        """delta = flux - mu exp(-tau_total) and the mask of EVERY resident row, once (reference QFA/dataloader.py:29,135-136
+        per batch); called again when mu / tau change (set_tau)."""
+        n = self.local_size
+        self._delta_pad = torch.empty((n, self._stride), dtype=f32, device=self.device)
+        self._mask_pad = torch.empty((n, self._stride), dtype=torch.bool, device=self.device)
+        self._zq1_res = torch.empty((n,), dtype=f32, device=self.device)
+        if n == 0:
+            return
+        _lib.check(_lib.lib().qfa_build_resident_f32(
+            C.c_void_p(self._flux_pad.data_ptr()), C.c_void_p(self._error_pad.data_ptr()), C.c_void_p(self._zq_dev.data_ptr()),
+            C.c_void_p(self._wav_dev.data_ptr()), float(self.wav_grid[0]), C.c_void_p(self._mu_dev.data_ptr()), self._which,
+            n, self.Npix, self.Nb, self._stride, C.c_void_p(self._delta_pad.data_ptr()), C.c_void_p(self._mask_pad.data_ptr()),
+            C.c_void_p(self._zq1_res.data_ptr()), _lib.current_stream(self.device)), "qfa_build_resident_f32")
+
+    def _upload_order(self):
+        """the epoch's row order as ONE int32 device array (batches are contiguous slices of it)"""
+        if self._plan is not None and self._steps is not None:
+            lens = [len(r) for r in self._steps]
+            self._step_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            flat = np.concatenate(self._steps).astype(np.int32) if sum(lens) else np.zeros((0,), dtype=np.int32)
+        else:
+            self._step_off = None
+            flat = np.asarray(self._order, dtype=np.int32)
+        self._order_dev = torch.as_tensor(flat, device=self.device)
+
+    def rows_view(self, rows):
+        """``ResidentBatch`` of the given int32 device tensor of LOCAL row numbers (no copy)"""
+        from .resident import ResidentBatch
+        return ResidentBatch(self._flux_pad, self._delta_pad, self._error_pad, self._mask_pad, self._zq1_res, self._pix_ratio,
+                             rows, self.Npix, self.Nb)
+
+    def _next_slice(self):
+        """[start, end) of the next batch inside _order_dev; advances the cursor"""
+        if self._plan is not None:
+            if self._steps is None:
+                self.rewind()
+            a, b = int(self._step_off[self.cur]), int(self._step_off[self.cur + 1])
+            self.cur += 1
+            return a, b
+        start = self.cur
+        end = min(self.cur + self.batch_size, self.local_size)
+        self.cur = end
+        return start, end
+
+    def next_batch_rows(self):
+        """The next batch in the resident, indexed form: a ``ResidentBatch`` whose rows are a slice of the epoch's
+        permutation on the device.  Same rows, same order as ``next_batch()`` would return (reference
+        QFA/dataloader.py:124-138); nothing is launched or copied.  Under data parallelism: this rank's part (possibly empty)."""
+        a, b = self._next_slice()
+        return self.rows_view(self._order_dev[a:b])
+
+    def next_rows_into(self, buf):
+        """copy the row numbers of the next batch into the caller's fixed int32 device buffer (a captured step graph reads it)"""
+        a, b = self._next_slice()
+        if b - a != buf.shape[0]:
+            raise _lib.QFAHipError(f"next batch has {b - a} rows, the buffer {buf.shape[0]}")
+        buf.copy_(self._order_dev[a:b])
+
+    def rows_batch(self, lo, hi):
+        """``ResidentBatch`` of the resident rows [lo, hi) in storage order, and their paths (the batched predict writer)"""
+        lo, hi = max(int(lo), 0), min(int(hi), self.local_size)
+        rows = torch.arange(lo, max(hi, lo), dtype=torch.int32, device=self.device)
+        return self.rows_view(rows), self.pathlist[lo:max(hi, lo)]
+
     # ------------------------------------------------------------------ batches
-    def _build(self, rows, out=None):
+    def _build(self, rows, out=None, idx=None):
         """rows: LOCAL row indices (into this rank's resident spectra)"""
         n = len(rows)
         if n == 0:                                            # an exhausted rank's step under data parallelism
@@ -149,7 +239,8 @@ class DeviceDataloader(object):
                     torch.empty((0, self.Npix), dtype=f32, device=self.device),
                     torch.empty((0, self.Nb), dtype=f32, device=self.device),
                     torch.empty((0, self.Npix), dtype=torch.bool, device=self.device))
-        idx = torch.as_tensor(np.asarray(rows, dtype=np.int32), device=self.device)
+        if idx is None:                                       # (next_batch passes a slice of the epoch's order on the device)
+            idx = torch.as_tensor(np.asarray(rows, dtype=np.int32), device=self.device)
         if out is not None:                                   # caller-owned buffers (a captured step graph reads them)
             delta, err, zabs, mask = out
             if tuple(delta.shape) != (n, self.Npix) or tuple(zabs.shape) != (n, self.Nb):
@@ -160,10 +251,10 @@ class DeviceDataloader(object):
             zabs = torch.empty((n, self.Nb), dtype=f32, device=self.device)
             mask = torch.empty((n, self.Npix), dtype=torch.bool, device=self.device)
         _lib.check(_lib.lib().qfa_build_batch_f32(
-            C.c_void_p(self.flux.data_ptr()), C.c_void_p(self.error.data_ptr()), C.c_void_p(self._zq_dev.data_ptr()),
+            C.c_void_p(self._flux_pad.data_ptr()), C.c_void_p(self._error_pad.data_ptr()), C.c_void_p(self._zq_dev.data_ptr()),
             C.c_void_p(idx.data_ptr()), C.c_void_p(self._wav_dev.data_ptr()), float(self.wav_grid[0]),
-            C.c_void_p(self._mu_dev.data_ptr()), self._which, n, self.Npix, self.Nb, C.c_void_p(delta.data_ptr()),
-            C.c_void_p(err.data_ptr()), C.c_void_p(zabs.data_ptr()) if self.Nb > 0 else None,
+            C.c_void_p(self._mu_dev.data_ptr()), self._which, n, self.Npix, self.Nb, self._stride,
+            C.c_void_p(delta.data_ptr()), C.c_void_p(err.data_ptr()), C.c_void_p(zabs.data_ptr()) if self.Nb > 0 else None,
             C.c_void_p(mask.data_ptr()), _lib.current_stream(self.device)), "qfa_build_batch_f32")
         if self.factored_z and out is None and self.Nb > 0:
             # QFA.forward / step / predict look for this attribute on the zabs tensor they are handed (the 4-tuple of the
@@ -182,16 +273,9 @@ class DeviceDataloader(object):
         """delta, error, zabs, mask of the next batch (reference QFA/dataloader.py:124-138); ``out`` = four
         caller-owned tensors of the batch's shape to build into.  Under data parallelism: this rank's part of the
         global batch (possibly empty)."""
-        if self._plan is not None:
-            if self._steps is None:
-                self.rewind()
-            rows = self._steps[self.cur]
-            self.cur += 1
-            return self._build(rows, out)
-        start = self.cur
-        end = min(self.cur + self.batch_size, self.local_size)
-        self.cur = end
-        return self._build(self._order[start:end], out)
+        a, b = self._next_slice()
+        rows = self._steps[self.cur - 1] if self._plan is not None else self._order[a:b]
+        return self._build(rows, out, idx=self._order_dev[a:b] if b > a else None)
 
     def next_batch_size(self):
         if self._plan is not None:
@@ -206,6 +290,7 @@ class DeviceDataloader(object):
             self._steps = [r - self._row0 for r in self._plan.epoch_rows(self._epoch)]
         elif self.shuffle:
             np.random.shuffle(self._order)
+        self._upload_order()
         self.cur = 0
 
     def sample(self):
@@ -231,6 +316,7 @@ class DeviceDataloader(object):
         self._which = _lib.TAU_IDS[which]
         self._mu_raw, self._mu = self._estimate_mu(self._window)
         self._mu_dev = torch.as_tensor(self._mu, device=self.device)
+        self._build_resident()                                  # delta of every resident row follows mu and tau
 
     def __len__(self):
         return self.local_size

@@ -194,6 +194,44 @@ class QFA(object):
             bs.A_blue = _lib.require_device_tensor(a, f32, "A_blue").value
         return bs, keep
 
+    def _batch_struct_rows(self, rb, raw_flux=False):
+        """qfa_batch_t of a ``ResidentBatch`` (qfa_amd/resident.py; ABI v3 rows / row_stride): pointers to the WHOLE resident
+        arrays plus the device array of row numbers -- no gather, no copy.  ``raw_flux``: the predict call (delta = raw flux)."""
+        if self._tau_callable is not None:
+            raise _lib.QFAHipError("a custom tau callable is evaluated on materialised zabs: use the 4-tensor form")
+        if rb.Npix != self.Npix or rb.Nb != self.Nb:
+            raise _lib.QFAHipError(f"resident batch of shape (.., {rb.Npix}), Nb = {rb.Nb}; the model has ({self.Npix}, {self.Nb})")
+        src = rb.flux if raw_flux else rb.delta
+        if src is None:
+            raise _lib.QFAHipError("resident batch without " + ("flux" if raw_flux else "delta"))
+        N, stride = int(rb.error.shape[0]), int(rb.stride)
+        for t, name, dt in ((src, "delta", f32), (rb.error, "error", f32), (rb.mask, "mask", torch.bool)):
+            if tuple(t.shape) != (N, stride) or stride < self.Npix:
+                raise _lib.QFAHipError(f"resident {name}: shape {tuple(t.shape)}, expected ({N}, {stride} >= {self.Npix})")
+        if rb.rows.dtype != torch.int32:
+            raise _lib.QFAHipError(f"rows: dtype {rb.rows.dtype}, expected torch.int32")
+        bs = _lib.Batch()
+        bs.delta = _lib.require_device_tensor(src, f32, "delta").value
+        bs.error = _lib.require_device_tensor(rb.error, f32, "error").value
+        bs.mask = _lib.require_device_tensor(rb.mask, torch.bool, "mask").value
+        bs.rows = _lib.require_device_tensor(rb.rows, torch.int32, "rows").value
+        bs.row_stride = stride
+        bs.A_blue = None
+        bs.zabs = bs.zq1 = bs.pix_ratio = None
+        if self.Nb > 0:
+            if rb.zq1 is not None and self.use_factored_z:
+                if tuple(rb.zq1.shape) != (N,) or tuple(rb.pix_ratio.shape) != (self.Nb,):
+                    raise _lib.QFAHipError(f"resident zq1 / pix_ratio: shapes {tuple(rb.zq1.shape)}, {tuple(rb.pix_ratio.shape)}")
+                bs.zq1 = _lib.require_device_tensor(rb.zq1, f32, "zq1").value
+                bs.pix_ratio = _lib.require_device_tensor(rb.pix_ratio, f32, "pix_ratio").value
+            elif rb.zabs is not None:
+                if tuple(rb.zabs.shape) != (N, self.Nb):
+                    raise _lib.QFAHipError(f"resident zabs: shape {tuple(rb.zabs.shape)}, expected ({N}, {self.Nb})")
+                bs.zabs = _lib.require_device_tensor(rb.zabs, f32, "zabs").value
+            else:
+                raise _lib.QFAHipError("resident batch carries neither zabs nor usable (zq1, pix_ratio)")
+        return bs, [rb]
+
     def _workspace(self, B):
         need = _lib.lib().qfa_workspace_bytes(int(B), self.Npix, self.Nh)
         if need == 0:
@@ -273,13 +311,19 @@ class QFA(object):
                                    "sync_replicas(optimizer) after random_init_func / load_* on every rank")
         self._dp_checked = True
 
-    def accumulate(self, delta, error, zabs, mask, accum=None, nll=None, events=None, zfac=None):
+    def accumulate(self, delta=None, error=None, zabs=None, mask=None, accum=None, nll=None, events=None, zfac=None,
+                   batch=None):
         """Raw sums of one (shard of a) batch into the packed buffer; no normalisation.
         ``events``: optional list of 5 recorded torch.cuda.Event(enable_timing=True) that the library
-        re-records at {start, PF image, pass 1, solve, pass 2} on the current stream (bench.py)."""
-        B = self._check_batch_shapes(delta, error, zabs, mask)
+        re-records at {start, PF image, pass 1, solve, pass 2} on the current stream (bench.py).
+        ``batch``: a ``ResidentBatch`` in the place of the four tensors (the resident, indexed input form)."""
         ps = self._params_struct()
-        bs, keep = self._batch_struct(delta, error, zabs, mask, zfac)
+        if batch is not None:
+            B = batch.B
+            bs, keep = self._batch_struct_rows(batch)
+        else:
+            B = self._check_batch_shapes(delta, error, zabs, mask)
+            bs, keep = self._batch_struct(delta, error, zabs, mask, zfac)
         ws = self._workspace(B)
         acc = self._accum() if accum is None else accum
         evs = None
@@ -317,15 +361,16 @@ class QFA(object):
         return loss, g
 
     # ------------------------------------------------------------------ reference surface
-    def forward(self, delta: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor,
-                events=None, zfac=None):
-        """Batch loss (1,1) and count-normalised gradient dict (reference QFA/model.py:74-105)."""
-        if delta.shape[0] == 0:
+    def forward(self, delta: torch.Tensor = None, error: torch.Tensor = None, zabs: torch.Tensor = None,
+                mask: torch.Tensor = None, events=None, zfac=None, batch=None):
+        """Batch loss (1,1) and count-normalised gradient dict (reference QFA/model.py:74-105).
+        ``batch``: a ``ResidentBatch`` in the place of the four tensors."""
+        if (batch.B if batch is not None else delta.shape[0]) == 0:
             if not self._dp:
                 raise _lib.QFAHipError("forward: empty batch")
             acc = self._accum()                         # an exhausted rank adds zeros to the global sums and counts
         else:
-            acc = self.accumulate(delta, error, zabs, mask, events=events, zfac=zfac)
+            acc = self.accumulate(delta, error, zabs, mask, events=events, zfac=zfac, batch=batch)
         if self._dp:
             from .distributed import all_reduce_accum
             all_reduce_accum(acc, self._dp_group)
@@ -337,17 +382,21 @@ class QFA(object):
         acc = self.accumulate(delta[None, :], error[None, :], zabs[None, :], mask[None, :])
         return self._finalize(acc, False)
 
-    def predict(self, flux: torch.Tensor, error: torch.Tensor, zabs: torch.Tensor, mask: torch.Tensor, events=None,
-                out=None, zfac=None):
+    def predict(self, flux: torch.Tensor = None, error: torch.Tensor = None, zabs: torch.Tensor = None,
+                mask: torch.Tensor = None, events=None, out=None, zfac=None, batch=None):
         """Batched posterior prediction: ll (B,), hmean (B,Nh), hcov (B,Nh,Nh), cont (B,Npix),
         unc (B,Npix) (reference QFA/model.py:160-180 applied to every row).  ``events``: optional list of 4 recorded
         torch.cuda.Event(enable_timing=True), re-recorded at {start, images + pass 1, solve, continuum writer};
         ``out``: the five output tensors to write into (bench.py re-uses them)."""
         if self.mu is None:
             raise _lib.QFAHipError("predict needs model.mu (load_from_npz or train first)")
-        B = self._check_batch_shapes(flux, error, zabs, mask)
         ps = self._params_struct()
-        bs, keep = self._batch_struct(flux, error, zabs, mask, zfac)
+        if batch is not None:                                   # a ResidentBatch: rows of the resident flux / error / mask
+            B = batch.B
+            bs, keep = self._batch_struct_rows(batch, raw_flux=True)
+        else:
+            B = self._check_batch_shapes(flux, error, zabs, mask)
+            bs, keep = self._batch_struct(flux, error, zabs, mask, zfac)
         mu = self.mu.to(device=self.device, dtype=f32).contiguous()
         ws = self._workspace(B)
         dev = self.device
@@ -382,13 +431,18 @@ class QFA(object):
         n = len(dataloader)
         written = []
         for s in range(0, n, batch_size):
-            if hasattr(dataloader, "get_rows"):                  # one launch for the whole slice
+            if hasattr(dataloader, "rows_batch") and self._tau_callable is None:     # rows of the resident arrays: no copy
+                rb, paths = dataloader.rows_batch(s, min(s + batch_size, n))
+                res = self.predict(batch=rb)
+            elif hasattr(dataloader, "get_rows"):                # one launch for the whole slice
                 f, e, z, m, paths = dataloader.get_rows(s, min(s + batch_size, n))
+                res = self.predict(f, e, z, m)
             else:                                                # the reference's per-spectrum contract
                 items = [dataloader[i] for i in range(s, min(s + batch_size, n))]
                 f, e, z, m = (torch.stack([it[j] for it in items]) for j in range(4))
                 paths = [it[4] for it in items]
-            ll, hmean, hcov, cont, unc = (x.cpu().numpy() for x in self.predict(f, e, z, m))
+                res = self.predict(f, e, z, m)
+            ll, hmean, hcov, cont, unc = (x.cpu().numpy() for x in res)
             for r, path in enumerate(paths):
                 name = os.path.basename(str(path))
                 if not name.endswith(".npz"):
@@ -431,18 +485,18 @@ class QFA(object):
         ll, hmean, hcov, cont, unc = self.predict(flux[None, :], error[None, :], zabs[None, :], mask[None, :])
         return ll.reshape(1, 1), hmean.reshape(self.Nh, 1), hcov[0], cont[0], unc[0]
 
-    def step(self, optimizer, delta, error, zabs, mask, events=None, zfac=None):
+    def step(self, optimizer, delta=None, error=None, zabs=None, mask=None, events=None, zfac=None, batch=None):
         """forward -> Adam.update -> clip, all on device, no host sync (model.py:212-214, 316).
-        Returns the (1,1) loss tensor."""
-        loss, grads = self.forward(delta, error, zabs, mask, events=events, zfac=zfac)
+        Returns the (1,1) loss tensor.  ``batch``: a ``ResidentBatch`` in the place of the four tensors."""
+        loss, grads = self.forward(delta, error, zabs, mask, events=events, zfac=zfac, batch=batch)
         new = optimizer.update(self.parameters, grads, clip=self._clip_table())
         for k in PARAM_KEYS:
             setattr(self, k, new[k])
         return loss
 
-    def step_graph(self, optimizer, batch_size):
+    def step_graph(self, optimizer, batch_size, resident=None):
         """A captured hipGraph of one training step for batches of ``batch_size`` spectra (StepGraph)."""
-        return StepGraph(self, optimizer, batch_size)
+        return StepGraph(self, optimizer, batch_size, resident=resident)
 
     def train(self, optimizer, dataloader, n_epochs, output_dir="./result", save_interval=5, smooth_interval=5,
               quiet=False, logger=None, use_graph=False):
@@ -466,7 +520,13 @@ class QFA(object):
             self.check_replicas(optimizer)
         # the captured step graph is a single-process tool (launch-bound small batches); under data parallelism the
         # per-rank batch is large (c4: 125 000 spectra) and the collective stays an eager RCCL call
-        sg = self.step_graph(optimizer, dataloader.batch_size) if (use_graph and not self._dp) else None
+        # A loader that keeps the data set resident (DeviceDataloader.next_batch_rows) hands over row numbers instead of a
+        # materialised copy of every batch (the reference rebuilds delta per batch on the host, dataloader.py:124-138, although
+        # it depends on mu and tau only); a custom tau callable needs the materialised zabs
+        resident = hasattr(dataloader, "next_batch_rows") and self._tau_callable is None
+        sg = None
+        if use_graph and not self._dp:
+            sg = StepGraph(self, optimizer, dataloader.batch_size, resident=dataloader if resident else None)
         # Side effects under data parallelism: the replicas are identical, so ONE rank prints, logs and writes the
         # checkpoints (concurrent np.savez of the same path from every rank can interleave into a corrupt zip); the
         # others wait at a barrier so that nobody reads a half-written file.
@@ -489,6 +549,8 @@ class QFA(object):
             while dataloader.have_next_batch():
                 if sg is not None and sg.fits(dataloader):
                     loss = sg.run_next(dataloader)
+                elif resident:
+                    loss = self.step(optimizer, batch=dataloader.next_batch_rows())
                 else:
                     d, e, z, m = dataloader.next_batch()
                     loss = self.step(optimizer, d, e, z, m)
@@ -554,26 +616,41 @@ class StepGraph(object):
     kernel arguments by value, so the graph is re-captured when they (or a parameter tensor) change -- once per
     epoch in ``QFA.train``.  The first step after such a change runs eagerly (it also warms the workspace up)."""
 
-    def __init__(self, model, optimizer, batch_size):
+    def __init__(self, model, optimizer, batch_size, resident=None):
+        """``resident``: a loader with the resident form (``next_rows_into`` / ``rows_view``): the graph then reads the
+        loader's resident arrays through ONE fixed buffer of row numbers, refilled per step by a device-side copy of
+        4 B bytes, instead of four batch-sized input buffers."""
         self.model, self.opt, self.B = model, optimizer, int(batch_size)
         dev = model.device
-        self.buf = (torch.empty((self.B, model.Npix), dtype=f32, device=dev),
-                    torch.empty((self.B, model.Npix), dtype=f32, device=dev),
-                    torch.empty((self.B, model.Nb), dtype=f32, device=dev),
-                    torch.empty((self.B, model.Npix), dtype=torch.bool, device=dev))
+        self.resident = resident
+        if resident is not None:
+            self.rows = torch.zeros((self.B,), dtype=torch.int32, device=dev)
+            self.buf = None
+        else:
+            self.buf = (torch.empty((self.B, model.Npix), dtype=f32, device=dev),
+                        torch.empty((self.B, model.Npix), dtype=f32, device=dev),
+                        torch.empty((self.B, model.Nb), dtype=f32, device=dev),
+                        torch.empty((self.B, model.Npix), dtype=torch.bool, device=dev))
         self.graph, self.key, self.loss = None, None, None
         self.replays = 0
+
+    @property
+    def rb(self):
+        """the loader's resident arrays (as they are NOW: set_tau rebuilds them) seen through the fixed buffer of row numbers"""
+        return self.resident.rows_view(self.rows)
 
     def _key(self):
         # everything the captured launches bake in: scalars passed by value and every buffer address
         m, o = self.model, self.opt
         return ((o.i, float(o.scheduled_lr), float(o.b1), float(o.b2), float(o.eps), float(o.weight_decay))
                 + tuple(getattr(m, k).data_ptr() for k in PARAM_KEYS)
-                + tuple(o.m[k].data_ptr() for k in PARAM_KEYS) + tuple(o.v[k].data_ptr() for k in PARAM_KEYS))
+                + tuple(o.m[k].data_ptr() for k in PARAM_KEYS) + tuple(o.v[k].data_ptr() for k in PARAM_KEYS)
+                + (tuple(t.data_ptr() for t in (self.rb.delta, self.rb.error, self.rb.mask, self.rb.zq1))
+                   if self.resident is not None else ()))
 
     def _body(self):
         m = self.model
-        loss, grads = m.forward(*self.buf)
+        loss, grads = m.forward(batch=self.rb) if self.resident is not None else m.forward(*self.buf)
         self.opt.update(m.parameters, grads, clip=m._clip_table(), inplace=True)
         return loss
 
@@ -582,6 +659,11 @@ class StepGraph(object):
         return n is None or n == self.B
 
     def _fill(self, dataloader):
+        if self.resident is not None:
+            if dataloader is not self.resident:
+                raise _lib.QFAHipError("StepGraph(resident=loader) replays batches of that loader only")
+            dataloader.next_rows_into(self.rows)
+            return True
         if hasattr(dataloader, "next_batch_size"):
             dataloader.next_batch(out=self.buf)
             return True
