@@ -175,6 +175,72 @@ def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
             "call_hbm_frac": (B / dt) * by_total / (PEAK_HBM_GBS * 1e9), "alg_bytes_per_spectrum": by_total}
 
 
+def epoch_leg(params, mu, wav, nb, nr, nh, B, masks, dev, seed, n_batches, epochs, use_graph, rank=0, world=1):
+    """Throughput of whole training EPOCHS through the product's own loop: ``QFA.train`` over a ``DeviceDataloader`` that
+    holds ``n_batches`` x B spectra resident (delta / mask built once, rows padded to 128 bytes), reshuffled every epoch
+    (reference QFA/dataloader.py:154-167, QFA/model.py:204-215), every batch handed to the kernels as row numbers (ABI v3,
+    qfa_amd/resident.py).  Includes everything an epoch costs: the shuffle and its upload, Adam, the scheduler step, the one
+    host synchronisation per epoch.  The data set differs from the step legs' batch (same generator, other seeds)."""
+    import tempfile
+    import torch
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+    from qfa_amd.dataloader import DeviceDataloader
+    npix, N = len(wav), n_batches * B
+    flux = torch.empty((N, npix), dtype=torch.float32, device=dev)
+    error = torch.empty((N, npix), dtype=torch.float32, device=dev)
+    zq = torch.empty((N,), dtype=torch.float32, device=dev)
+    slab = 25000
+    for i, s0 in enumerate(range(0, N, slab)):
+        n = min(slab, N - s0)
+        f, e, z = synthetic.make_batch_torch(params, mu, wav, nb, n, seed + 31 * i, dev, masks=masks, return_flux=True)
+        flux[s0:s0 + n], error[s0:s0 + n], zq[s0:s0 + n] = f, e, z
+        del f, e, z
+    t_b = time.perf_counter()
+    dl = DeviceDataloader(flux, error, zq, wav, B, dev, tau="becker", shuffle=True)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_b
+    del flux, error
+    torch.cuda.empty_cache()
+    model = QFA(nb, nr, nh, dev, model_params=params)
+    opt = Adam(model.parameters, dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3, weight_decay=1e-1)
+    big = 10 ** 9
+    with tempfile.TemporaryDirectory() as td:
+        model.train(opt, dl, 1, output_dir=td, save_interval=big, smooth_interval=big, quiet=True, use_graph=use_graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.train(opt, dl, epochs, output_dir=td, save_interval=big, smooth_interval=big, quiet=True, use_graph=use_graph)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    steps = epochs * n_batches
+    # one indexed step alone, with the library's stage events (a full batch of the current shuffled order)
+    import numpy as np
+    def one_step(rb):
+        for _ in range(3):
+            model.step(opt, batch=rb)
+        sev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(10)]
+        for es in sev:
+            for e in es:
+                e.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for es in sev:
+            model.step(opt, batch=rb, events=es)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / len(sev)
+        sst = np.array([[es[j].elapsed_time(es[j + 1]) for j in range(4)] for es in sev]).mean(axis=0)
+        return {"ms_per_step": dt1 * 1e3, "stage_ms": {"pf_image": float(sst[0]), "pass1_moments": float(sst[1]),
+                                                        "solve": float(sst[2]), "pass2_grads": float(sst[3])}}
+    dl.rewind()
+    indexed = one_step(dl.next_batch_rows())
+    # the same kernels on B consecutive rows in storage order: what the random order of a shuffled epoch costs by itself
+    indexed["rows_in_storage_order"] = one_step(dl.rows_batch(0, B)[0])
+    return {"value": world * N * epochs / dt, "indexed_step": indexed, "unit": "spectra/s", "ms_per_step": dt / steps * 1e3, "epochs": epochs,
+            "batches_per_epoch": n_batches, "resident_spectra": N, "batch": B, "shuffled": True, "use_graph": bool(use_graph),
+            "row_stride": dl._stride, "resident_bytes": int(13 * dl._stride) * N, "loader_build_s": t_build,
+            "path": "QFA.train -> DeviceDataloader.rewind / next_batch_rows -> QFA.step(batch=ResidentBatch): the kernels read "
+                    "rows[s] x row_stride of the resident delta / error / mask (no per-batch kernel, copy or upload)"}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as FRESH child processes
     (torch.distributed.run) before this process has touched the GPU, relay rank 0's single JSON line, exit with the
@@ -236,6 +302,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain", type=float, default=3.0, help="seconds of extra steps after the timed region (0 = skip)")
     ap.add_argument("--no-predict", action="store_true")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the epoch leg (QFA.train over a resident, reshuffled data set)")
+    ap.add_argument("--epoch-batches", type=int, default=0, help="batches resident in the epoch leg (default: 4, more for small batches)")
+    ap.add_argument("--epoch-graph", type=int, default=-1, help="epoch leg: replay the step as a hipGraph (default: batches <= 2048 spectra)")
     ap.add_argument("--deterministic", action="store_true", help="fixed-order accumulation (model.deterministic)")
     ap.add_argument("--flags", type=lambda x: int(x, 0), default=0, help="QFA_F_* kernel-form flags (include/qfa_hip.h); 0 = defaults")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal without a GPU: no spectra are processed")
@@ -504,6 +573,15 @@ def main():
                                              workload="50000 spectra x N_pix=1913 (N_b=720), N_h=8, masks")
             del b1, m1
             torch.cuda.empty_cache()
+    if world == 1 and not args.no_epoch:
+        nbat = args.epoch_batches or max(4, -(-32768 // B))
+        graph = (B <= 2048) if args.epoch_graph < 0 else bool(args.epoch_graph)
+        ep_epochs = max(2, min(50, int(1.0 / max(nbat * step_ms * 1e-3, 1e-3))))
+        ep = epoch_leg(params, mu, wav, nb, nr, nh, B, masks, dev, 20220900 + cfg_index, nbat, ep_epochs, graph)
+        ep["vs_step_only"] = ep["value"] / rate
+        if fz is not None:
+            ep["vs_step_only_factored_z"] = ep["value"] / fz["value"]
+        out["epoch"] = ep
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, batch, n_cpu, npix, args.config)
     sys.stdout.flush()

@@ -134,7 +134,7 @@ __device__ unsigned long long qfa_gt_stamps[2 * 16];
 #else
 #define GTS(i) {}
 #endif
-template <int KP, bool HASA, bool ZF>
+template <int KP, bool HASA, bool ZF, bool IDX>        // IDX: the batch carries row numbers (qfa_batch_t::rows)
 __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t bt, qfa_tau_t tau, int B, int Npix, int Nb,
                                                     int Nh, GtPlan gp, const unsigned char *__restrict__ PGT,
                                                     const unsigned char *__restrict__ PST, const float4 *__restrict__ ZS,
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     // (+ 1 in the indexed form of ABI v3: the row indices of the group two groups later, stage_spectra)
     const int nsp = !active ? 0
                             : (slow ? 9 * TPW + (zblue ? 4 * TPW : 0) + (zfb ? 1 : 0)
-                                    : (zstrad ? 7 * TPW : 3 * TPW + (zblue ? TPW : 0) + (zfb ? 1 : 0))) + (bt.rows ? 1 : 0);
+                                    : (zstrad ? 7 * TPW : 3 * TPW + (zblue ? TPW : 0) + (zfb ? 1 : 0))) + (IDX ? 1 : 0);
     // first byte of the 4-byte mask piece (half h of the tile, piece pc) in its row; the ragged tile clamps it to Npix - 4
     auto mask_start = [&](int h, int pc) __attribute__((always_inline)) {
         const int st = PXW * wt + 16 * h + 4 * pc;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     // staging buffer (one more request per group, on the counted path), and stage_spectra(t + 2), which re-uses that
     // buffer, reads them there before its first request.  The first two groups (FIRST) read theirs from global memory.
     const unsigned RS = (unsigned)bt.row_stride;            // (elements; < 2^31: check_batch)
-    const bool idx = bt.rows != nullptr;                    // (wave-uniform: a kernel argument)
+    constexpr bool idx = IDX;
     // row of the batch arrays <- row `row` of group t, whose indices wait in staging buffer bufi (FIRST: in global memory)
     auto row_index = [&](int t, int bufi, unsigned row, auto first_tag) __attribute__((always_inline)) -> unsigned {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -311,6 +311,49 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         // the masks of the forms that do not carry them in their one statement: per half of 16 pixels one request of 4-byte
         // pieces (lane = (slot, piece)); their row index first, with the other LDS reads of this call
         const unsigned Rm = ri.m;
+        if constexpr (!IDX) {
+            // batch order = storage order: the 16 rows of a group are neighbours -- wave-uniform bases (the group's first row,
+            // SGPRs) and 32-bit per-lane offsets, no address arithmetic beyond one multiply-add per request (15 RS < 2^29: check_batch)
+            if (!slow && !zstrad) {
+                const float *dbase = uniform_ptr(bt.delta + (size_t)s0 * RS);
+                const float *ebase = uniform_ptr(bt.error + (size_t)s0 * RS);
+                const uint8_t *mbase = uniform_ptr(bt.mask + (size_t)s0 * RS);
+                const float *zbase = zblue ? uniform_ptr(bt.zabs + (size_t)s0 * Nb) : dbase;
+                if (zfb && lane < 16) glds16a(uniform_ptr(ZS + s0), 16u * (unsigned)min(lane, last_row), dst + 2 * GT::STG_ARR);
+                if constexpr (TPW == 1) {
+                    const unsigned row = slot_row(lane >> 2);
+                    const unsigned pc = 16u * (unsigned)wt + 4u * (unsigned)(lane & 3);
+                    const unsigned o = row * RS + pc;
+                    const unsigned vo = 4u * o, vz = 4u * (row * (unsigned)Nb + pc);
+                    const unsigned char *eb = reinterpret_cast<const unsigned char *>(ebase) - GT::STG_ARR;
+                    const unsigned char *zb = reinterpret_cast<const unsigned char *>(zbase) - 2 * GT::STG_ARR;
+                    const unsigned char *mb_ = reinterpret_cast<const unsigned char *>(mbase) - GT::STG_MASK;
+                    if (zblue)
+                        asm volatile("s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+                                     "global_load_lds_dwordx4 %0, %4 offset:1024\n\tglobal_load_lds_dwordx4 %1, %5 offset:2048\n\t"
+                                     "global_load_lds_dword %2, %6 offset:3072"
+                                     ::"v"(vo), "v"(vz), "v"(o), "s"(dbase), "s"(eb), "s"(zb), "s"(mb_), "s"(dst) : "memory");
+                    else
+                        asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                                     "global_load_lds_dwordx4 %0, %3 offset:1024\n\tglobal_load_lds_dword %1, %4 offset:3072"
+                                     ::"v"(vo), "v"(o), "s"(dbase), "s"(eb), "s"(mb_), "s"(dst) : "memory");
+                } else {
+                    constexpr int LPR = 4 * TPW, SPI = 64 / LPR;
+#pragma unroll
+                    for (int h = 0; h < TPW; ++h)
+                        glds4a(mbase, slot_row(lane >> 2) * RS + (unsigned)mask_start(h, lane & 3), dst + GT::STG_MASK + h * 256);
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) {
+                        const unsigned row = slot_row(SPI * i + lane / LPR);
+                        const unsigned pc = (unsigned)(PXW * wt) + 4u * (unsigned)(lane % LPR);
+                        glds16a(dbase, 4u * (row * RS + pc), dst + i * 1024);
+                        glds16a(ebase, 4u * (row * RS + pc), dst + GT::STG_ARR + i * 1024);
+                        if (zblue) glds16a(zbase, 4u * (row * (unsigned)Nb + pc), dst + 2 * GT::STG_ARR + i * 1024);
+                    }
+                }
+                return;
+            }
+        }
         if (!slow) {
             if constexpr (TPW == 1) {
                 const unsigned R = ri.r[0];                                           // staging slot lane >> 2

@@ -50,13 +50,15 @@ template <int KP>
 static void gt_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                       const GtPlan &g, const unsigned char *PGT, const unsigned char *PST, const float4 *zs, float *accum,
                       float *slab, double *slabS, int slab_stride, Scal64 *sc64, hipStream_t st) {
-    auto go = [&](auto hasa, auto zf) {
-        k_grads_t<KP, decltype(hasa)::value, decltype(zf)::value><<<g.items(), 512, 0, st>>>(
+    auto go = [&](auto hasa, auto zf, auto ix) {
+        k_grads_t<KP, decltype(hasa)::value, decltype(zf)::value, decltype(ix)::value><<<g.items(), 512, 0, st>>>(
             p, b, tau, B, Npix, Nb, Nh, g, PGT, PST, zs, accum, slab, slabS, slab_stride, sc64);
     };
-    if (b.A_blue) go(std::true_type{}, std::false_type{});
-    else if (zs) go(std::false_type{}, std::true_type{});
-    else go(std::false_type{}, std::false_type{});
+    using T = std::true_type;
+    using F = std::false_type;
+    if (b.A_blue) go(T{}, F{}, F{});                         // (not combined with rows: check_batch)
+    else if (zs) { if (b.rows) go(F{}, T{}, T{}); else go(F{}, T{}, F{}); }
+    else { if (b.rows) go(F{}, F{}, T{}); else go(F{}, F{}, F{}); }
 }
 void qfa_gt_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int max_ranges, const unsigned char *PGT, const unsigned char *PST, const float *ZS, float *accum,

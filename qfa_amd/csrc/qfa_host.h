@@ -183,6 +183,8 @@ inline int check_batch(const qfa_batch_t &b, int Npix, int Nb) {
     if (Nb > 0 && !fac && !b.zabs) return QFA_E_NULL;
     if (b.rows && b.A_blue) return QFA_E_NULL;
     if (b.row_stride != 0 && (b.row_stride < (int64_t)Npix || b.row_stride >= (1LL << 31))) return QFA_E_SIZE;
+    if (!b.rows && (long long)64 * b.row_stride >= (1LL << 31)) return QFA_E_SIZE;   // batch order = storage order: 32-bit offsets
+                                                                                    // inside a wave's 16 neighbouring rows
     return 0;
 }
 // the batch as the kernels take it: row_stride filled in

@@ -110,10 +110,11 @@ def make_batch_numpy(params, mu, wav, nb, batch, seed, masks=True, red_only=(), 
     }
 
 
-def make_batch_torch(params, mu, wav, nb, batch, seed, device, masks=True, return_zq=False):
+def make_batch_torch(params, mu, wav, nb, batch, seed, device, masks=True, return_zq=False, return_flux=False):
     """On-device generator for benchmark-sized batches (same model, torch RNG).
 
-    Returns (delta, error, zabs, mask) float32/bool tensors on ``device``; with ``return_zq`` also z_qso (batch,).
+    Returns (delta, error, zabs, mask) float32/bool tensors on ``device``; with ``return_zq`` also z_qso (batch,); with
+    ``return_flux`` (flux, error, z_qso) -- what a loader is given (masked pixels hold -999 in both arrays).
     """
     import torch
     g = torch.Generator(device=device)
@@ -155,6 +156,8 @@ def make_batch_torch(params, mu, wav, nb, batch, seed, device, masks=True, retur
         mask &= torch.rand(batch, n_pix, generator=g, **f32) >= 0.01
         flux = torch.where(mask, flux, torch.full_like(flux, -999.0))
         sigma = torch.where(mask, sigma, torch.full_like(sigma, -999.0))
+    if return_flux:
+        return flux.contiguous(), sigma.contiguous(), zq
     delta = flux - mu_t[None, :] * A
     if return_zq:
         return delta.contiguous(), sigma.contiguous(), zabs.contiguous(), mask.contiguous(), zq

@@ -172,13 +172,15 @@ def _mock_loader(dev, npix, nh, N, B, seed, **kw):
     return dl, p, wav, nb, nr
 
 
-def test_loader_rows_batches_equal_its_materialised_batches(dev):
+@pytest.mark.parametrize("sort_batches", [True, False])
+def test_loader_rows_batches_equal_its_materialised_batches(dev, sort_batches):
     """DeviceDataloader.next_batch_rows() against next_batch() over a shuffled epoch: the same rows in the same order; delta /
     error / mask of the resident arrays equal the per-batch builder's bit for bit (qfa_build_resident_f32 and
     qfa_build_batch_f32 share their arithmetic); the last, short batch included; set_tau rebuilds the resident delta"""
     import torch
     dl, p, wav, nb, nr = _mock_loader(dev, 1913, 8, 150, 64, seed=21)
     dl2 = _mock_loader(dev, 1913, 8, 150, 64, seed=21)[0]                   # the same data walked through next_batch()
+    dl.sort_batches = dl2.sort_batches = sort_batches
     assert dl._stride == 1920
     for epoch in range(2):
         np.random.seed(100 + epoch)
@@ -191,8 +193,14 @@ def test_loader_rows_batches_equal_its_materialised_batches(dev):
             refs.append(rb)
             d, e, z, mk = dl2.next_batch()
             (d2, e2, _, mk2), zfac = rb.materialize()
+            if sort_batches:                                                # the same SET of spectra, rows in storage order
+                assert torch.equal(rb.rows, torch.sort(rb.rows)[0])
+                back = torch.as_tensor(np.argsort(np.argsort(dl2._order[dl2.cur - d.shape[0]:dl2.cur])), device=dev)
+                d2, e2, mk2, zq = d2[back], e2[back], mk2[back], zfac[0][back]
+            else:
+                zq = zfac[0]
             assert torch.equal(d, d2) and torch.equal(e, e2) and torch.equal(mk, mk2)
-            assert torch.equal(z.zfac[0], zfac[0])
+            assert torch.equal(z.zfac[0], zq)
         assert not dl2.have_next_batch()
         assert [r.B for r in refs] == [64, 64, 22]
     seen = torch.cat([r.rows for r in refs]).cpu().numpy()
@@ -234,6 +242,7 @@ def test_train_through_the_resident_form_reproduces_the_materialised_loop(dev, n
     res = []
     for mode in ("resident", "materialised"):
         dl, p, wav, nb, nr = _mock_loader(dev, npix, nh, N, B, seed=33)
+        dl.sort_batches = False                             # (bit comparison: the same summation order in both loops)
         m = QFA(nb, nr, nh, dev, model_params=p)
         m.deterministic = True
         opt = Adam(m.parameters, dev, scheduler=step_scheduler(0.9, 2), learning_rate=2e-3)
@@ -252,6 +261,23 @@ def test_train_through_the_resident_form_reproduces_the_materialised_loop(dev, n
         res.append({k: getattr(m, k).clone() for k in ("F", "Psi", "omega", "tau0", "c0", "beta")})
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
+
+
+def test_sorted_batches_train_like_unsorted_ones(dev, tmp_path):
+    """sort_batches (the default: the rows of a batch in storage order) changes the order of a sum, nothing else"""
+    import torch
+    from qfa_amd import QFA, Adam, step_scheduler
+    res = []
+    for sort in (True, False):
+        dl, p, wav, nb, nr = _mock_loader(dev, 640, 12, 300, 64, seed=41)
+        dl.sort_batches = sort
+        m = QFA(nb, nr, 12, dev, model_params=p)
+        opt = Adam(m.parameters, dev, scheduler=step_scheduler(0.9, 2), learning_rate=2e-3)
+        np.random.seed(3)
+        m.train(opt, dl, 3, output_dir=str(tmp_path / str(sort)), save_interval=100, smooth_interval=100, quiet=True)
+        res.append({k: getattr(m, k).double().cpu().numpy() for k in ("F", "Psi", "omega", "tau0", "c0", "beta")})
+    for k in res[0]:
+        assert rel_l2(res[0][k], res[1][k]) < 2e-5, k
 
 
 def test_predict_to_npz_reads_the_resident_rows(dev, tmp_path):
