@@ -44,6 +44,8 @@ CONFIGS = {
     #        B/GPU   Npix  Nh  masks cpu_sample
     "c2": (10000, 2000, 8, False, 64),
     "c3": (100000, 4000, 16, True, 32),
+    # BASELINE configs[3]: 1M spectra data-parallel over 8 GPUs = 125 000 per GPU of the c3 shape (the default of --gpus 8)
+    "c4": (125000, 4000, 16, True, 32),
     "c1": (128, 1913, 8, True, 64),
     "c5": (20000, 8000, 32, True, 4),
     # the reference's own shapes: its default batch (QFA/config.py:32) on the SDSS grid, and its second shipped model
@@ -55,7 +57,7 @@ PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (XDL) peak
 PEAK_HBM_GBS = 8000.0
 # the true reference (imported in the survey container, SURVEY.md section 6 / BASELINE.md section 2): forward, 8 cores
-REFERENCE_8CORE = {"c1": 13.4, "c1b": 13.4, "c2": 12.2, "c3": 1.54, "c5": 0.21}
+REFERENCE_8CORE = {"c1": 13.4, "c1b": 13.4, "c2": 12.2, "c3": 1.54, "c4": 1.54, "c5": 0.21}
 
 
 def alg_flops(npix, k):
@@ -297,7 +299,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: c3 (100 000 spectra per GPU); with --gpus 8: c4 (BASELINE configs[3]: 1M spectra over 8 GPUs)")
     ap.add_argument("--batch", type=int, default=0, help="spectra per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain", type=float, default=3.0, help="seconds of extra steps after the timed region (0 = skip)")
@@ -309,6 +312,8 @@ def main():
     ap.add_argument("--flags", type=lambda x: int(x, 0), default=0, help="QFA_F_* kernel-form flags (include/qfa_hip.h); 0 = defaults")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal without a GPU: no spectra are processed")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = "c4" if args.gpus >= 8 else "c3"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         os.dup2(real_stdout, 1)
         self_launch(args)
@@ -349,7 +354,7 @@ def main():
         wav, nb, nr = synthetic.wavelength_grid(None if args.config in ("c1", "c1b") else npix)
     npix = len(wav)
     params, mu = synthetic.mock_parameters(npix, nb, nh, seed=20220700)
-    cfg_index = {"c1": 1, "c2": 2, "c3": 3, "c5": 5, "c1b": 11, "desi": 13}[args.config]
+    cfg_index = {"c1": 1, "c2": 2, "c3": 3, "c4": 4, "c5": 5, "c1b": 11, "desi": 13}[args.config]
     # generate in slabs to bound temporary memory
     parts = []
     slab = 25000
@@ -382,10 +387,14 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    ar_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if use_dist else None
     t0 = time.perf_counter()
     losses = []
     for i in range(args.steps):
+        if ar_evs is not None:
+            model._ar_events = ar_evs[i]
         losses.append(model.step(opt, *batch, events=evs[i]))
+    model._ar_events = None
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -398,6 +407,8 @@ def main():
 
     stage = np.array([[es[j].elapsed_time(es[j + 1]) for j in range(4)] for es in evs]).mean(axis=0)   # ms
     ms_prep, ms_p1, ms_solve, ms_p2 = [float(x) for x in stage]
+    # the one collective of the step (packed sums + counts, qfa_accum_floats floats) between events on the launch stream
+    ms_ar = float(np.mean([a.elapsed_time(b) for a, b in ar_evs])) if ar_evs is not None else None
 
     # ---- sustained leg: the same step for >= --sustain seconds (held clock; lets rocm-smi sampling see the run)
     sustained = None
@@ -492,11 +503,20 @@ def main():
         xdl_flops = None          # k_grads (N_h <= 8): stage 1 on the float32 MFMA -- priced against the float32 roof
     ach32 = dom_flops * B / (dom_ms * 1e-3) / 1e12
     traffic = traffic_step = None
+    traffic_src = None
     tfile = os.path.join(REPO, "profiles", f"traffic_{args.config}.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             if tj.get("B") == B:
+                # the byte counts are REPLAYED from the builder's PMC run (rocprofv3 cannot run inside this process): say so,
+                # and say whether that run measured the library loaded here
+                import hashlib
+                from qfa_amd import _lib as _L
+                sha = hashlib.sha256(open(_L.LIB_PATH, "rb").read()).hexdigest()
+                traffic_src = {"traffic_source": f"profiles/traffic_{args.config}.json (builder's rocprofv3 --pmc run, tools/profile_round.sh)",
+                               "traffic_stale": tj.get("libqfa_hip_sha256") != sha,
+                               "traffic_measured_on_sha256": tj.get("libqfa_hip_sha256"), "libqfa_hip_sha256": sha}
                 traffic = tj.get(dominant.replace("k_moments_x", "k_moments") + "_hbm_bytes_per_launch")
                 p2key = p2_name
                 parts = [tj.get(kk + "_hbm_bytes_per_launch") for kk in ("k_moments", "k_solve", p2key)]
@@ -522,6 +542,8 @@ def main():
                 "frac": ach32 / PEAK_FP32_TFLOPS, "traffic": traffic, "kernel_ms": dom_ms,
                 "flops_per_spectrum": dom_flops, "priced": "algorithmic float32 flops over the float32 MFMA / VALU peak",
                 "alg_flops_per_spectrum": dom_flops}
+    if traffic_src:
+        roof.update(traffic_src)
     hbm_frac = rate_gpu * by / (PEAK_HBM_GBS * 1e9)
     step_ms = dt / args.steps * 1e3
     out = {
@@ -541,7 +563,9 @@ def main():
                                  + "; k x k solve and scalar-gradient sums in float64", "flags": fl},
         "roofline": roof,
         "stage_ms": {"pf_image": ms_prep, "pass1_moments": ms_p1, "solve": ms_solve, "pass2_grads": ms_p2,
-                     "rest_of_step": dt / args.steps * 1e3 - float(stage.sum())},
+                     "rest_of_step": dt / args.steps * 1e3 - float(stage.sum()) - (ms_ar or 0.0),
+                     **({"allreduce": ms_ar, "allreduce_bytes": 4 * (npix * nh + 3 * npix + nb + 8),
+                         "allreduce_backend": os.environ.get("QFA_BENCH_BACKEND", "nccl")} if ms_ar is not None else {})},
         "step_roofline": {"achieved_hbm_frac": hbm_frac, "achieved_hbm_GBs": rate_gpu * by / 1e9,
                           "alg_bytes_per_spectrum": by, "alg_flops_per_spectrum": f1 + f2,
                           "achieved_fp32_frac": rate_gpu * (f1 + f2) / (PEAK_FP32_TFLOPS * 1e12),

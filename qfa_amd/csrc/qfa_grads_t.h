@@ -41,11 +41,13 @@
 // the split of the launch: tiles, pixel blocks, ranges of spectra groups (host and device agree through this struct)
 struct GtPlan {
     int T16, PB, R, gpr;          // wave tiles (GTT::PXW pixels each); pixel blocks of 8 wave tiles; ranges; groups of 16 spectra per range
-    // Work item i = r PB + pb (range-major).  Workgroup b runs item (b % 8) ceil(PB R / 8) + b / 8: workgroups go to the XCDs
-    // round-robin (b % 8), so every XCD gets a contiguous run of items -- the pixel blocks of ONE or two ranges, which walk
-    // the same state in step and share it in that XCD's L2, whatever R is (the grid is padded to a multiple of 8)
-    __host__ __device__ int per_xcd() const { return (PB * R + 7) / 8; }
-    __host__ __device__ int items() const { return 8 * per_xcd(); }
+    int nxcd;                     // XCDs the hardware deals workgroups to, round-robin (hipDeviceAttributeNumberOfXccs: 8 on MI355X
+                                  // in SPX mode, fewer in the partitioned modes; qfa_host.h xcd_count)
+    // Work item i = r PB + pb (range-major).  Workgroup b runs item (b % nxcd) ceil(PB R / nxcd) + b / nxcd: workgroups go to the
+    // XCDs round-robin (b % nxcd), so every XCD gets a contiguous run of items -- the pixel blocks of ONE or two ranges, which walk
+    // the same state in step and share it in that XCD's L2, whatever R is (the grid is padded to a multiple of nxcd)
+    __host__ __device__ int per_xcd() const { return (PB * R + nxcd - 1) / nxcd; }
+    __host__ __device__ int items() const { return nxcd * per_xcd(); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const int lane = tid & 63;
     const int wv8 = wave_uniform(tid >> 6);
     const int lo = lane & 15, g = lane >> 4;
-    const int item = ((int)blockIdx.x & 7) * gp.per_xcd() + ((int)blockIdx.x >> 3);
+    const int item = ((int)blockIdx.x % gp.nxcd) * gp.per_xcd() + ((int)blockIdx.x / gp.nxcd);
     const bool idle = item >= gp.PB * gp.R;                 // (padding of the grid)
     const int rr = idle ? 0 : item / gp.PB, pb = idle ? 0 : item % gp.PB;
     const int G = (B + 15) >> 4;

@@ -12,6 +12,7 @@ size_t qfa_gt_state_bytes(int KP, int B) {
 // workgroups of a range then share an XCD, block = pb R + r) where the batch has the groups for it
 static GtPlan gt_plan(int KP, int B, int Npix, int max_ranges) {
     GtPlan g;
+    g.nxcd = xcd_count();
     const int pxw = KP == 8 ? GTT<8>::PXW : GTT<16>::PXW;       // pixels per wave
     g.T16 = (Npix + pxw - 1) / pxw;
     g.PB = (g.T16 + 7) / 8;
@@ -26,7 +27,8 @@ static GtPlan gt_plan(int KP, int B, int Npix, int max_ranges) {
         for (int r = 2; r <= rmax; ++r) best = std::min(best, cost(r));
         for (int r = 1; r <= rmax; ++r)
             if (cost(r) <= 1.03 * best) { R = r; break; }
-        if (R >= 8 && R % 8 != 0 && (R + 7) / 8 * 8 <= rmax && cost((R + 7) / 8 * 8) <= cost(R)) R = (R + 7) / 8 * 8;
+        const int X = g.nxcd;
+        if (R >= X && R % X != 0 && (R + X - 1) / X * X <= rmax && cost((R + X - 1) / X * X) <= cost(R)) R = (R + X - 1) / X * X;
     }
     R = std::max(1, std::min(R, max_ranges));
     g.gpr = (G + R - 1) / R;

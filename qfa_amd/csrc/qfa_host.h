@@ -57,6 +57,23 @@ inline int cu_count() {
     return n;
 }
 
+// XCDs of the current device (each has its own L2; the hardware deals the workgroups of a launch to them round-robin), queried
+// once per device: 8 on MI355X in SPX mode, fewer in the partitioned modes.  k_grads_t maps its work items so that the
+// workgroups that walk the same spectra share an XCD (GtPlan).
+inline int xcd_count() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 8; }
+    int n = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || n < 1 || n > 64) {
+        (void)hipGetLastError();
+        n = 8;
+    }
+    __atomic_store_n(&cache[dev], n, __ATOMIC_RELAXED);
+    return n;
+}
+
 // Work plan of a pass (WorkPlan, qfa_common.h): the blocks of 64 spectra that fill whole rounds of the 512
 // resident-workgroup slots walk the whole pixel axis; the remaining blocks are cut into 1..8 pixel segments.  The
 // plan minimises rounds x (tiles per item + prologue), the prologue of an item (operand loads, pipeline fill)

@@ -42,10 +42,12 @@ class DeviceDataloader(object):
 
     def __init__(self, flux, error, zqso, wav_grid, batch_size, device, tau="becker", window_length_for_mu=16,
                  shuffle=True, mode="train", paths=None, rank=0, world=1, seed=0, group=None, sharded_input=False,
-                 global_size=None):
+                 global_size=None, reshuffle="shard"):
         """``rank`` / ``world`` / ``seed`` / ``group``: data parallelism (see the module docstring).  By default the
         arrays hold ALL spectra and the loader keeps rows ``shard_bounds(N, rank, world)``; with
-        ``sharded_input=True`` they already are this rank's shard of ``global_size`` spectra."""
+        ``sharded_input=True`` they already are this rank's shard of ``global_size`` spectra.  ``reshuffle``: "shard" (every
+        epoch shuffles inside the rank's shard) or "global" (one permutation of the whole set per epoch, every rank feeds the
+        members of a global batch that live in its shard: the reference's batches; qfa_amd.distributed.ShardPlan)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.QFAHipError("DeviceDataloader needs a HIP device (torch device 'cuda')")
@@ -111,7 +113,7 @@ class DeviceDataloader(object):
         self._zq1_dev = (1.0 + self._zq_dev).to(f32)
         self._pix_ratio = torch.as_tensor((self.wav_grid[:self.Nb] / LYA).astype(np.float32), device=self.device)
         self.factored_z = True                                  # attach the factors to the zabs tensor of every batch
-        self._plan = ShardPlan(n_global, self.batch_size, self.rank, self.world, seed, shuffle) if self.world > 1 else None
+        self._plan = ShardPlan(n_global, self.batch_size, self.rank, self.world, seed, shuffle, reshuffle) if self.world > 1 else None
         self._epoch = -1
         self._steps = None                                      # DP: list of local row arrays of the current epoch
         self._order = np.arange(self.local_size)

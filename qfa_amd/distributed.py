@@ -152,24 +152,62 @@ class ShardPlan(object):
     ``local = ceil(batch_size / world)``.  EVERY rank runs ``steps = ceil(max_shard / local)`` steps; a rank whose
     shard is exhausted contributes an empty batch (zeros to the all-reduce), so the collective never deadlocks on
     an uneven tail.  The union of the ranks' step-i rows is the global batch of step i (about ``batch_size`` rows).
+
+    ``reshuffle="shard"`` (above) keeps the per-rank batch size fixed, but a global batch is always one slice from each of
+    the same ``world`` sub-populations (a catalogue sorted by redshift or S/N gives every rank a different population for
+    the whole run) -- a divergence from the reference's shuffle of the WHOLE set (QFA/dataloader.py:154-167).
+    ``reshuffle="global"`` removes it: one permutation of all n rows per epoch, shared by the ranks; global batch k is
+    ``perm[k B:(k+1) B]`` and rank r feeds the members that fall into its shard (binomially ~B / world of them; the packed
+    sums and COUNTS are all-reduced, so uneven contributions need nothing special).  The batches are then exactly those of a
+    single process walking the same permutation; each rank's spectra still never leave its HBM.
     """
 
-    def __init__(self, n: int, batch_size: int, rank: int = 0, world: int = 1, seed: int = 0, shuffle: bool = True):
+    def __init__(self, n: int, batch_size: int, rank: int = 0, world: int = 1, seed: int = 0, shuffle: bool = True,
+                 reshuffle: str = "shard"):
         if world < 1 or not (0 <= rank < world):
             raise ValueError("need 0 <= rank < world")
+        if reshuffle not in ("shard", "global"):
+            raise ValueError("reshuffle must be 'shard' or 'global'")
         self.n, self.batch_size, self.rank, self.world = int(n), int(batch_size), int(rank), int(world)
-        self.seed, self.shuffle = int(seed), bool(shuffle)
+        self.seed, self.shuffle, self.reshuffle = int(seed), bool(shuffle), reshuffle
         self.lo, self.hi = shard_bounds(self.n, self.rank, self.world)
         self.local = -(-self.batch_size // self.world)
         max_shard = -(-self.n // self.world)
-        self.steps = -(-max_shard // self.local) if self.n > 0 else 0
+        if reshuffle == "global":
+            # the reference's own walk: ceil(n / batch_size) global batches per epoch (QFA/dataloader.py:124-138)
+            self.steps = -(-self.n // self.batch_size) if self.n > 0 else 0
+        else:
+            self.steps = -(-max_shard // self.local) if self.n > 0 else 0
 
     def epoch_rows(self, epoch: int, rank=None):
         """list (one entry per step, possibly empty arrays) of GLOBAL row indices for ``rank`` (default: own)"""
         import numpy as np
         r = self.rank if rank is None else int(rank)
         lo, hi = shard_bounds(self.n, r, self.world)
+        if self.reshuffle == "global":
+            # ONE permutation of the whole data set per epoch, the same on every rank (seed, epoch -- not the rank): global
+            # batch k is perm[k B : (k + 1) B], exactly the batches a single process walking this permutation would form
+            # (reference QFA/dataloader.py:154-167), and a rank contributes the members that live in its resident shard
+            # -- about B / world of them, B over all ranks.  Indices only: nothing moves between GPUs.
+            perm = np.arange(self.n)
+            if self.shuffle:
+                np.random.default_rng([self.seed, int(epoch)]).shuffle(perm)
+            out = []
+            for k in range(self.steps):
+                rows = perm[k * self.batch_size:(k + 1) * self.batch_size]
+                out.append(rows[(rows >= lo) & (rows < hi)])
+            return out
         rows = np.arange(lo, hi)
         if self.shuffle:
             np.random.default_rng([self.seed, int(epoch), r]).shuffle(rows)
         return [rows[i * self.local:(i + 1) * self.local] for i in range(self.steps)]
+
+    def global_batch(self, epoch: int, step: int):
+        """rows of the whole global batch of a step (the union over the ranks), in the order a single process would walk them"""
+        import numpy as np
+        if self.reshuffle == "global":
+            perm = np.arange(self.n)
+            if self.shuffle:
+                np.random.default_rng([self.seed, int(epoch)]).shuffle(perm)
+            return perm[step * self.batch_size:(step + 1) * self.batch_size]
+        return np.concatenate([self.epoch_rows(epoch, rank=r)[step] for r in range(self.world)])

@@ -79,6 +79,7 @@ class QFA(object):
         self._dp_group = None
         self._dp = False
         self._dp_checked = False
+        self._ar_events = None                          # optional (start, end) torch.cuda.Event pair recorded around the all-reduce
         # deterministic=True: per-block slab + fixed-order reducer instead of float32 atomics in pass 2
         # (qfa_nll_grad_det_f32): bit-identical sums from run to run, at the price of a (B/64) x accum-sized slab
         # (8..64 rows where pass 2 is pixel-resident -- large batches; there the default has no atomics either)
@@ -373,7 +374,12 @@ class QFA(object):
             acc = self.accumulate(delta, error, zabs, mask, events=events, zfac=zfac, batch=batch)
         if self._dp:
             from .distributed import all_reduce_accum
+            ev = self._ar_events                    # (bench.py: a pair of recorded events around the collective)
+            if ev is not None:
+                ev[0].record()
             all_reduce_accum(acc, self._dp_group)
+            if ev is not None:
+                ev[1].record()
         return self._finalize(acc, True)
 
     def loglikelihood_and_gradient_for_single_spectra(self, delta, error, zabs, mask):

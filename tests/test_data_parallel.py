@@ -172,6 +172,36 @@ def test_shard_plan_covers_every_row_once_and_equalises_steps():
             assert [list(x) for x in e0] != [list(x) for x in e1]      # reshuffled every epoch
 
 
+def test_shard_plan_global_reshuffle_forms_the_single_process_batches():
+    """ShardPlan(reshuffle="global"): one permutation of the WHOLE set per epoch (reference QFA/dataloader.py:154-167); the
+    union over the ranks of step k is exactly global batch k of that permutation -- the batches of a single process -- every
+    rank touches its own shard only, and all ranks run ceil(n / B) steps"""
+    from qfa_amd.distributed import ShardPlan, shard_bounds
+    for n, bs, world in ((23, 8, 2), (7, 4, 4), (100, 16, 8), (5, 64, 2), (16, 5, 3), (1000, 100, 8)):
+        plans = [ShardPlan(n, bs, r, world, seed=11, reshuffle="global") for r in range(world)]
+        assert {p.steps for p in plans} == {-(-n // bs)}
+        for epoch in range(3):
+            rows = [p.epoch_rows(epoch) for p in plans]
+            perm = np.arange(n)
+            np.random.default_rng([11, epoch]).shuffle(perm)
+            for k in range(plans[0].steps):
+                want = perm[k * bs:(k + 1) * bs]
+                got = np.concatenate([rows[r][k] for r in range(world)])
+                assert sorted(got.tolist()) == sorted(want.tolist())           # global batch k, split by residence
+                assert list(plans[0].global_batch(epoch, k)) == list(want)
+                for r in range(world):
+                    lo, hi = shard_bounds(n, r, world)
+                    assert ((rows[r][k] >= lo) & (rows[r][k] < hi)).all()
+                    # (the order inside a rank's part is the permutation's)
+                    assert list(rows[r][k]) == [x for x in want if lo <= x < hi]
+            seen = np.concatenate([np.concatenate(r) for r in rows])
+            assert sorted(seen.tolist()) == list(range(n))
+        if n >= 16:
+            assert [list(x) for x in plans[0].epoch_rows(0)] != [list(x) for x in plans[0].epoch_rows(1)]
+    with pytest.raises(ValueError):
+        ShardPlan(10, 4, 0, 2, reshuffle="nope")
+
+
 def _train_case():
     from qfa_amd import synthetic
     wav, nb, nr = synthetic.wavelength_grid(96)
@@ -233,14 +263,14 @@ def _oracle_epochs(p, b, nb, plan_rows_fn, n_epochs, steps, reduce_fn):
     return params, losses
 
 
-def _worker_train_cpu(rank, world, port, q):
+def _worker_train_cpu(rank, world, port, q, reshuffle="shard", bs=10):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from qfa_amd.distributed import ShardPlan, all_reduce_accum, replicas_in_sync
     p, mu, nb, b, wav = _train_case()
-    plan = ShardPlan(11, 10, rank, world, seed=5)
+    plan = ShardPlan(11, bs, rank, world, seed=5, reshuffle=reshuffle)
     cache = {}
 
     def rows(epoch, step):
@@ -279,6 +309,30 @@ def test_dp_training_loop_world2_gloo_cpu():
     assert steps == plans[0].steps == 2 and len(plans[1].epoch_rows(0)[1]) == 0     # the uneven tail is exercised
     union = lambda e, s: np.concatenate([pl.epoch_rows(e)[s] for pl in plans])
     ref, ref_losses = _oracle_epochs(p, b, nb, union, 2, steps, lambda a: a)
+    assert np.allclose(losses, ref_losses, rtol=1e-10)
+    for k in KEYS:
+        assert np.allclose(params[k], ref[k], rtol=1e-9, atol=1e-12), k
+
+
+def test_dp_training_loop_global_reshuffle_world2_gloo_cpu():
+    """reshuffle="global": two ranks over gloo against the SINGLE-PROCESS loop of the reference over the same permutation
+    (global batch k = perm[k B:(k+1) B]; batch 4 of 11 rows: a short last batch, uneven and sometimes empty rank parts)"""
+    from qfa_amd.distributed import ShardPlan
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_train_cpu, args=(r, 2, port, q, "global", 4)) for r in range(2)]
+    [pr.start() for pr in procs]
+    params, losses, same, differ, steps = _collect(procs, q, 300)
+    [pr.join(60) for pr in procs]
+    assert all(pr.exitcode == 0 for pr in procs)
+    assert same and not differ and steps == 3
+    p, mu, nb, b, wav = _train_case()
+    single = ShardPlan(11, 4, 0, 1, seed=5, reshuffle="global")          # one process, the same permutation
+    parts = [ShardPlan(11, 4, r, 2, seed=5, reshuffle="global") for r in range(2)]
+    sizes = [[len(x) for x in pl.epoch_rows(0)] for pl in parts]
+    assert [a + c for a, c in zip(*sizes)] == [4, 4, 3] and sizes[0] != sizes[1]
+    ref, ref_losses = _oracle_epochs(p, b, nb, lambda e, s: single.epoch_rows(e)[s], 2, steps, lambda a: a)
     assert np.allclose(losses, ref_losses, rtol=1e-10)
     for k in KEYS:
         assert np.allclose(params[k], ref[k], rtol=1e-9, atol=1e-12), k

@@ -75,7 +75,7 @@ def test_config2_full_size_10k(dev):
     run_config(dev, 2000, 8, 10000, False, 20220702, 1024)
 
 
-def test_config5_shape_2048(dev):
-    """BASELINE configs[4] shape (8000 px, N_h = 32) at 2 048 spectra; oracle on 192 of them (float64 numpy at
-    8000 x 32 runs ~10 spectra/s)."""
-    run_config(dev, 8000, 32, 2048, True, 20220705, 192, dict(TOL_ORACLE, F=2e-4))
+def test_config5_shape_20000(dev):
+    """BASELINE configs[4] shape (8000 px, N_h = 32) at the 20 000 spectra per GPU bench.py --config c5 times; oracle on 192
+    of them (float64 numpy at 8000 x 32 runs ~10 spectra/s)."""
+    run_config(dev, 8000, 32, 20000, True, 20220705, 192, dict(TOL_ORACLE, F=2e-4))

@@ -1,15 +1,20 @@
 """profiles/traffic_<cfg>.json from a tools/pmc.sh summary: HBM bytes per launch per kernel =
 2 * FETCH_SIZE * 1024 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md section HBM; cross-checked
 here with TCC_EA0_RDREQ_128B * 128) + WRITE_SIZE * 1024."""
-import json, re, sys
+import hashlib, json, os, re, sys
 summary, cfg, B, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-cur, vals = None, {}
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cur, vals, names = None, {}, []
 for line in open(summary):
     if not line.startswith(" "):
         name = line.strip()
+        names.append(name)
         cur = name.split("<")[0]
-        # the factored-z instantiations (last template argument `true` of k_grads_x / k_moments_x) are kept apart
-        if cur in ("k_grads_x", "k_grads_t", "k_moments_x") and name.rstrip(">").endswith("true"):
+        targs = [a.strip() for a in name[name.find("<") + 1:name.rfind(">")].split(",")] if "<" in name else []
+        # the factored-z instantiations are kept apart: template argument ZF = the last one of k_grads_x<KP, HASA, TERMS, ZF> and
+        # k_moments_x<KP, PREDICT, NW, ZF>, the third of k_grads_t<KP, HASA, ZF, IDX>
+        zf = (cur in ("k_grads_x", "k_moments_x") and targs and targs[-1] == "true") or (cur == "k_grads_t" and len(targs) >= 3 and targs[2] == "true")
+        if zf:
             cur += "_zfac"
         if cur == "k_moments_x" and ", true, 4" in name:      # the prediction instantiation of pass 1
             cur = "k_moments_x_predict"
@@ -17,7 +22,12 @@ for line in open(summary):
     else:
         m = re.match(r"\s+(\S+)\s+mean/dispatch\s+(\S+)", line)
         if m: vals[cur][m.group(1)] = float(m.group(2))
-res = {"config": cfg, "B": B, "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ*); "
+lib = os.path.join(REPO, "qfa_amd", "libqfa_hip.so")
+res = {"config": cfg, "B": B,
+       # what was measured: bench.py compares this hash with the library it loaded and says `traffic_stale` when they differ
+       "libqfa_hip_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+       "kernels_measured": names,
+       "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ*); "
        "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; check: TCC_EA0_RDREQ_128B*128"}
 # (k_prep_pst: the operand images of the pixel-resident pass 2, written behind the solve and counted with it)
 if "k_prep_pst" in vals and "k_solve" in vals:
