@@ -39,6 +39,10 @@ namespace {
 #define QFA_P2_S12 1        // pass 2 at N_h > 16: 1 = k_s12_x + two k_grads_s3, 0 = k_grads (f32 stage 1) + one k_grads_s3
 #endif
 
+#ifndef QFA_P1_MAX_CHAIN
+#define QFA_P1_MAX_CHAIN 64  // longest accumulation chain of pass 1 at N_h = 17..32, in 32-pixel tiles (make_layout_t)
+#endif
+
 inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }
 
 // Compute units of the current device, queried once per device (launch geometry: resident-workgroup slots of the
@@ -81,9 +85,15 @@ inline int xcd_count() {
 // tiles per item while the chip stays at most half full (the step of a small batch is latency-bound).
 constexpr int kMaxSeg = 32;
 
-inline WorkPlan plan_work(int B, int ntiles, int pro, int slots, int spb = 64) {
+inline WorkPlan plan_work(int B, int ntiles, int pro, int slots, int spb = 64, int max_chain = 0) {
     // slots = CUs x resident workgroups per CU; spb = spectra per block (64; 32 for k_grads_x)
     const int nblk = (B + spb - 1) / spb;
+    // max_chain > 0: no item walks more than max_chain tiles (pass 1 at N_h = 17..32: see make_layout_t) -- every block is cut
+    // into the same ceil(ntiles / max_chain) segments
+    if (max_chain > 0 && ntiles > max_chain) {
+        const int nn0 = (ntiles + max_chain - 1) / max_chain, st = (ntiles + nn0 - 1) / nn0;
+        return WorkPlan{0, nblk, (ntiles + st - 1) / st, st};
+    }
     WorkPlan best{0, nblk, 1, ntiles};
     double best_cost = 1e300;
     for (int full = (nblk / slots) * slots; full >= 0; full -= slots) {       // whole rounds kept unsegmented
@@ -131,8 +141,16 @@ Layout make_layout_t(int B, int Npix) {
     L.wp2 = plan_work(B, L.ntiles, 4, NCU * (KP == 8 ? QFA_G8_OCC : (KP > 16 ? 1 : 2)));
     // pass 1 runs on the XDL pipe at every N_h (32-pixel tiles; one workgroup per CU at N_h > 16)
     L.spb1 = KP <= 16 ? 16 * QFA_P1_NW : 64;
+    // Pass 1 sums C, T, b, b2 of a spectrum over the pixel axis in MFMA accumulators.  The matrix pipe aligns the 32 products
+    // of an instruction with the accumulator they are added to and keeps about two bits below the accumulator's last place
+    // (tools/ubench/mfma_round.hip: products of 1/16 ulp(C) vanish, of 1/4 ulp survive; the sum itself is rounded to nearest), so
+    // the longer the chain, the more of each new product is cut off: the per-spectrum NLL of a launch that walks 250 tiles in one
+    // chain is 3.3e-6 (rms) from the float64 oracle, of the same spectra in segmented small-batch launches 7.8e-7
+    // (tools/chain_bias.py, c5's shape; 1.8e-6 against 6.3e-7 at c3's 125 tiles), and at N_h = 17..32 the F gradient of
+    // 20 000 spectra came out 3.6e-4 from the oracle.  So at N_h = 17..32 no chain is longer than QFA_P1_MAX_CHAIN tiles (the
+    // partial records are 4.5 KB per spectrum and segment: 90 MB per segment at c5, against 1.7 ms of pass 1).
     L.wp1 = KP <= 16 ? (QFA_P1_NW == 8 ? plan_work(B, L.ntiles32, 1, NCU, 128) : plan_work(B, L.ntiles32, 1, 2 * NCU))
-                     : plan_work(B, L.ntiles32, 1, NCU);
+                     : plan_work(B, L.ntiles32, 1, NCU, 64, QFA_P1_MAX_CHAIN);
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
     L.oPF = take((size_t)L.ntiles * C::TILE_PF);
@@ -437,7 +455,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
             if (flags & QFA_F_S3_FAST)
                 k_grads_s3<KP, 3><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, bh, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
             else
-                k_grads_s3<KP, 4><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, bh, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
+                k_grads_s3<KP, 6><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, bh, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
         }
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
@@ -456,7 +474,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
         float *BG = Nh > 16 ? ws + L.oBG : nullptr, *GG = Nh > 16 ? BG + (size_t)round_up(B, 64) * L.bg_stride : nullptr;
         grads(0, BG, GG);
         if (Nh > 16)
-            k_grads_s3<KP, 4><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, 1, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
+            k_grads_s3<KP, 6><<<L.wp2.items(), 256, 0, st>>>(B, Npix, Nh, L.ntiles, L.wp2, 1, PFT, SOL, BG, GG, L.bg_stride, accum, slab, (int)D.stride);
     } else {
     for (int bh = 0; bh < (KP + 15) / 16; ++bh) {          // one launch per 16 columns of the F gradient
         if (16 * bh >= Nh) break;

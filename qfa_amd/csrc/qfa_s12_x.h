@@ -688,7 +688,8 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
 #ifndef QFA_S3_ABL
 #define QFA_S3_ABL 0         // timing-only ablations of k_grads_s3: 1 no flush, 2 no input DMA, 4 no beta-scaled products (gamma term only)
 #endif
-template <int KP, int TERMS>      // TERMS: bf16 piece products per stage-3 contraction -- 4 (default) or 3 (QFA_F_S3_FAST)
+template <int KP, int TERMS>      // TERMS: bf16 piece products per stage-3 contraction -- 6 (default: float32 grade; the third
+                                  // piece of Z is 64 more registers: one workgroup per CU), 4 or 3 (QFA_F_S3_FAST)
 __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, int ntiles, WorkPlan wp, int bhalf,
                                                      const float *__restrict__ PFT, const float *__restrict__ SOL,
                                                      const float *__restrict__ BG, const float *__restrict__ GG,
@@ -696,7 +697,8 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
                                                      int slab_stride) {
     static_assert(KP == 32, "k_grads_s3: N_h = 17..32");
     using C = Cfg<KP>;
-    constexpr int RING = 3, BUF_B = 4096;                       // per wave and tile: beta 1 KiB | gamma 1 KiB | Fh 1 KiB | Fm 1 KiB
+    constexpr int RING = 3, BUF_B = TERMS == 6 ? 5120 : 4096;   // per wave and tile: beta 1 KiB | gamma 1 KiB | Fh 1 KiB | Fm 1 KiB (| Fl 1 KiB)
+    constexpr int NREQ = TERMS == 6 ? 5 : 4;                    // input requests per wave and tile
     __shared__ __attribute__((aligned(16))) unsigned char lin[4][RING][BUF_B];
     __shared__ float ldspart[2][4][256];
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_uniform(tid >> 6);
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
     for (int i = tid; i < 2 * 4 * 256; i += 256) (&ldspart[0][0][0])[i] = 0.f;      // inactive waves' slots stay 0
 
     // B operands: Z_s[a = 8g + j][col] of all 16 spectra as two bf16 pieces, p of the spectra 4g + j (gamma term)
-    u32x4 Zh[16], Zm[16];
+    u32x4 Zh[16], Zm[16], Zl[TERMS == 6 ? 16 : 1];
     u32x2 ph, pm, pl;
     {
         const int zcol = 16 * bhalf + lo;
@@ -732,6 +734,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
                 split2(zraw[s][2 * q], zraw[s][2 * q + 1], h, m, l);
                 Zh[s][q] = h;
                 Zm[s][q] = m;
+                if constexpr (TERMS == 6) Zl[s][q] = l;
             }
         float pr[4];
 #pragma unroll
@@ -764,6 +767,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
         const float *fg = uniform_ptr(PFT + (size_t)tg * C::TILE_PFT + C::PFT_MAIN);
         glds16a(fg, (unsigned)lane * 16u, dst + 2048);
         glds16a(fg + 256, (unsigned)lane * 16u, dst + 3072);
+        if constexpr (TERMS == 6) glds16a(fg + 512, (unsigned)lane * 16u, dst + 4096);
     };
     auto flush = [&](int tg, const float (*pp)[256]) {
         const int idx = lane + 64 * wv;
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
     if (n <= 0) return;
     get_tile(0);
     if (n > 1) get_tile(1);
-    if (n > 1) dma_wait<4>();                                   // tile 0 has landed (tile 1 may be in flight)
+    if (n > 1) dma_wait<NREQ>();                                // tile 0 has landed (tile 1 may be in flight)
     else dma_wait<0>();
     __syncthreads();                                            // (also the zeroing of ldspart)
     for (int c = 0; c < n; ++c) {
@@ -791,6 +795,8 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
 
             const u32x4 Fh = *reinterpret_cast<const u32x4 *>(in + 2048 + lane * 16),
                         Fm = *reinterpret_cast<const u32x4 *>(in + 3072 + lane * 16);
+            u32x4 Fl = Fh;
+            if constexpr (TERMS == 6) Fl = *reinterpret_cast<const u32x4 *>(in + 4096 + lane * 16);
 
             float *part = ldspart[pbuf][wv];
             if constexpr (QFA_S3_SETPRIO != 0) __builtin_amdgcn_s_setprio(QFA_S3_SETPRIO);
@@ -802,10 +808,14 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
             const float4 *brow = reinterpret_cast<const float4 *>(bet) + g;          // beta[s][px = 4g .. 4g + 3]
 #pragma unroll
             for (int s = 0; s < ((QFA_S3_ABL & 4) ? 0 : 16); ++s) {
-                f32x4 G = xdl(Fm, Zh[s], zero);
-                if (TERMS >= 4) G = xdl(Fm, Zm[s], G);
-                G = xdl(Fh, Zm[s], G);
-                G = xdl(Fh, Zh[s], G);
+                f32x4 G;
+                if constexpr (TERMS == 6) G = xdl6(Fh, Fm, Fl, Zh[s], Zm[s], Zl[s], zero);
+                else {
+                    G = xdl(Fm, Zh[s], zero);
+                    if (TERMS >= 4) G = xdl(Fm, Zm[s], G);
+                    G = xdl(Fh, Zm[s], G);
+                    G = xdl(Fh, Zh[s], G);
+                }
                 const float4 bq = brow[s * 4];
                 acc[0] = fmaf(bq.x, G[0], acc[0]);
                 acc[1] = fmaf(bq.y, G[1], acc[1]);
@@ -819,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
         // The wave's inputs of tile c + 1 must have landed before it goes round; behind them in its queue are the
         // flush of tile c - 1 and the requests of tile c + 2, which stay in flight.
         if (QFA_S3_ABL & 3) dma_wait<0>();
-        else if (c + 1 < n) dma_wait_n((c + 2 < n ? 4 : 0) + (c >= 1 ? 1 : 0));
+        else if (c + 1 < n) dma_wait_n((c + 2 < n ? NREQ : 0) + (c >= 1 ? 1 : 0));
         step_barrier();
         if (!(QFA_S3_ABL & 1)) flush(tile_of(c), ldspart[pbuf]);          // ldspart[pbuf] is rewritten two tiles later, behind the next barrier
     }

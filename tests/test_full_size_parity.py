@@ -1,7 +1,7 @@
 """GPU parity at BASELINE.json's FULL sizes, section by section (VERDICT r1 "weak" item 1).
 
 For c3 (100 000 x 4000, N_h = 16, masks), c2 (10 000 x 2000, N_h = 8, no masks) and the c5 shape (8000, N_h = 32) at
-2 048 spectra:
+the 20 000 spectra bench.py times:
   * ONE launch over the whole batch against a float64 sum of the same batch accumulated in 512-spectrum HIP launches,
     EACH section of the packed buffer on its own (accF, sumA, gPsi, gOmega, cnt, and g_tau0 / g_c0 / g_beta / sum NLL
     individually) -- the float32 atomic accumulation of sign-alternating sums over 1e5 spectra is where error grows;
@@ -78,4 +78,4 @@ def test_config2_full_size_10k(dev):
 def test_config5_shape_20000(dev):
     """BASELINE configs[4] shape (8000 px, N_h = 32) at the 20 000 spectra per GPU bench.py --config c5 times; oracle on 192
     of them (float64 numpy at 8000 x 32 runs ~10 spectra/s)."""
-    run_config(dev, 8000, 32, 20000, True, 20220705, 192, dict(TOL_ORACLE, F=2e-4))
+    run_config(dev, 8000, 32, 20000, True, 20220705, 192)      # (round 4: six piece products in stage 3 at N_h = 17..32 too: F 1e-4)

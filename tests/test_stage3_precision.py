@@ -171,3 +171,42 @@ def test_headline_shape_24613_spectra_normalised_gradients_vs_float64_oracle(dev
     assert out["default"] == out["pixres"]
     del batch
     torch.cuda.empty_cache()
+
+
+def test_c5_shape_4096_spectra_normalised_gradients_vs_float64_oracle(dev, tmp_path):
+    """BASELINE configs[4]'s shape (8000 px, N_h = 32, masks): the NORMALISED gradients of one HIP launch over 4 096 spectra
+    against the float64 oracle summed over the same spectra on the host cores (the oracle runs ~60 spectra/s there: the
+    20 000-spectrum run of the same comparison is tools/c5_probe.py, its output profiles/r4_c5_precision.txt: F 8.3e-5).
+    From round 4 on stage 3 at N_h = 17..32 issues six piece products too (k_grads_s3<32, 6>) and pass 1 cuts its
+    accumulation chains at 63 tiles (qfa_host.h, QFA_P1_MAX_CHAIN: 3.6e-4 -> 8.3e-5 on the 20 000 spectra)."""
+    import torch
+    from qfa_amd import synthetic
+    from tools import oracle_pool
+    from tools import parity_sections as PS
+    npix, nh, B = 8000, 32, 4096
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=20220700)
+    batch = PS.make_config_batch(p, mu, wav, nb, B, 20220755, dev, True)
+    host = {k: x.cpu().numpy() for k, x in zip(("delta", "error", "zabs", "mask"), batch)}
+    ol, og, sums, counts = oracle_pool.oracle_sums(p, host, str(tmp_path / "oracle"))
+    del host
+    out = {}
+    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)):
+        m = _model(dev, p, mu, nb, nr, nh, fl)
+        acc = m.accumulate(*batch).clone()
+        loss, g = m._finalize(acc, True)
+        e = {k: rel_l2(g[k].cpu().numpy(), og[k]) for k in KEYS}
+        e["loss"] = abs(loss.item() - ol) / abs(ol)
+        d = g["F"].cpu().numpy().astype(np.float64) - og["F"]
+        e["F_over_terms"] = np.linalg.norm(d) / _gF_terms_scale(m, acc)
+        e["cancellation"] = _gF_terms_scale(m, acc) / np.linalg.norm(og["F"])
+        out[name] = e
+    print("4096 x 8000, N_h = 32 vs float64 oracle:", out)
+    six, fast = out["six"], out["fast"]
+    assert six["loss"] < 2e-6
+    # achieved on 20 000 spectra: F 8.3e-5 (5.4e-6 of the cancelling sums in this test's yardstick, which are 15x the gradient)
+    assert six["F"] < 1e-4 and six["F_over_terms"] < 8e-6, six
+    assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
+    assert six["F"] <= 1.05 * fast["F"] + 1e-6, (six["F"], fast["F"])      # six piece products are never the worse form
+    del batch
+    torch.cuda.empty_cache()
