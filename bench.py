@@ -238,6 +238,7 @@ def epoch_leg(params, mu, wav, nb, nr, nh, B, masks, dev, seed, n_batches, epoch
     indexed["rows_in_storage_order"] = one_step(dl.rows_batch(0, B)[0])
     return {"value": world * N * epochs / dt, "indexed_step": indexed, "unit": "spectra/s", "ms_per_step": dt / steps * 1e3, "epochs": epochs,
             "batches_per_epoch": n_batches, "resident_spectra": N, "batch": B, "shuffled": True, "use_graph": bool(use_graph),
+            "graph_steps_per_replay": 8 if use_graph else None,
             "row_stride": dl._stride, "resident_bytes": int(13 * dl._stride) * N, "loader_build_s": t_build,
             "path": "QFA.train -> DeviceDataloader.rewind / next_batch_rows -> QFA.step(batch=ResidentBatch): the kernels read "
                     "rows[s] x row_stride of the resident delta / error / mask (no per-batch kernel, copy or upload)"}

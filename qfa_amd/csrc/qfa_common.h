@@ -222,7 +222,7 @@ static __global__ void k_zfac_pix(const float *__restrict__ pix_ratio, qfa_param
 }
 
 #ifndef QFA_ABL
-#define QFA_ABL 0          // timing-only ablation builds (tools/ablate.sh); 0 = product
+#define QFA_ABL 0          // timing-only ablation builds (build with -DQFA_ABL=n: tools/build_full_variant.sh); 0 = product
 #endif
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 #if QFA_ABL == 1           // no MFMA: keep operands alive, one VALU op instead

@@ -18,17 +18,30 @@ static void gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau
                       int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, const float4 *ZS,
                       const float4 *ZP, float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64,
                       unsigned flags, hipStream_t st) {
-    const bool fast = (flags & QFA_F_S3_FAST) != 0;
+    // QFA_WITH_GFORM (a variant build, tools/build_full_variant.sh gform -DQFA_WITH_GFORM=1): the three-product G form of stage 3 behind QFA_F_S3_FAST --
+    // round 2's headline form, kept out of the shipped library from round 4 on (the host refuses the flag at N_h <= 16)
+#ifndef QFA_WITH_GFORM
+#define QFA_WITH_GFORM 0
+#endif
+    const bool fast = QFA_WITH_GFORM && (flags & QFA_F_S3_FAST) != 0;
     k_prep_pgx<KP><<<ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, ZP, Npix, Nb, Nh, fast ? 0 : 1, PGX);
     auto go = [&](auto hasa, auto terms, auto zf) {
         k_grads_x<KP, decltype(hasa)::value, decltype(terms)::value, decltype(zf)::value><<<wp.items(), 512, 0, st>>>(
             p, b, tau, B, Npix, Nb, Nh, ntiles32, wp, PGX, SOL, ZS, accum, slab, slabS, slab_stride, sc64);
     };
     using T6 = std::integral_constant<int, 6>;
+#if QFA_WITH_GFORM
     using T3 = std::integral_constant<int, 3>;
-    if (b.A_blue) { if (fast) go(std::true_type{}, T3{}, std::false_type{}); else go(std::true_type{}, T6{}, std::false_type{}); }
-    else if (ZS) { if (fast) go(std::false_type{}, T3{}, std::true_type{}); else go(std::false_type{}, T6{}, std::true_type{}); }
-    else { if (fast) go(std::false_type{}, T3{}, std::false_type{}); else go(std::false_type{}, T6{}, std::false_type{}); }
+    if (fast) {
+        if (b.A_blue) go(std::true_type{}, T3{}, std::false_type{});
+        else if (ZS) go(std::false_type{}, T3{}, std::true_type{});
+        else go(std::false_type{}, T3{}, std::false_type{});
+        return;
+    }
+#endif
+    if (b.A_blue) go(std::true_type{}, T6{}, std::false_type{});
+    else if (ZS) go(std::false_type{}, T6{}, std::true_type{});
+    else go(std::false_type{}, T6{}, std::false_type{});
 }
 void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, const float *ZS, const float *ZP,

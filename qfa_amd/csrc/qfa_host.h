@@ -382,6 +382,10 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     };
     bool pass2_xdl = false;
     if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP, B, flags);
+#ifndef QFA_WITH_GFORM
+    // the three-product form of stage 3 at N_h <= 16 (the G form of k_grads_x) is not part of the shipped library any more
+    if constexpr (KP <= 16) { if (flags & QFA_F_S3_FAST) return QFA_E_SIZE; }
+#endif
     mark(0);
     const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
     // the float32 images PF / PFT serve k_grads: not needed when pass 2 runs on the XDL pipe

@@ -242,11 +242,25 @@ class DeviceDataloader(object):
         a, b = self._next_slice()
         return self.rows_view(self._order_dev[a:b])
 
+    def full_batches_left(self):
+        """whole batches of ``batch_size`` rows left in the epoch (not under data parallelism: the parts of a rank vary)"""
+        if self._plan is not None:
+            return 0
+        return (self.local_size - self.cur) // self.batch_size
+
     def next_rows_into(self, buf):
-        """copy the row numbers of the next batch into the caller's fixed int32 device buffer (a captured step graph reads it)"""
-        a, b = self._next_slice()
-        if b - a != buf.shape[0]:
-            raise _lib.QFAHipError(f"next batch has {b - a} rows, the buffer {buf.shape[0]}")
+        """copy the row numbers of the next batch -- or of the next k whole batches, for a buffer of k batch_size rows -- into
+        the caller's fixed int32 device buffer (a captured step graph reads it)"""
+        n = int(buf.shape[0])
+        if self._plan is None and n > self.batch_size:
+            if n % self.batch_size or self.cur + n > self.local_size:
+                raise _lib.QFAHipError(f"{n} rows asked for: not a number of whole batches left in the epoch")
+            a, b = self.cur, self.cur + n
+            self.cur = b
+        else:
+            a, b = self._next_slice()
+        if b - a != n:
+            raise _lib.QFAHipError(f"next batch has {b - a} rows, the buffer {n}")
         buf.copy_(self._order_dev[a:b])
 
     def rows_batch(self, lo, hi):

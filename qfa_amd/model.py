@@ -505,12 +505,13 @@ class QFA(object):
         return StepGraph(self, optimizer, batch_size, resident=resident)
 
     def train(self, optimizer, dataloader, n_epochs, output_dir="./result", save_interval=5, smooth_interval=5,
-              quiet=False, logger=None, use_graph=False):
+              quiet=False, logger=None, use_graph=False, graph_steps=8):
         """Training loop with the reference's control flow (reference QFA/model.py:183-231):
         Niter = data_size // batch_size (quirk Q5), optimizer.step() once per epoch (Q4), early
         stop the first time the epoch-mean NLL is negative (Q6), smooth / save cadence.
         ``use_graph``: replay a captured hipGraph of the step for the full-size batches (small batches are
-        launch-bound: ~15 launches of a few microseconds each); same arithmetic, parameters updated in place."""
+        launch-bound: ~15 launches of a few microseconds each); same arithmetic, parameters updated in place.
+        ``graph_steps``: consecutive steps per replay with a resident loader (StepGraph; the tail of an epoch runs eagerly)."""
         os.makedirs(output_dir, exist_ok=True)
         output_dir = os.path.join(output_dir, "checkpoints")
         os.makedirs(output_dir, exist_ok=True)
@@ -532,7 +533,8 @@ class QFA(object):
         resident = hasattr(dataloader, "next_batch_rows") and self._tau_callable is None
         sg = None
         if use_graph and not self._dp:
-            sg = StepGraph(self, optimizer, dataloader.batch_size, resident=dataloader if resident else None)
+            sg = StepGraph(self, optimizer, dataloader.batch_size, resident=dataloader if resident else None,
+                           steps=graph_steps if resident else 1)
         # Side effects under data parallelism: the replicas are identical, so ONE rank prints, logs and writes the
         # checkpoints (concurrent np.savez of the same path from every rank can interleave into a corrupt zip); the
         # others wait at a barrier so that nobody reads a half-written file.
@@ -626,15 +628,22 @@ class StepGraph(object):
     kernel arguments by value, so the graph is re-captured when they (or a parameter tensor) change -- once per
     epoch in ``QFA.train``.  The first step after such a change runs eagerly (it also warms the workspace up)."""
 
-    def __init__(self, model, optimizer, batch_size, resident=None):
+    def __init__(self, model, optimizer, batch_size, resident=None, steps=1):
         """``resident``: a loader with the resident form (``next_rows_into`` / ``rows_view``): the graph then reads the
-        loader's resident arrays through ONE fixed buffer of row numbers, refilled per step by a device-side copy of
-        4 B bytes, instead of four batch-sized input buffers."""
+        loader's resident arrays through ONE fixed buffer of row numbers, refilled per replay by a device-side copy of
+        4 B bytes per step, instead of four batch-sized input buffers.  ``steps`` (resident form only): consecutive training
+        steps per replay -- the step of the reference's default batch (500 spectra) is 80 us of kernels, and one graph launch
+        plus the refill per step costs half of that again; ``steps`` = 8 replays eight steps (eight consecutive batches of the
+        epoch's order, parameters and Adam moments updated in place between them) with one launch and one refill.  ``run``
+        then returns the SUM of the steps' losses."""
         self.model, self.opt, self.B = model, optimizer, int(batch_size)
         dev = model.device
         self.resident = resident
+        self.steps = int(steps) if resident is not None else 1
+        if self.steps < 1:
+            raise ValueError("steps >= 1")
         if resident is not None:
-            self.rows = torch.zeros((self.B,), dtype=torch.int32, device=dev)
+            self.rows = torch.zeros((self.steps * self.B,), dtype=torch.int32, device=dev)
             self.buf = None
         else:
             self.buf = (torch.empty((self.B, model.Npix), dtype=f32, device=dev),
@@ -649,6 +658,9 @@ class StepGraph(object):
         """the loader's resident arrays (as they are NOW: set_tau rebuilds them) seen through the fixed buffer of row numbers"""
         return self.resident.rows_view(self.rows)
 
+    def _rb_step(self, k):
+        return self.resident.rows_view(self.rows[k * self.B:(k + 1) * self.B])
+
     def _key(self):
         # everything the captured launches bake in: scalars passed by value and every buffer address
         m, o = self.model, self.opt
@@ -660,11 +672,20 @@ class StepGraph(object):
 
     def _body(self):
         m = self.model
-        loss, grads = m.forward(batch=self.rb) if self.resident is not None else m.forward(*self.buf)
-        self.opt.update(m.parameters, grads, clip=m._clip_table(), inplace=True)
-        return loss
+        if self.resident is None:
+            loss, grads = m.forward(*self.buf)
+            self.opt.update(m.parameters, grads, clip=m._clip_table(), inplace=True)
+            return loss
+        total = None
+        for k in range(self.steps):                              # consecutive steps: each sees the previous one's update
+            loss, grads = m.forward(batch=self._rb_step(k))
+            self.opt.update(m.parameters, grads, clip=m._clip_table(), inplace=True)
+            total = loss if total is None else total + loss
+        return total
 
     def fits(self, dataloader):
+        if self.resident is not None and self.steps > 1:
+            return dataloader is self.resident and dataloader.full_batches_left() >= self.steps
         n = dataloader.next_batch_size() if hasattr(dataloader, "next_batch_size") else None
         return n is None or n == self.B
 

@@ -232,10 +232,11 @@ class _ReferenceContractOnly(object):
         return self._dl.next_batch()
 
 
-@pytest.mark.parametrize("nh,use_graph", [(8, False), (8, True), (12, False)])
+@pytest.mark.parametrize("nh,use_graph", [(8, False), (8, 1), (8, 2), (8, 3), (12, False)])
 def test_train_through_the_resident_form_reproduces_the_materialised_loop(dev, nh, use_graph, tmp_path):
     """QFA.train takes the resident form of a DeviceDataloader by itself (next_batch is never called); against the same
-    loop over materialised batches with the same seeds: identical parameters (deterministic accumulation)"""
+    loop over materialised batches with the same seeds: identical parameters (deterministic accumulation).  use_graph = k:
+    the step graph replays k consecutive steps per launch (5 batches per epoch: k = 2 and 3 leave an eager tail)"""
     import torch
     from qfa_amd import QFA, Adam, step_scheduler
     npix, N, B = 1913, 320, 64
@@ -257,7 +258,7 @@ def test_train_through_the_resident_form_reproduces_the_materialised_loop(dev, n
         # (the reference loop is always eager: a step graph fed by a foreign loader copies its batches into fixed buffers and
         # so loses the factored-z attribute of the zabs tensor -- same numbers to rounding, not to the bit)
         m.train(opt, loader, 3, output_dir=str(tmp_path / mode), save_interval=100, smooth_interval=2, quiet=True,
-                use_graph=use_graph and mode == "resident")
+                use_graph=bool(use_graph) and mode == "resident", graph_steps=int(use_graph) or 1)
         res.append({k: getattr(m, k).clone() for k in ("F", "Psi", "omega", "tau0", "c0", "beta")})
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k

@@ -57,7 +57,8 @@ def test_f_columns_spanning_three_decades(dev, npix, nh, B):
     b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=901 + nh)
     ol, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
     errs = {}
-    forms = (("six", 0), ("fast", _lib.F_S3_FAST)) + ((("pixres", _lib.F_PASS2_PIXRES),) if nh <= 16 else ())
+    # (QFA_F_S3_FAST: N_h = 17..32 only in the shipped library)
+    forms = (("six", 0),) + ((("fast", _lib.F_S3_FAST),) if nh > 16 else (("pixres", _lib.F_PASS2_PIXRES),))
     for name, fl in forms:
         m = _model(dev, p, mu, nb, nr, nh, fl)
         loss, g = m.forward(*_bt(b, dev))
@@ -75,7 +76,8 @@ def test_f_columns_spanning_three_decades(dev, npix, nh, B):
     lim = 2e-3 if nh > 16 else 3e-4
     assert six["F"] < lim and six["F_worst_column"] < 2 * lim, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
-    assert errs["fast"]["F"] < 3e-3, errs["fast"]                # (not the default)
+    if "fast" in errs:
+        assert errs["fast"]["F"] < 3e-3, errs["fast"]            # (not the default)
     if "pixres" in errs:                                         # the pixel-resident form of pass 2 (k_grads_t): same bar as six
         t = errs["pixres"]
         assert t["F"] < lim and t["F_worst_column"] < 2 * lim and t["Psi"] < 2e-5 and t["omega"] < 2e-5, t
@@ -107,7 +109,7 @@ def test_near_stationary_parameters_after_200_steps(dev, nh):
     sub = {k: data[k][:96] for k in ("delta", "error", "zabs", "mask")}
     ol, og = O.forward(trained, sub["delta"], sub["error"], sub["zabs"], sub["mask"])
     out = {}
-    for name, fl in (("six", 0), ("fast", _lib.F_S3_FAST)) + ((("pixres", _lib.F_PASS2_PIXRES),) if nh == 16 else ()):
+    for name, fl in (("six", 0),) + ((("pixres", _lib.F_PASS2_PIXRES),) if nh == 16 else (("fast", _lib.F_S3_FAST),)):
         mm = _model(dev, trained, mu, nb, nr, nh, fl)
         acc = mm.accumulate(*_bt(sub, dev)).clone()
         loss, g = mm._finalize(acc, True)
@@ -117,11 +119,12 @@ def test_near_stationary_parameters_after_200_steps(dev, nh):
                      "cancellation": _gF_terms_scale(mm, acc) / np.linalg.norm(og["F"])}
     print("after 200 steps:", nh, out)
     six = out["six"]
-    # achieved: F_rel 5.4e-6 / 8.6e-6 (N_h = 16 / 32) with the default, 8.9e-6 / 8.6e-6 with F_S3_FAST (at N_h = 32 the
-    # default is four products over two pieces -- k_grads_s3 holds no third piece of Z -- and "fast" three)
+    # achieved: F_rel 5.4e-6 / 8.6e-6 (N_h = 16 / 32) with the default (six products everywhere from round 4 on); 8.6e-6 with
+    # F_S3_FAST at N_h = 32
     assert six["F_over_terms"] < 8e-6 and six["F_rel"] < 3e-5, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
-    assert out["fast"]["F_rel"] < 2e-4, out["fast"]
+    if "fast" in out:
+        assert out["fast"]["F_rel"] < 2e-4, out["fast"]
     if "pixres" in out:                                          # k_grads_t: the same bars as the six-term default
         t = out["pixres"]
         assert t["F_over_terms"] < 8e-6 and t["F_rel"] < 3e-5 and t["Psi"] < 2e-5 and t["omega"] < 2e-5, t
@@ -144,7 +147,7 @@ def test_headline_shape_24613_spectra_normalised_gradients_vs_float64_oracle(dev
     host = {k: x.cpu().numpy() for k, x in zip(("delta", "error", "zabs", "mask"), batch)}
     ol, og, sums, counts = oracle_pool.oracle_sums(p, host, str(tmp_path / "oracle"))
     out = {}
-    for name, fl in (("default", 0), ("six", _lib.F_PASS2_XDL), ("fast", _lib.F_PASS2_XDL | _lib.F_S3_FAST), ("pixres", _lib.F_PASS2_PIXRES)):
+    for name, fl in (("default", 0), ("six", _lib.F_PASS2_XDL), ("pixres", _lib.F_PASS2_PIXRES)):
         m = _model(dev, p, mu, nb, nr, nh, fl)
         acc = m.accumulate(*batch).clone()
         loss, g = m._finalize(acc, True)
@@ -155,13 +158,12 @@ def test_headline_shape_24613_spectra_normalised_gradients_vs_float64_oracle(dev
         e["cancellation"] = _gF_terms_scale(m, acc) / np.linalg.norm(og["F"])
         out[name] = e
     print("24613 x 4000, N_h = 16 vs float64 oracle:", out)
-    six, fast = out["six"], out["fast"]
+    six = out["six"]
     assert six["loss"] < 2e-6
-    # achieved: six F 2.3e-5 (1.1e-6 of the cancelling sums, which are 21x the gradient); three 5.5e-5 (2.6e-6): at this
-    # batch size the narrow product IS visible, which is why six is the default and the headline
+    # achieved: six F 2.3e-5 (1.1e-6 of the cancelling sums, which are 21x the gradient); round 2's three-product form (no
+    # longer in the shipped library) was at 5.5e-5 (2.6e-6): at this batch size the narrow product IS visible
     assert six["F"] < 6e-5 and six["F_over_terms"] < 3e-6, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
-    assert six["F"] <= 1.05 * fast["F"] + 1e-6, (six["F"], fast["F"])      # six piece products are never the worse form
     # the pixel-resident form (k_grads_t: W accumulated in float32 MFMA registers over 2 500 spectra per range, F applied once
     # at the end) meets the same bars
     for name in ("pixres", "default"):

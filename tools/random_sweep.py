@@ -29,7 +29,7 @@ for case in range(ncase):
     if nh <= 16: forms += [("det+pixres", _lib.F_PASS2_PIXRES, None)]
     if nh <= 16:
         forms += [("xdl", _lib.F_PASS2_XDL, None), ("xdl+zfac", _lib.F_PASS2_XDL, zfac), ("f32", _lib.F_PASS2_F32, zfac),
-                  ("fast", _lib.F_PASS2_XDL | _lib.F_S3_FAST, None)]
+                  ]
         if True:
             forms += [("pixres", _lib.F_PASS2_PIXRES, None), ("pixres+zfac", _lib.F_PASS2_PIXRES, zfac)]
     msgs = []
