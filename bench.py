@@ -599,7 +599,7 @@ def main():
             del b1, m1
             torch.cuda.empty_cache()
     if world == 1 and not args.no_epoch:
-        nbat = args.epoch_batches or max(4, -(-32768 // B))
+        nbat = args.epoch_batches or max(4, -(-131072 // B))
         graph = (B <= 2048) if args.epoch_graph < 0 else bool(args.epoch_graph)
         ep_epochs = max(2, min(50, int(1.0 / max(nbat * step_ms * 1e-3, 1e-3))))
         ep = epoch_leg(params, mu, wav, nb, nr, nh, B, masks, dev, 20220900 + cfg_index, nbat, ep_epochs, graph)

@@ -101,6 +101,9 @@ typedef struct {
                                   * QFA_F_PASS2_* flag the library picks between k_grads_x (small batches) and this form
                                   * (from 96 spectra per CU on; N_h <= 8 and N_pix >= 1024: from 36 per CU on) --
                                   * qfa_host.h, pass2_use_pixres                                                      */
+#define QFA_F_ZERO_ACCUM   0x80u /* qfa_nll_grad_*: the library zeroes `accum` itself before it adds to it (inside the first
+                                  * kernel of the call: one launch less than a caller-side fill -- the step of a small
+                                  * batch is a chain of dependent launches a few microseconds long)                  */
 /* (0x10: the one-wave-per-SIMD form k_grads_w of round 3, removed from the library in round 4 -- same results, 5.4 against
  *  2.15 ms at c3; the measurement is kept in profiles/r3_ablation_pass2.txt) */
 

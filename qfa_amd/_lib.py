@@ -24,6 +24,7 @@ ABI_VERSION = 3
 # `flags` of qfa_nll_grad_ex_f32 / qfa_predict_ex_f32 (include/qfa_hip.h QFA_F_*)
 F_PASS2_F32, F_PASS2_XDL, F_S3_FAST, F_PREDICT_F32, F_SYNC = 0x1, 0x2, 0x4, 0x8, 0x20
 F_PASS2_PIXRES = 0x40
+F_ZERO_ACCUM = 0x80
 
 
 class QFAHipError(RuntimeError):

@@ -205,13 +205,16 @@ __device__ __forceinline__ const unsigned char *lane_ptr(const void *sbase, unsi
 }
 
 // ZS[s] from zq1[row of s] = 1 + z_qso;  ZP[i] from pix_ratio[i] = wav_i / 1215.67 (blue pixels)
-static __global__ void k_zfac_spec(const float *__restrict__ zq1, const int *__restrict__ rows, qfa_params_t p, qfa_tau_t tau,
-                                   int B, float4 *__restrict__ ZS) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void zfac_spec_body(int s, const float *__restrict__ zq1, const int *__restrict__ rows,
+                                               const qfa_params_t &p, const qfa_tau_t &tau, int B, float4 *__restrict__ ZS) {
     if (s >= B) return;
     const double l2s = log2((double)zq1[rows ? rows[s] : s]);
     const double ts = -1.4426950408889634 * (double)tau.amp * exp2((double)tau.expo * (l2s + log2((double)tau.scale)));
     ZS[s] = float4{(float)ts, (float)exp2((double)*p.beta * l2s), (float)l2s, 0.f};
+}
+static __global__ void k_zfac_spec(const float *__restrict__ zq1, const int *__restrict__ rows, qfa_params_t p, qfa_tau_t tau,
+                                   int B, float4 *__restrict__ ZS) {
+    zfac_spec_body(blockIdx.x * blockDim.x + threadIdx.x, zq1, rows, p, tau, B, ZS);
 }
 static __global__ void k_zfac_pix(const float *__restrict__ pix_ratio, qfa_params_t p, qfa_tau_t tau, int Nb,
                                   float4 *__restrict__ ZP) {
@@ -220,6 +223,22 @@ static __global__ void k_zfac_pix(const float *__restrict__ pix_ratio, qfa_param
     const double l2i = log2((double)pix_ratio[i]);
     ZP[i] = float4{(float)exp2((double)tau.expo * l2i), (float)exp2((double)*p.beta * l2i), (float)l2i, 0.f};
 }
+
+// The per-pixel factors as the image builders take them: the table k_zfac_pix wrote, or -- the fused per-step prep kernel,
+// where no table exists yet -- computed in place from pix_ratio with k_zfac_pix's own arithmetic (bit-identical images).
+struct ZPSrc {
+    const float4 *tab;
+    const float *ratio;
+    const float *beta;
+    float expo;
+    __device__ __forceinline__ bool on() const { return tab != nullptr || ratio != nullptr; }
+    __device__ __forceinline__ float4 at(int i) const {
+        if (tab) return tab[i];
+        const double l2i = log2((double)ratio[i]);
+        return float4{(float)exp2((double)expo * l2i), (float)exp2((double)*beta * l2i), (float)l2i, 0.f};
+    }
+};
+__host__ __device__ inline ZPSrc zp_table(const float4 *ZP) { return ZPSrc{ZP, nullptr, nullptr, 0.f}; }
 
 #ifndef QFA_ABL
 #define QFA_ABL 0          // timing-only ablation builds (build with -DQFA_ABL=n: tools/build_full_variant.sh); 0 = product

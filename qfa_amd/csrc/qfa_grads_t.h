@@ -54,13 +54,13 @@ struct GtPlan {
 // k_prep_pgt : F, Psi, omega (+ the per-pixel factors of the factored-z form) -> the image of every 16-pixel tile
 // ------------------------------------------------------------------------------------------------
 template <int KP>
-__global__ __launch_bounds__(256) void k_prep_pgt(const float *__restrict__ F, const float *__restrict__ Psi,
-                                                  const float *__restrict__ omega, const float4 *__restrict__ ZP,
-                                                  int Npix, int Nb, int Nh, unsigned char *__restrict__ PGT) {
+__device__ __forceinline__ void prep_pgt_body(int bid, const float *__restrict__ F, const float *__restrict__ Psi,
+                                              const float *__restrict__ omega, const ZPSrc &ZP, int Npix, int Nb, int Nh,
+                                              unsigned char *__restrict__ PGT) {
     using GT = GTT<KP>;
-    unsigned char *tile = PGT + (size_t)blockIdx.x * GT::TILE_B;
-    // tile blockIdx = TPW wt + j of wave tile wt: column lo <-> pixel PXW wt + TPW lo + j
-    const int p0 = GT::PXW * ((int)blockIdx.x / GT::TPW) + (int)blockIdx.x % GT::TPW;
+    unsigned char *tile = PGT + (size_t)bid * GT::TILE_B;
+    // tile bid = TPW wt + j of wave tile wt: column lo <-> pixel PXW wt + TPW lo + j
+    const int p0 = GT::PXW * (bid / GT::TPW) + bid % GT::TPW;
     auto pixel = [&](int lo) { return p0 + GT::TPW * lo; };
     __shared__ float f[16][KP + 1];
     for (int i = threadIdx.x; i < 16 * KP; i += 256) {
@@ -99,14 +99,20 @@ __global__ __launch_bounds__(256) void k_prep_pgt(const float *__restrict__ F, c
         float v = 0.f;
         if (j < 16) v = px < Npix ? Psi[px] : 0.f;
         else if (j < 32) v = px < Nb ? omega[px] : 0.f;
-        else if (j < 80 && ZP && px < Nb) {
-            const float4 q = ZP[px];
+        else if (j < 80 && ZP.on() && px < Nb) {
+            const float4 q = ZP.at(px);
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
         }
         reinterpret_cast<float *>(tile + GT::OFF_PAR)[j] = v;
     }
     float *fr = reinterpret_cast<float *>(tile + GT::OFF_F);
     for (int i = threadIdx.x; i < 16 * KP; i += 256) fr[i] = f[i / KP][i % KP];
+}
+template <int KP>
+__global__ __launch_bounds__(256) void k_prep_pgt(const float *__restrict__ F, const float *__restrict__ Psi,
+                                                  const float *__restrict__ omega, const float4 *__restrict__ ZP,
+                                                  int Npix, int Nb, int Nh, unsigned char *__restrict__ PGT) {
+    prep_pgt_body<KP>(blockIdx.x, F, Psi, omega, zp_table(ZP), Npix, Nb, Nh, PGT);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -107,12 +107,12 @@ __device__ __forceinline__ f32x16 xdl32_6(const u32x4 &ah, const u32x4 &am, cons
 //   stage-3 part       [piece][lane (r, h2)][8 a] bf16: A[px = r][a = 8 h2 + j]
 // ------------------------------------------------------------------------------------------------
 template <int KP>
-__global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, const float *__restrict__ Psi,
-                                                  const float *__restrict__ omega, const float4 *__restrict__ ZP,
-                                                  int Npix, int Nb, int Nh, int wform, unsigned char *__restrict__ PGX) {
+__device__ __forceinline__ void prep_pgx_body(int bid, const float *__restrict__ F, const float *__restrict__ Psi,
+                                              const float *__restrict__ omega, const ZPSrc &ZP, int Npix, int Nb, int Nh,
+                                              int wform, unsigned char *__restrict__ PGX) {
     using GX = GXT<KP>;
-    unsigned char *tile = PGX + (size_t)blockIdx.x * GX::TILE_B;
-    const int p0 = 32 * blockIdx.x;
+    unsigned char *tile = PGX + (size_t)bid * GX::TILE_B;
+    const int p0 = 32 * bid;
     __shared__ float f[32][17];
     for (int i = threadIdx.x; i < 32 * 16; i += 256) {
         const int px = i >> 4, a = i & 15;
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, c
         float v = 0.f;
         if (j < 16) v = px < Npix ? Psi[px] : 0.f;
         else if (j < 32) v = px < Nb ? omega[px] : 0.f;
-        else if (j < 80 && ZP && px < Nb) {                 // factored-z form: ti | pwi | l2i of the half's pixels
-            const float4 q = ZP[px];
+        else if (j < 80 && ZP.on() && px < Nb) {            // factored-z form: ti | pwi | l2i of the half's pixels
+            const float4 q = ZP.at(px);
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
         }
         po[j] = v;
@@ -179,6 +179,12 @@ __global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, c
         *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
         *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
     }
+}
+template <int KP>
+__global__ __launch_bounds__(256) void k_prep_pgx(const float *__restrict__ F, const float *__restrict__ Psi,
+                                                  const float *__restrict__ omega, const float4 *__restrict__ ZP,
+                                                  int Npix, int Nb, int Nh, int wform, unsigned char *__restrict__ PGX) {
+    prep_pgx_body<KP>(blockIdx.x, F, Psi, omega, zp_table(ZP), Npix, Nb, Nh, wform, PGX);
 }
 
 struct SpecA {                       // role A: one lane's 4 spectra x 2 pixels of a tile (sigma < 0: masked pixel)

@@ -11,7 +11,12 @@
 size_t qfa_gx_image_bytes(int KP, int ntiles32);
 void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix, int Nb, int Nh,
                    int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, const float *ZS, const float *ZP,
-                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st);
+                   float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64, unsigned flags, hipStream_t st,
+                   bool prep = true);
+// everything a training step derives from the parameters before pass 1, in one launch (N_h <= 16; qfa_gx.hip, k_prep_step)
+void qfa_prep_step_launch(int KP, bool pixres, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
+                          int Nb, int Nh, int ntiles32, unsigned char *PFX, unsigned char *P2, float *ZS, float *zero,
+                          size_t n_zero, hipStream_t st);
 
 // the pixel-resident form of the all-XDL pass 2 (qfa_grads_t.h, built in qfa_gx.hip; N_h = 9..16): QFA_F_PASS2_PIXRES
 struct GtPlan;
@@ -315,10 +320,10 @@ inline ZTables launch_zfac(const qfa_params_t &p, const qfa_batch_t &b, const qf
 // pass 1 on the XDL pipe (split-bf16 operands, 32-pixel tiles) at every N_h
 template <int KP, bool PREDICT>
 void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, const float *mu, int B, int Npix,
-                   int Nb, int Nh, const Layout &L, const ZTables &zt, float *ws, hipStream_t st) {
+                   int Nb, int Nh, const Layout &L, const ZTables &zt, float *ws, hipStream_t st, bool prep = true) {
     float *MOM = ws + L.oMOM;
     unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
-    k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, Npix, Nb, Nh, PFX);
+    if (prep) k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, Npix, Nb, Nh, PFX);
     constexpr int NW = KP <= 16 ? QFA_P1_NW : 4;      // (L.spb1 = 16 NW spectra per block)
     if (zt.ZS)
         k_moments_x<KP, PREDICT, NW, true><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, zt.ZS, MOM);
@@ -387,13 +392,29 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     if constexpr (KP <= 16) { if (flags & QFA_F_S3_FAST) return QFA_E_SIZE; }
 #endif
     mark(0);
-    const ZTables zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
-    // the float32 images PF / PFT serve k_grads: not needed when pass 2 runs on the XDL pipe
-    if (!(KP <= 16 && pass2_xdl)) launch_prep<KP>(p, zt.ZP, Npix, Nb, Nh, L, PF, PFT, st);
     const bool pixres = pass2_xdl && pass2_use_pixres(KP, B, Npix, flags);             // (its ragged-tile staging wants N_pix >= 4)
-    if (pixres) qfa_gt_prep_image(KP, p, reinterpret_cast<const float *>(zt.ZP), Npix, Nb, Nh, reinterpret_cast<unsigned char *>(ws + L.oPGX), st);
+    const size_t n_acc = (size_t)Npix * Nh + 3 * (size_t)Npix + Nb + 8;
+    ZTables zt{nullptr, nullptr};
+    bool fused = false;
+    if constexpr (KP == 8 || KP == 16) {
+        // both passes on the XDL pipe: ONE launch builds the two images and the per-spectrum factors (and zeroes accum)
+        if (pass2_xdl) {
+            fused = true;
+            const bool zf = b.zq1 && b.pix_ratio && Nb > 0;
+            if (zf) zt.ZS = reinterpret_cast<float4 *>(ws + L.oZS);
+            qfa_prep_step_launch(KP, pixres, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, reinterpret_cast<unsigned char *>(ws + L.oPFX),
+                                 reinterpret_cast<unsigned char *>(ws + L.oPGX), zf ? ws + L.oZS : nullptr,
+                                 (flags & QFA_F_ZERO_ACCUM) ? accum : nullptr, n_acc, st);
+        }
+    }
+    if (!fused) {
+        if (flags & QFA_F_ZERO_ACCUM) (void)hipMemsetAsync(accum, 0, n_acc * sizeof(float), st);
+        zt = launch_zfac(p, b, tau, B, Nb, L, ws, st);
+        // the float32 images PF / PFT serve k_grads (and the N_h = 17..32 kernels)
+        launch_prep<KP>(p, zt.ZP, Npix, Nb, Nh, L, PF, PFT, st);
+    }
     mark(1);
-    launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, zt, ws, st);
+    launch_moments<KP, false>(p, b, tau, nullptr, B, Npix, Nb, Nh, L, zt, ws, st, !fused);
     mark(2);
     sum_segments<KP>(MOM, L, B, st);
     constexpr int G = 64 / KP;
@@ -439,7 +460,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     if (pass2_xdl) {
         qfa_gx_launch(KP, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, L.wp2x, reinterpret_cast<unsigned char *>(ws + L.oPGX), SOL,
                       reinterpret_cast<const float *>(zt.ZS), reinterpret_cast<const float *>(zt.ZP), accum, slab, slabS,
-                      (int)D.stride, sc64, flags, st);
+                      (int)D.stride, sc64, flags, st, !fused);
         if (slab) launch_reduce_slab(slab, D, B, L.wp2x.items() * 4, accum, st);
         mark(4);
         return hip_status(st, flags);

@@ -193,13 +193,12 @@ __device__ __forceinline__ void step_barrier() {        // LDS writes of this st
 
 // ------------------------------------------------------------------------------------------------
 template <int KP>
-__global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, const float *__restrict__ Psi,
-                                                  const float *__restrict__ omega, const float *__restrict__ mu,
-                                                  const float4 *__restrict__ ZP, int Npix, int Nb, int Nh,
-                                                  unsigned char *__restrict__ PFX) {
+__device__ __forceinline__ void prep_pfx_body(int bid, const float *__restrict__ F, const float *__restrict__ Psi,
+                                              const float *__restrict__ omega, const float *__restrict__ mu,
+                                              const ZPSrc &ZP, int Npix, int Nb, int Nh, unsigned char *__restrict__ PFX) {
     using C = Cfg<KP>;
     using X = XCfg<KP>;
-    unsigned char *tile = PFX + (size_t)blockIdx.x * X::TILE_B;
+    unsigned char *tile = PFX + (size_t)bid * X::TILE_B;
     for (int idx = threadIdx.x; idx < X::NCOL * 16; idx += 256) {         // (column, pixel pair)
         const int c = idx >> 4, q = (idx & 15) * 2;
         float v[2] = {0.f, 0.f};
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, c
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int i = 32 * blockIdx.x + q + e;
+            const int i = 32 * bid + q + e;
             if (okc && i < Npix) v[e] = pairc ? F[(size_t)i * Nh + a] * F[(size_t)i * Nh + b] : F[(size_t)i * Nh + a];
         }
         unsigned h, m, l;
@@ -235,15 +234,22 @@ __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, c
     }
     float *po = reinterpret_cast<float *>(tile + X::OFF_PSI);
     for (int idx = threadIdx.x; idx < (X::SUB0_B - X::OFF_PSI) / 4; idx += 256) {
-        const int i = 32 * blockIdx.x + (idx & 31);
+        const int i = 32 * bid + (idx & 31);
         float v = 0.f;
         if (idx < 32) v = i < Npix ? Psi[i] : 0.f;
         else if (idx < 64) v = i < Nb ? omega[i] : 0.f;
         else if (idx < 96) v = (mu && i < Npix) ? mu[i] : 0.f;      // mean continuum (prediction: delta = flux - mu A)
-        else if (idx < 128) v = (ZP && i < Nb) ? ZP[i].x : 0.f;     // factored-z form: ti
-        else if (idx < 160) v = (ZP && i < Nb) ? ZP[i].y : 0.f;     //                  pwi
+        else if (idx < 128) v = (ZP.on() && i < Nb) ? ZP.at(i).x : 0.f;     // factored-z form: ti
+        else if (idx < 160) v = (ZP.on() && i < Nb) ? ZP.at(i).y : 0.f;     //                  pwi
         po[idx] = v;
     }
+}
+template <int KP>
+__global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, const float *__restrict__ Psi,
+                                                  const float *__restrict__ omega, const float *__restrict__ mu,
+                                                  const float4 *__restrict__ ZP, int Npix, int Nb, int Nh,
+                                                  unsigned char *__restrict__ PFX) {
+    prep_pfx_body<KP>(blockIdx.x, F, Psi, omega, mu, zp_table(ZP), Npix, Nb, Nh, PFX);
 }
 
 // ------------------------------------------------------------------------------------------------

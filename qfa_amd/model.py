@@ -243,13 +243,14 @@ class QFA(object):
             self._ws["ws"] = ws
         return ws
 
-    def _accum(self):
+    def _accum(self, zero=True):
         n = _lib.lib().qfa_accum_floats(self.Npix, self.Nb, self.Nh)
         acc = self._ws.get("accum")
         if acc is None or acc.numel() != n:
             acc = torch.empty(n, dtype=f32, device=self.device)
             self._ws["accum"] = acc
-        acc.zero_()
+        if zero:
+            acc.zero_()
         return acc
 
     def _check_batch_shapes(self, delta, error, zabs, mask):
@@ -326,7 +327,9 @@ class QFA(object):
             B = self._check_batch_shapes(delta, error, zabs, mask)
             bs, keep = self._batch_struct(delta, error, zabs, mask, zfac)
         ws = self._workspace(B)
-        acc = self._accum() if accum is None else accum
+        # (the model's own buffer is zeroed by the library's first kernel, QFA_F_ZERO_ACCUM: one launch less per step)
+        acc = self._accum(zero=False) if accum is None else accum
+        zero_flag = _lib.F_ZERO_ACCUM if accum is None else 0
         evs = None
         if events is not None:
             evs = (C.c_void_p * 5)(*[C.c_void_p(e.cuda_event) for e in events])
@@ -341,8 +344,8 @@ class QFA(object):
         _lib.check(_lib.lib().qfa_nll_grad_ex_f32(
             C.byref(ps), C.byref(bs), C.byref(self._tau_model), B, self.Npix, self.Nb, self.Nh,
             C.c_void_p(nll.data_ptr()) if nll is not None else None, C.c_void_p(acc.data_ptr()),
-            C.c_void_p(ws.data_ptr()), ws.numel(), slab, slab_bytes, int(self.flags), _lib.current_stream(self.device),
-            evs), "qfa_nll_grad_ex_f32")
+            C.c_void_p(ws.data_ptr()), ws.numel(), slab, slab_bytes, int(self.flags) | zero_flag,
+            _lib.current_stream(self.device), evs), "qfa_nll_grad_ex_f32")
         return acc
 
     def _finalize(self, acc, normalize=True):
