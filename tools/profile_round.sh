@@ -4,7 +4,7 @@ tag=${1:-r1}; cfg=${2:-c3}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 d=$R/gpurun_out/prof_${tag}_${cfg}; rm -rf $d
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline > $d.json 2> $d.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline ${BENCH_ARGS} > $d.json 2> $d.err
 f=$(find $d -name "*kernel_stats.csv" | head -1)
 (head -1 $f; grep -E '"(void )?k_' $f) > $R/gpurun_out/${tag}_${cfg}_kernel_stats.csv
 cd $R
