@@ -338,7 +338,7 @@ def test_dp_training_loop_global_reshuffle_world2_gloo_cpu():
         assert np.allclose(params[k], ref[k], rtol=1e-9, atol=1e-12), k
 
 
-def _worker_train_gpu(rank, world, port, q, backend, outdir=None):
+def _worker_train_gpu(rank, world, port, q, backend, outdir=None, reshuffle="shard", bs=10):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -357,8 +357,8 @@ def _worker_train_gpu(rank, world, port, q, backend, outdir=None):
     m.enable_data_parallel(optimizer=opt)             # ... rank 0's is broadcast
     # world 1 shuffles with numpy's global generator as the reference does: unshuffled there, or the one-spectrum tail
     # batch is the red-only spectrum once in 11 epochs (no blue pixel observed: NaN gradients, quirk Q3)
-    dl = DeviceDataloader(b["flux"], b["error"], b["zqso"], wav, 10, dev, rank=rank, world=world, seed=5,
-                          shuffle=world > 1)
+    dl = DeviceDataloader(b["flux"], b["error"], b["zqso"], wav, bs, dev, rank=rank, world=world, seed=5,
+                          shuffle=world > 1, reshuffle=reshuffle)
     import tempfile
     if outdir is not None:
         # ONE output directory for every rank, a checkpoint after every epoch: only the lead rank may write
@@ -391,11 +391,11 @@ def _worker_train_gpu(rank, world, port, q, backend, outdir=None):
     dist.destroy_process_group()
 
 
-def _run_train_gpu(world, backend, outdir=None):
+def _run_train_gpu(world, backend, outdir=None, reshuffle="shard", bs=10):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 33500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker_train_gpu, args=(r, world, port, q, backend, outdir)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_train_gpu, args=(r, world, port, q, backend, outdir, reshuffle, bs)) for r in range(world)]
     [pr.start() for pr in procs]
     gathered = _collect(procs, q, 300)
     [pr.join(120) for pr in procs]
@@ -441,6 +441,37 @@ def test_dp_train_two_ranks_sharded_loader_matches_single_process():
         # the two runs differ by the order of float32 sums only; Adam's first steps move every element by ~lr * sign(g),
         # so an element whose gradient sits at rounding level may land 2 lr apart: loose bound, exactness of the
         # protocol is test_dp_training_loop_world2_gloo_cpu's job
+        assert np.isfinite(a).all() and np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-30) < 1e-2, k
+
+
+@pytest.mark.gpu
+def test_dp_train_two_ranks_global_reshuffle_matches_the_single_process_batches():
+    """DeviceDataloader(reshuffle="global") under QFA.train on two processes sharing the GPU: every rank feeds the members of
+    global batch k = perm[k B:(k+1) B] that live in its resident shard (uneven parts, through the indexed form); against a
+    single process walking the SAME permutation -- the reference's batches (QFA/dataloader.py:154-167)"""
+    from qfa_amd import QFA, Adam, step_scheduler
+    from qfa_amd.dataloader import DeviceDataloader
+    from qfa_amd.distributed import ShardPlan
+    g = _run_train_gpu(2, "gloo", None, "global", 4)
+    (p0, mu0, n0, c0), (p1, mu1, n1, c1) = g
+    assert (n0, n1) == (6, 5) and c0 and c1
+    for k in KEYS:
+        assert np.array_equal(p0[k], p1[k], equal_nan=True), k
+    dev = torch.device("cuda:0")
+    p, mu, nb, b, wav = _train_case()
+    torch.manual_seed(100)
+    m = QFA(nb, 96 - nb, 3, dev)
+    opt = Adam(m.parameters, dev, scheduler=step_scheduler(0.9, 1), learning_rate=1e-2, weight_decay=1e-1)
+    dl = DeviceDataloader(b["flux"], b["error"], b["zqso"], wav, 4, dev, shuffle=False)
+    m.mu = torch.tensor(dl.mu, dtype=torch.float32, device=dev)
+    single = ShardPlan(11, 4, 0, 1, seed=5, reshuffle="global")
+    assert single.steps == 3
+    for epoch in range(2):
+        for rows in single.epoch_rows(epoch):
+            m.step(opt, *dl._build(rows))
+        opt.step()
+    for k in KEYS:
+        a, r = p0[k].astype(np.float64), m.parameters[k].cpu().numpy().astype(np.float64)
         assert np.isfinite(a).all() and np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-30) < 1e-2, k
 
 
