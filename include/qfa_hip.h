@@ -226,6 +226,14 @@ typedef struct {
 int qfa_adam_clip_multi_f32(const qfa_adam_multi_t *t, double lr, double b1, double b2, double eps, double wd, int i,
                             void *stream);
 
+/* qfa_finalize_grads_f32 (normalised) followed by qfa_adam_clip_multi_f32 for the six parameter tensors in ONE launch -- the
+ * reference's `loss, grad = self.forward(...); self.parameters = optimizer.update(self.parameters, grad)` (QFA/model.py:212-214)
+ * without the gradients in between.  `t` holds the tensors in the order F, Psi, omega, tau0, c0, beta (count = 6; its `g`
+ * pointers are not read); the gradient of every element is formed from `accum` with k_finalize's arithmetic and fed to
+ * qfa_adam_clip_multi_f32's: the new parameters are bit-identical to the two calls.  loss (1 float) = sum NLL / n_spectra. */
+int qfa_finalize_adam_clip_f32(const float *accum, int Npix, int Nb, int Nh, const qfa_adam_multi_t *t, double lr, double b1,
+                               double b2, double eps, double wd, int i, float *loss, void *stream);
+
 /* Replaces QFA.clip for one tensor (reference QFA/model.py:233-241): y = clamp(x, lo, hi), NaN kept. */
 int qfa_clip_f32(const float *x, float *y, size_t n, float lo, float hi, void *stream);
 

@@ -16,7 +16,7 @@ EXPORTS = (
     "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_nll_grad_det_f32", "qfa_nll_grad_ex_f32", "qfa_predict_ex_f32", "qfa_det_slab_bytes", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_predict_events_f32",
     "qfa_adam_clip_f32",
     "qfa_adam_clip_multi_f32", "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32", "qfa_build_batch_f32", "qfa_mu_estimate_f64",
-    "qfa_mu_sums_f64", "qfa_mu_finish_f64", "qfa_build_resident_f32",
+    "qfa_mu_sums_f64", "qfa_mu_finish_f64", "qfa_build_resident_f32", "qfa_finalize_adam_clip_f32",
 )
 
 TAU_IDS = {"becker": 0, "fg": 1, "kamble": 2, "mock": 3}
@@ -93,6 +93,7 @@ def lib():
                                        p, p, p, p, p, p, sz, p, C.POINTER(C.c_void_p)]),
         "qfa_adam_clip_f32": (i, [p, p, p, p, p, sz, d, d, d, d, d, i, f, f, p]),
         "qfa_adam_clip_multi_f32": (i, [C.POINTER(AdamMulti), d, d, d, d, d, i, p]),
+        "qfa_finalize_adam_clip_f32": (i, [p, i, i, i, C.POINTER(AdamMulti), d, d, d, d, d, i, p, p]),
         "qfa_clip_f32": (i, [p, p, sz, f, f, p]),
         "qfa_smooth_f32": (i, [p, p, i, i, i, p]),
         "qfa_tau_f32": (i, [p, p, sz, C.POINTER(TauModel), p]),

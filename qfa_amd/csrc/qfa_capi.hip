@@ -185,6 +185,28 @@ int qfa_adam_clip_multi_f32(const qfa_adam_multi_t *t, double lr, double b1, dou
     return hip_status();
 }
 
+int qfa_finalize_adam_clip_f32(const float *accum, int Npix, int Nb, int Nh, const qfa_adam_multi_t *t, double lr, double b1,
+                               double b2, double eps, double wd, int i, float *loss, void *stream) {
+    if (!accum || !t || !loss) return QFA_E_NULL;
+    if (int e = check_shape(1, Npix, Nb, Nh)) return e;
+    if (t->count != 6 || i < 0) return QFA_E_SIZE;
+    const size_t want[6] = {(size_t)Npix * Nh, (size_t)Npix, (size_t)Nb, 1, 1, 1};
+    AdamMultiArgs a;
+    a.t = *t;
+    unsigned nblk = 0;
+    for (int k = 0; k < 6; ++k) {
+        if (t->n[k] != want[k]) return QFA_E_SIZE;
+        if (t->n[k] != 0 && (!t->p[k] || !t->m[k] || !t->v[k] || !t->p_out[k])) return QFA_E_NULL;
+        a.blk0[k] = nblk;
+        nblk += (unsigned)((t->n[k] + 255) / 256);
+    }
+    for (int k = 6; k <= QFA_ADAM_MAX; ++k) a.blk0[k] = nblk;
+    const float bc1 = (float)(1.0 - pow(b1, (double)(i + 1))), bc2 = (float)(1.0 - pow(b2, (double)(i + 1)));
+    k_finalize_adam<<<nblk, 256, 0, (hipStream_t)stream>>>(a, accum, Npix, Nb, Nh, loss, (float)lr, (float)b1, (float)b2,
+                                                           (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, bc1, bc2);
+    return hip_status();
+}
+
 int qfa_clip_f32(const float *x, float *y, size_t n, float lo, float hi, void *stream) {
     if (n == 0) return 0;                      // empty tensors (N_b = 0) carry NULL data pointers
     if (!x || !y) return QFA_E_NULL;

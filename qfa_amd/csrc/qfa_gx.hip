@@ -63,8 +63,10 @@ __global__ __launch_bounds__(256) void k_prep_step(qfa_params_t p, qfa_tau_t tau
                                                    const float *__restrict__ pix_ratio, const int *__restrict__ rows, int B,
                                                    int Npix, int Nb, int Nh, int n_pfx, int n_p2, int n_zs,
                                                    unsigned char *__restrict__ PFX, unsigned char *__restrict__ P2,
-                                                   float4 *__restrict__ ZS, float *__restrict__ zero, size_t n_zero) {
+                                                   float4 *__restrict__ ZS, float *__restrict__ zero, size_t n_zero,
+                                                   unsigned *__restrict__ tick1) {
     const int b = (int)blockIdx.x;
+    if (b == 0 && threadIdx.x == 0) *tick1 = 0u;             // arrival counter of k_solve<.., NLLRED> later in this step
     const ZPSrc zp{nullptr, pix_ratio, p.beta, tau.expo};
     if (b < n_pfx) prep_pfx_body<KP>(b, p.F, p.Psi, p.omega, nullptr, zp, Npix, Nb, Nh, PFX);
     else if (b < n_pfx + n_p2) {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void k_prep_step(qfa_params_t p, qfa_tau_t tau
 }
 void qfa_prep_step_launch(int KP, bool pixres, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
                           int Nb, int Nh, int ntiles32, unsigned char *PFX, unsigned char *P2, float *ZS, float *zero,
-                          size_t n_zero, hipStream_t st) {
+                          size_t n_zero, hipStream_t st, unsigned *tick1) {
     const bool zf = ZS != nullptr;
     const int n_pfx = ntiles32, n_zs = zf ? (B + 255) / 256 : 0;
     const int pxw = KP == 8 ? GTT<8>::PXW : GTT<16>::PXW, tpw = KP == 8 ? GTT<8>::TPW : GTT<16>::TPW;
@@ -91,7 +93,7 @@ void qfa_prep_step_launch(int KP, bool pixres, const qfa_params_t &p, const qfa_
     const float *zq1 = zf ? b.zq1 : nullptr, *ratio = zf ? b.pix_ratio : nullptr;
     auto go = [&](auto kp, auto px) {
         k_prep_step<decltype(kp)::value, decltype(px)::value><<<grid, 256, 0, st>>>(p, tau, zq1, ratio, b.rows, B, Npix, Nb, Nh, n_pfx, n_p2,
-                                                                                    n_zs, PFX, P2, zs, zero, nz);
+                                                                                    n_zs, PFX, P2, zs, zero, nz, tick1);
     };
     using K8 = std::integral_constant<int, 8>;
     using K16 = std::integral_constant<int, 16>;

@@ -16,7 +16,7 @@ void qfa_gx_launch(int KP, const qfa_params_t &p, const qfa_batch_t &b, const qf
 // everything a training step derives from the parameters before pass 1, in one launch (N_h <= 16; qfa_gx.hip, k_prep_step)
 void qfa_prep_step_launch(int KP, bool pixres, const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &tau, int B, int Npix,
                           int Nb, int Nh, int ntiles32, unsigned char *PFX, unsigned char *P2, float *ZS, float *zero,
-                          size_t n_zero, hipStream_t st);
+                          size_t n_zero, hipStream_t st, unsigned *tick1);
 
 // the pixel-resident form of the all-XDL pass 2 (qfa_grads_t.h, built in qfa_gx.hip; N_h = 9..16): QFA_F_PASS2_PIXRES
 struct GtPlan;
@@ -404,7 +404,8 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
             if (zf) zt.ZS = reinterpret_cast<float4 *>(ws + L.oZS);
             qfa_prep_step_launch(KP, pixres, p, b, tau, B, Npix, Nb, Nh, L.ntiles32, reinterpret_cast<unsigned char *>(ws + L.oPFX),
                                  reinterpret_cast<unsigned char *>(ws + L.oPGX), zf ? ws + L.oZS : nullptr,
-                                 (flags & QFA_F_ZERO_ACCUM) ? accum : nullptr, n_acc, st);
+                                 (flags & QFA_F_ZERO_ACCUM) ? accum : nullptr, n_acc, st,
+                                 reinterpret_cast<unsigned *>(reinterpret_cast<double *>(ws + L.oRED) + 2 * NRED) + 1);
         }
     }
     if (!fused) {
@@ -430,9 +431,18 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
             solved = true;
         }
     }
+    // small batches (one block of k_reduce_nll): the solve's last block sums the NLL itself (ticket[1]: zeroed by k_prep_step)
+    bool nll_done = false;
+    if constexpr (KP == 8 || KP == 16) {
+        if (!solved && fused && B <= 2048) {
+            k_solve<KP, false, false, true><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr, ticket,
+                                                                                      nullptr, accum + accS);
+            solved = nll_done = true;
+        }
+    }
     if (!solved) k_solve<KP, false><<<(B + 4 * G - 1) / (4 * G), 256, 0, st>>>(MOM, SOL, nllbuf, NBL, B, Nh, nullptr, nullptr, ticket);
     const int nred = B <= 2048 ? 1 : (B >= 2048 * NRED ? NRED : (B + 2047) / 2048);     // small batches: one block, no hand-over
-    k_reduce_nll<<<nred, 256, 0, st>>>(nllbuf, NBL, B, accum + accS, red, ticket);
+    if (!nll_done) k_reduce_nll<<<nred, 256, 0, st>>>(nllbuf, NBL, B, accum + accS, red, ticket);
     mark(3);
     if (pixres) {
         int ranges = 0;

@@ -76,6 +76,42 @@ __global__ void k_adam_clip_multi(AdamMultiArgs a, float lr, float b1, float b2,
     a.t.p_out[k][i] = q;
 }
 
+// k_finalize + k_adam_clip_multi in ONE launch (the training step never looks at the gradients themselves): block b works on
+// parameter tensor k (F, Psi, omega, tau0, c0, beta in this order), forms the normalised gradient of its element from the packed
+// buffer exactly as k_finalize does and applies Adam + clip exactly as k_adam_clip_multi does -- the same float32 operations in
+// the same order, so the new parameters are bit-identical to the two-launch path.  Block 0 also writes the batch loss.
+__global__ void k_finalize_adam(AdamMultiArgs a, const float *__restrict__ accum, int Npix, int Nb, int Nh, float *__restrict__ loss,
+                                float lr, float b1, float b2, float omb1, float omb2, float eps, float wd, float bc1, float bc2) {
+    const float *accF = accum;
+    const float *accA = accF + (size_t)Npix * Nh;
+    const float *accPsi = accA + Npix;
+    const float *accOm = accPsi + Npix;
+    const float *accCnt = accOm + Nb;
+    const float *accS = accCnt + Npix;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *loss = accS[4] / accS[5];
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 6; ++j)
+        if (blockIdx.x >= a.blk0[j]) k = j;
+    const size_t i = (size_t)(blockIdx.x - a.blk0[k]) * blockDim.x + threadIdx.x;
+    if (i >= a.t.n[k]) return;
+    const float pi = a.t.p[k][i];
+    float g;
+    if (k == 0) g = (pi * accA[i / Nh] - accF[i]) / accCnt[i / Nh];        // (p[0] is F itself)
+    else if (k == 1) g = accPsi[i] / accCnt[i];
+    else if (k == 2) g = accOm[i] / accCnt[i];
+    else g = accS[k - 3] / accS[3];
+    const float gi = g + wd * pi;
+    const float mi = omb1 * gi + b1 * a.t.m[k][i];
+    const float vi = omb2 * gi * gi + b2 * a.t.v[k][i];
+    a.t.m[k][i] = mi;
+    a.t.v[k][i] = vi;
+    float q = pi - lr * (mi / bc1) / (__fsqrt_rn(vi / bc2) + eps);
+    const float lo = a.t.lo[k], hi = a.t.hi[k];
+    if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
+    a.t.p_out[k][i] = q;
+}
+
 __global__ void k_clip(const float *__restrict__ x, float *__restrict__ y, size_t n, float lo, float hi) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {

@@ -158,12 +158,17 @@ static __global__ void k_sum_segments(float4 *__restrict__ mom, const float4 *__
 #ifndef QFA_SOLVE_OCC4
 #define QFA_SOLVE_OCC4 1      // four waves per SIMD at N_h <= 16 (the state-writing instantiation sat at 130 VGPRs: 126 now, no scratch; c3 solve 0.179 -> 0.163 ms)
 #endif
-template <int KP, bool PREDICT, bool STATE = false>
+// NLLRED (small batches, training): the block that finishes last also does k_reduce_nll's one-block job -- sum NLL, the number
+// of spectra with a blue pixel and B into the packed buffer's scalars `scal`, float64, the same fixed order (bit-identical) --
+// through the arrival counter ticket[1], which the step's first kernel (k_prep_step) zeroed: one link less in the chain of
+// dependent launches of a small-batch step.
+template <int KP, bool PREDICT, bool STATE = false, bool NLLRED = false>
 __global__ __launch_bounds__(256, (KP <= 16 && QFA_SOLVE_OCC4) ? 4 : 2) void k_solve(const float *__restrict__ MOM, float *__restrict__ SOL,
                                                float *__restrict__ nll_out, float *__restrict__ nblue_out, int B,
                                                int Nh, float *__restrict__ hmean, float *__restrict__ hcov,
                                                unsigned *__restrict__ ticket = nullptr,
-                                               unsigned char *__restrict__ PST = nullptr) {
+                                               unsigned char *__restrict__ PST = nullptr, float *__restrict__ scal = nullptr) {
+    static_assert(!NLLRED || (!PREDICT && !STATE), "NLLRED: the training step of a small batch");
     using C = Cfg<KP>;
     constexpr int G = 64 / KP;
     static_assert(!STATE || ((KP == 16 || KP == 8) && !PREDICT), "state images: N_h <= 16, training step");
@@ -344,6 +349,35 @@ __global__ __launch_bounds__(256, (KP <= 16 && QFA_SOLVE_OCC4) ? 4 : 2) void k_s
             const int grp = (int)blockIdx.x * ((4 * G) / 16) + q;
             if (16 * grp < B)
                 build_state<KP>(s_rows + q * 16 * C::NSOL, 16 * grp, B, Nh, PST + (size_t)grp * GTT<KP>::STATE_B, (int)threadIdx.x);
+        }
+    }
+    if constexpr (NLLRED) {
+        __shared__ double sh[2][4];
+        __shared__ bool last;
+        __threadfence();                                              // release: this block's nll / nblue before the ticket
+        __syncthreads();
+        if (threadIdx.x == 0) last = atomicAdd(ticket + 1, 1u) == (unsigned)gridDim.x - 1u;
+        __syncthreads();
+        if (!last) return;
+        __threadfence();                                              // acquire: the other blocks' stores
+        double a = 0.0, nb = 0.0;
+        for (int q = threadIdx.x; q < B; q += 256) {                  // (k_reduce_nll's order for one block)
+            a += (double)__hip_atomic_load(nll_out + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nb += __hip_atomic_load(nblue_out + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0.f ? 1.0 : 0.0;
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            a += __shfl_xor(a, o);
+            nb += __shfl_xor(nb, o);
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = nb; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double ta = 0.0, tb = 0.0;
+            for (int i = 0; i < 4; ++i) { ta += sh[0][i]; tb += sh[1][i]; }
+            scal[3] += (float)tb;
+            scal[4] += (float)ta;
+            scal[5] += (float)B;
         }
     }
 }

@@ -325,6 +325,9 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
 #ifndef QFA_P1_PIPE_BLUE
 #define QFA_P1_PIPE_BLUE 2     // ... and on a blue tile (a group = one column tile, 12 MFMAs)
 #endif
+#ifndef QFA_P1_MULMASK
+#define QFA_P1_MULMASK 1       // pass 1: the pixel mask as a float factor instead of selects / exec-mask branches (weights())
+#endif
 #ifndef QFA_P1_STAMPS
 #define QFA_P1_STAMPS 0    // diagnostic build (tools/p1_stamps.sh): s_memtime shares of the tile steps of one wave of pass 1
 #endif
@@ -482,6 +485,77 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 }
             }
             float qd8 = 0.f, ld8 = 0.f;
+#if QFA_P1_MULMASK
+            // The mask as a FACTOR (round 4).  `w ? x : 0` per pixel compiles to an exec-mask branch per pixel (saveexec / xor /
+            // or, zero-initialising moves: ~100 of the 440 instructions of a red tile step) or to three selects.  Here the
+            // mask byte becomes m = 0.0 / 1.0 with ONE instruction (v_cvt_f32_ubyteN; min(., 1) so that any nonzero byte
+            // counts) and multiplies 1/D, log D and the count; D and delta of a masked pixel are clamped to finite values
+            // first (min / max drop a NaN: a masked pixel may hold anything, not only the reference's -999), so m = 0 times
+            // them is 0.  For unmasked pixels every product is by exactly 1: the same bits as the select form.
+            const unsigned mw0 = svalid ? cur.m[0] : 0u, mw1 = svalid ? cur.m[1] : 0u;
+            constexpr float BIG = 3.0e38f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float c2[2], c3[2], cb[2], cb2[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int e = 2 * q + h2;
+                    const int px = 32 * tg + 8 * g + e;
+                    const unsigned mw = e < 4 ? mw0 : mw1;
+                    float mf = (float)((mw >> (8 * (e & 3))) & 0xffu);       // (hipcc selects v_cvt_f32_ubyteN for this)
+                    mf = fminf(mf, 1.f);
+                    float d = e < 4 ? cur.d0[e & 3] : cur.d1[e & 3];
+                    const float sg = e < 4 ? cur.s0[e & 3] : cur.s1[e & 3];
+                    d = fmaxf(fminf(d, BIG), -BIG);
+                    float D, wD;
+                    if (BLUE) {
+                        const bool blue = px < Nb;
+                        const BlueTerms t = ZF ? blue_terms_zf(zs, ti[e], pwi[e], 0.f, k)
+                                               : blue_terms(e < 4 ? cur.z0[e & 3] : cur.z1[e & 3], k);
+                        float Ab = t.A;
+                        if (abase) Ab = abase[offB + min(px, Nb - 1)];        // custom tau callable (rare path)
+                        const float A = blue ? Ab : 1.f;
+                        const float zdom = blue ? t.zd * om[e] : 0.f;
+                        D = fminf(A * A * psi[e] + zdom + sg * sg, BIG);
+                        if (PREDICT) d = d - muv[e] * A;                     // QFA/model.py:166
+                        wD = mf * fast_rcp(D);
+                        const float wDA = wD * A;
+                        c2[h2] = wDA * A;
+                        cb[h2] = wDA * d;
+                        if (TSIDE) {
+                            c3[h2] = c2[h2] * A;
+                            cb2[h2] = c2[h2] * d;
+                        }
+                        cblue += blue ? mf : 0.f;
+                    } else {                                                 // red side: A = 1, no omega term
+                        D = fminf(psi[e] + sg * sg, BIG);
+                        if (PREDICT) d = d - muv[e];
+                        wD = mf * fast_rcp(D);
+                        c2[h2] = wD;
+                        cb[h2] = wD * d;
+                    }
+                    qd8 += wD * d * d;
+                    ld8 = fmaf(mf, fast_log(D), ld8);
+                    cn += mf;
+                }
+                unsigned h, m, l;
+                split2(c2[0], c2[1], h, m, l);
+                w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = l;
+                split2(cb[0], cb[1], h, m, l);
+                w.w3h[q] = h; w.w3m[q] = m; w.w3l[q] = l;
+                if (TSIDE) {
+                    split2(c3[0], c3[1], h, m, l);
+                    w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = l;
+                    split2(cb2[0], cb2[1], h, m, l);
+                    w.w4h[q] = h; w.w4m[q] = m; w.w4l[q] = l;
+                }
+                pin(qd8, ld8);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            qd += (double)qd8;
+            ld += (double)ld8;
+            return;
+#endif
             // pixel pair by pixel pair: weights of two pixels, then their bf16 pieces (short live ranges)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

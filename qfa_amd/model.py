@@ -369,6 +369,10 @@ class QFA(object):
                 mask: torch.Tensor = None, events=None, zfac=None, batch=None):
         """Batch loss (1,1) and count-normalised gradient dict (reference QFA/model.py:74-105).
         ``batch``: a ``ResidentBatch`` in the place of the four tensors."""
+        return self._finalize(self._global_sums(delta, error, zabs, mask, events, zfac, batch), True)
+
+    def _global_sums(self, delta, error, zabs, mask, events=None, zfac=None, batch=None):
+        """the packed sum / count buffer of the (global) batch: this rank's raw sums, all-reduced under data parallelism"""
         if (batch.B if batch is not None else delta.shape[0]) == 0:
             if not self._dp:
                 raise _lib.QFAHipError("forward: empty batch")
@@ -383,7 +387,7 @@ class QFA(object):
             all_reduce_accum(acc, self._dp_group)
             if ev is not None:
                 ev[1].record()
-        return self._finalize(acc, True)
+        return acc
 
     def loglikelihood_and_gradient_for_single_spectra(self, delta, error, zabs, mask):
         """One spectrum: NLL (1,1) and the six un-normalised gradients, zeros at masked pixels
@@ -494,13 +498,19 @@ class QFA(object):
         ll, hmean, hcov, cont, unc = self.predict(flux[None, :], error[None, :], zabs[None, :], mask[None, :])
         return ll.reshape(1, 1), hmean.reshape(self.Nh, 1), hcov[0], cont[0], unc[0]
 
-    def step(self, optimizer, delta=None, error=None, zabs=None, mask=None, events=None, zfac=None, batch=None):
+    def step(self, optimizer, delta=None, error=None, zabs=None, mask=None, events=None, zfac=None, batch=None, inplace=False):
         """forward -> Adam.update -> clip, all on device, no host sync (model.py:212-214, 316).
         Returns the (1,1) loss tensor.  ``batch``: a ``ResidentBatch`` in the place of the four tensors."""
-        loss, grads = self.forward(delta, error, zabs, mask, events=events, zfac=zfac, batch=batch)
-        new = optimizer.update(self.parameters, grads, clip=self._clip_table())
-        for k in PARAM_KEYS:
-            setattr(self, k, new[k])
+        if hasattr(optimizer, "update_from_accum"):
+            # sum / count and Adam + clip in one launch: the step never looks at the gradients (bit-identical to the two calls)
+            acc = self._global_sums(delta, error, zabs, mask, events, zfac, batch)
+            loss, new = optimizer.update_from_accum(self, acc, clip=self._clip_table(), inplace=inplace)
+        else:
+            loss, grads = self.forward(delta, error, zabs, mask, events=events, zfac=zfac, batch=batch)
+            new = optimizer.update(self.parameters, grads, clip=self._clip_table(), inplace=inplace)
+        if not inplace:
+            for k in PARAM_KEYS:
+                setattr(self, k, new[k])
         return loss
 
     def step_graph(self, optimizer, batch_size, resident=None):
@@ -676,13 +686,10 @@ class StepGraph(object):
     def _body(self):
         m = self.model
         if self.resident is None:
-            loss, grads = m.forward(*self.buf)
-            self.opt.update(m.parameters, grads, clip=m._clip_table(), inplace=True)
-            return loss
+            return m.step(self.opt, *self.buf, inplace=True)
         total = None
         for k in range(self.steps):                              # consecutive steps: each sees the previous one's update
-            loss, grads = m.forward(batch=self._rb_step(k))
-            self.opt.update(m.parameters, grads, clip=m._clip_table(), inplace=True)
+            loss = m.step(self.opt, batch=self._rb_step(k), inplace=True)
             total = loss if total is None else total + loss
         return total
 

@@ -85,6 +85,35 @@ class Adam(object):
                                                  int(self.i), _lib.current_stream(dev)), "qfa_adam_clip_multi_f32")
         return out
 
+    def update_from_accum(self, model, acc, clip=None, inplace=False):
+        """``forward``'s normalisation and ``update`` in ONE launch (qfa_finalize_adam_clip_f32): the packed, all-reduced sum /
+        count buffer ``acc`` of the step goes straight to the new parameters; the gradients are never materialised.
+        Returns (loss (1,1), new parameter dict); bit-identical to ``update(params, model._finalize(acc)[1], ...)``."""
+        keys = ("F", "Psi", "omega", "tau0", "c0", "beta")
+        params = model.parameters
+        t = _lib.AdamMulti()
+        out, keep = {}, []
+        for j, k in enumerate(keys):
+            p = params[k]
+            if p.dtype != f32 or not p.is_contiguous():
+                if inplace:
+                    raise ValueError(f"in-place update needs contiguous float32 params[{k}]")
+                p = p.to(f32).contiguous()
+            _lib.require_device_tensor(p, f32, f"params[{k}]")
+            q = p if inplace else torch.empty_like(p)
+            lo, hi = clip[k] if (clip is not None and k in clip) else (1.0, 0.0)
+            t.p[j], t.g[j], t.m[j], t.v[j], t.p_out[j] = p.data_ptr(), None, self.m[k].data_ptr(), self.v[k].data_ptr(), q.data_ptr()
+            t.n[j], t.lo[j], t.hi[j] = p.numel(), lo, hi
+            keep.append(p)
+            out[k] = q
+        t.count = 6
+        loss = torch.empty((1, 1), dtype=f32, device=model.device)
+        _lib.check(_lib.lib().qfa_finalize_adam_clip_f32(
+            C.c_void_p(acc.data_ptr()), model.Npix, model.Nb, model.Nh, C.byref(t), float(self.scheduled_lr), self.b1, self.b2,
+            self.eps, self.weight_decay, int(self.i), C.c_void_p(loss.data_ptr()), _lib.current_stream(model.device)),
+            "qfa_finalize_adam_clip_f32")
+        return loss, out
+
     # checkpoint support for the optimiser state (absent in the reference; SURVEY 8(f) N2)
     def state_dict(self):
         return {"i": self.i, "m": {k: v.clone() for k, v in self.m.items()},

@@ -308,3 +308,40 @@ def test_training_trajectory_on_the_xdl_path_matches_oracle_loop(tmp_path, npix,
     assert opt.i == 3
     for k in KEYS:
         assert rel_l2(model.parameters[k].cpu().numpy(), ref[k]) < 2e-5, (k, rel_l2(model.parameters[k].cpu().numpy(), ref[k]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npix,nh,B", [(320, 4, 27), (640, 12, 70), (97, 20, 9)])
+def test_fused_finalize_adam_is_bit_identical_to_the_two_calls(npix, nh, B):
+    """qfa_finalize_adam_clip_f32 (QFA.step: sum / count and Adam + clip in one launch) against qfa_finalize_grads_f32 followed by
+    qfa_adam_clip_multi_f32 (QFA.forward + Adam.update, reference QFA/model.py:212-214): the same bits in the new parameters,
+    both moments and the loss -- a dead pixel range (count 0: NaN gradients, quirk Q3) included"""
+    import torch
+    from qfa_amd import QFA, Adam, step_scheduler, synthetic
+    dev = torch.device("cuda:0")
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu0 = synthetic.mock_parameters(npix, nb, nh, seed=5)
+    b = synthetic.make_batch_numpy(p, mu0, wav, nb, B, seed=51, dead_range=(40, 44))
+    T = lambda k: torch.tensor(b[k], device=dev)
+    res = []
+    for fused in (False, True):
+        m = QFA(nb, nr, nh, dev, model_params=p)
+        opt = Adam(m.parameters, dev, scheduler=step_scheduler(0.5, 1), learning_rate=1e-3, weight_decay=1e-1)
+        first = None
+        for it in range(3):
+            if fused:
+                loss = m.step(opt, T("delta"), T("error"), T("zabs"), T("mask"))
+            else:
+                loss, g = m.forward(T("delta"), T("error"), T("zabs"), T("mask"))
+                new = opt.update(m.parameters, g, clip=m._clip_table())
+                for k in KEYS:
+                    setattr(m, k, new[k])
+            first = loss.clone() if first is None else first        # (from the second step on F holds NaN rows: NaN loss)
+            opt.step()
+        res.append(([getattr(m, k).clone() for k in KEYS], [opt.m[k].clone() for k in KEYS], [opt.v[k].clone() for k in KEYS], first))
+    for a, c in zip(res[0][:3], res[1][:3]):
+        for x, y in zip(a, c):
+            assert torch.equal(torch.nan_to_num(x, nan=123.0), torch.nan_to_num(y, nan=123.0))
+            assert torch.equal(torch.isnan(x), torch.isnan(y))
+    assert torch.equal(res[0][3], res[1][3]) and torch.isfinite(res[0][3]).all()
+    assert torch.isnan(res[0][0][0][40:44]).all()                          # the dead pixels' F rows went NaN in both
