@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     // ---- static operands of the wave's tiles
     const unsigned char *tile[TPW];
     u32x4 IBh[TPW][GT::NKQ], IBm[TPW][GT::NKQ], IBl[TPW][GT::NKQ];
-    float Psi[TPW], om[TPW], ti[TPW], pwi[TPW], l2i[TPW];
+    float Psi[TPW], om[TPW], ti[TPW], pwi[TPW], l2i[TPW], offl[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         tile[j] = PGT + (size_t)(active ? TPW * wt + j : 0) * GT::TILE_B;
@@ -205,6 +205,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         const float *par = reinterpret_cast<const float *>(tile[j] + GT::OFF_PAR);
         Psi[j] = par[lo]; om[j] = par[16 + lo];
         ti[j] = ZF ? par[32 + lo] : 0.f; pwi[j] = ZF ? par[48 + lo] : 0.f; l2i[j] = ZF ? par[64 + lo] : 0.f;
+        // factored-z form: a red pixel of the tile that holds the boundary has omega = ti = pwi = 0 in its image
+        // (prep_pgt_body) and offset 0 here: A = exp2(0) = 1 and omega zd = 0 come out of the blue arithmetic without a select
+        offl[j] = blue[j] ? k.offp : 0.f;
     }
 
     // Every load of this prologue is consumed HERE: hipcc puts the s_waitcnt of a load in front of its first use, and a first
@@ -221,14 +224,16 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 
     // ---- running sums
     f32x4 W[TPW][GT::NWT], gacc[TPW];
-    float gPsi[TPW], gOm[TPW], sA[TPW], cnt[TPW];
+    float gPsi[TPW], gOm[TPW], sA[TPW];
+    int cnt[TPW];
     f32x4 betaR[TPW], gamR[TPW];                            // stage 2 -> stage 3 (across one barrier)
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
 #pragma unroll
         for (int a = 0; a < GT::NWT; ++a) W[j][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         gacc[j] = betaR[j] = gamR[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gPsi[j] = gOm[j] = sA[j] = cnt[j] = 0.f;
+        gPsi[j] = gOm[j] = sA[j] = 0.f;
+        cnt[j] = 0;
     }
     double d_tau0 = 0.0, d_c0 = 0.0, d_beta = 0.0;
 
@@ -597,6 +602,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         }
         RowIdx ri{};
         if (t + 2 < n) ri = read_rows(t + 2, t & 1, std::false_type{});
+        bool wvm[TPW][4];                                        // element counts: mask & spectrum < B & pixel < Npix (lane masks)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staging buffer read: it may be overwritten now
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
@@ -606,27 +612,31 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sgv[j][r] = mk[j][r] ? fabsf(sgv[j][r]) : -1.f;
+            for (int r = 0; r < 4; ++r) wvm[j][r] = inb[j] & (s0 + 4 * g + r < B) & (mk[j][r] != 0u);
         GTS(6)
         if (t + 2 < n) stage_spectra(t + 2, t & 1, ri, std::false_type{});
         piece(pt, 0);
         piece(pt, 1);
         __builtin_amdgcn_sched_barrier(0);
         GTS(2)
+        // gPsi / gOmega accumulate h = 2 dG (halved once, at the store); the walk counts valid elements in integers (one
+        // add-with-carry each).  Factored-z form: pw = zqy[r] pwi[j] and l2 = zqz[r] + l2i[j] separate into the spectrum's and
+        // the pixel's factor, so the tau0 / beta sums of :142-143 need e zqy[r] and e zqy[r] zqz[r] per element only; the
+        // pixel's factors multiply the group's sums
         float t_tau0 = 0.f, t_c0 = 0.f, t_beta = 0.f;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
+        float e1 = 0.f, e2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool wv_ = inb[j] & (s0 + 4 * g + r < B) & (__float_as_int(sgv[j][r]) >= 0);
+            const bool wv_ = wvm[j][r];
             const float dd = wv_ ? dv[j][r] : 0.f;
             const float sg = sgv[j][r];
             if (BLUE) {
-                float l2, pw, Ab, re;
+                float l2 = 0.f, pw, Ab, re;
                 if (ZF) {                                                                         // qfa_common.h, ZFac
-                    l2 = zqz[r] + l2i[j];
                     pw = zqy[r] * pwi[j];
-                    Ab = fast_exp2(fmaf(zqx[r], ti[j], k.offp));                                  // QFA/model.py:125
+                    Ab = fast_exp2(fmaf(zqx[r], ti[j], offl[j]));                                 // QFA/model.py:125
                     re = k.omc0 - fast_exp2(k.k1 * pw);                                           // QFA/utils.py:91
                 } else {
                     l2 = fast_log2(1.0f + zv[j][r]);
@@ -636,23 +646,30 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                     re = 1.0f - k.c0 - fast_exp2(-k.tau0 * pw * QFA_LOG2E);                       // QFA/utils.py:91
                 }
                 if (HASA) Ab = bt.A_blue[(size_t)min(s0 + 4 * g + r, B - 1) * Nb + (unsigned)min(px[j], Nb - 1)];   // custom tau callable
-                const float Av = blue[j] ? Ab : 1.f;
-                const float zd = blue[j] ? re * re : 0.f;
+                const float Av = (ZF && !HASA) ? Ab : (blue[j] ? Ab : 1.f);
+                const float zd = (ZF && !HASA) ? re * re : (blue[j] ? re * re : 0.f);
                 const float A2 = Av * Av;
-                const float D = A2 * Psi[j] + om[j] * zd + sg * sg;
+                const float ozd = om[j] * zd;
+                const float D = A2 * Psi[j] + ozd + sg * sg;
                 const float wD = wv_ ? fast_rcp(D) : 0.f;
                 const float wDA = wD * Av;
                 const float uu = wD * (dd - Av * afy[j][r]);                // (Sigma^-1 delta)_i
                 const float dS = wD - wDA * wDA * aq[j][r];                 // diag(Sigma^-1)_i
-                const float dG = 0.5f * (dS - uu * uu);                     // QFA/model.py:136,138
-                gPsi[j] += A2 * dG;                                         // :139
-                gOm[j] += dG * zd;                                          // :140
-                const float root = 1.0f - k.tau0 * pw - k.c0;               // :141
-                const float e = dG * (om[j] * zd) * zd * 2.0f * root;
-                t_tau0 -= e * pw;                                           // :142
-                t_beta -= e * (k.tau0 * pw * (l2 * QFA_LN2));               // :143
+                const float h = dS - uu * uu;                               // 2 dG, QFA/model.py:136,138
+                gPsi[j] = fmaf(A2, h, gPsi[j]);                             // :139 (x 2)
+                gOm[j] = fmaf(h, zd, gOm[j]);                               // :140 (x 2)
+                const float root = fmaf(-k.tau0, pw, k.omc0);               // :141
+                const float e = h * ozd * zd * root;                        // dG (omega zd) zd 2 root
+                if (ZF) {
+                    const float ep = e * zqy[r];
+                    e1 += ep;                                               // :142 / pwi[j]
+                    e2 = fmaf(ep, zqz[r], e2);                              // :143, the spectrum's part of l2
+                } else {
+                    t_tau0 -= e * pw;                                       // :142
+                    t_beta -= e * (k.tau0 * pw * (l2 * QFA_LN2));           // :143
+                }
                 t_c0 -= e;                                                  // :144
-                cnt[j] += wv_ ? 1.f : 0.f;
+                cnt[j] += wv_ ? 1 : 0;
                 betaR[j][r] = wDA * Av;
                 sA[j] += betaR[j][r] * Av;
                 gamR[j][r] = Av * uu;
@@ -661,8 +678,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                 const float wD = wv_ ? fast_rcp(D) : 0.f;
                 const float uu = wD * (dd - afy[j][r]);
                 const float dS = wD - wD * wD * aq[j][r];
-                gPsi[j] += 0.5f * (dS - uu * uu);
-                cnt[j] += wv_ ? 1.f : 0.f;
+                gPsi[j] += dS - uu * uu;
+                cnt[j] += wv_ ? 1 : 0;
                 betaR[j][r] = wD;
                 sA[j] += wD;
                 gamR[j][r] = uu;
@@ -675,6 +692,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                     if (r == 3) piece(pt, 6);
                 }
             }
+        }
+        if (BLUE && ZF) {
+            const float t1 = pwi[j] * e1;
+            t_tau0 -= t1;
+            t_beta -= k.tau0 * QFA_LN2 * fmaf(pwi[j], e2, l2i[j] * t1);
         }
         }
         if (BLUE) {                                            // float32 inside a group, float64 across the walk
@@ -843,7 +865,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                 }
             }
             // per-pixel sums over the lanes lo + 16 g'
-            float vsA = sA[j], vgPsi = gPsi[j], vgOm = gOm[j], vcnt = cnt[j];
+            float vsA = sA[j], vgPsi = 0.5f * gPsi[j], vgOm = 0.5f * gOm[j], vcnt = (float)cnt[j];
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
                 vsA += __shfl_xor(vsA, o);
