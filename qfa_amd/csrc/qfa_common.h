@@ -231,6 +231,7 @@ struct ZPSrc {
     const float *ratio;
     const float *beta;
     float expo;
+    float offp;                 // -log2(e) tau.offset (DevConsts::offp): the image builders store it per BLUE pixel, 0 for red ones
     __device__ __forceinline__ bool on() const { return tab != nullptr || ratio != nullptr; }
     __device__ __forceinline__ float4 at(int i) const {
         if (tab) return tab[i];
@@ -238,7 +239,7 @@ struct ZPSrc {
         return float4{(float)exp2((double)expo * l2i), (float)exp2((double)*beta * l2i), (float)l2i, 0.f};
     }
 };
-__host__ __device__ inline ZPSrc zp_table(const float4 *ZP) { return ZPSrc{ZP, nullptr, nullptr, 0.f}; }
+__host__ __device__ inline ZPSrc zp_table(const float4 *ZP, float offp = 0.f) { return ZPSrc{ZP, nullptr, nullptr, 0.f, offp}; }
 
 #ifndef QFA_ABL
 #define QFA_ABL 0          // timing-only ablation builds (build with -DQFA_ABL=n: tools/build_full_variant.sh); 0 = product

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_prep_step(qfa_params_t p, qfa_tau_t tau
                                                    unsigned *__restrict__ tick1) {
     const int b = (int)blockIdx.x;
     if (b == 0 && threadIdx.x == 0) *tick1 = 0u;             // arrival counter of k_solve<.., NLLRED> later in this step
-    const ZPSrc zp{nullptr, pix_ratio, p.beta, tau.expo};
+    const ZPSrc zp{nullptr, pix_ratio, p.beta, tau.expo, -QFA_LOG2E * tau.offset};      // (offp as load_consts forms it)
     if (b < n_pfx) prep_pfx_body<KP>(b, p.F, p.Psi, p.omega, nullptr, zp, Npix, Nb, Nh, PFX);
     else if (b < n_pfx + n_p2) {
         if constexpr (PIXRES) prep_pgt_body<KP>(b - n_pfx, p.F, p.Psi, p.omega, zp, Npix, Nb, Nh, P2);

@@ -323,7 +323,7 @@ void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t
                    int Nb, int Nh, const Layout &L, const ZTables &zt, float *ws, hipStream_t st, bool prep = true) {
     float *MOM = ws + L.oMOM;
     unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
-    if (prep) k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, Npix, Nb, Nh, PFX);
+    if (prep) k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, -QFA_LOG2E * tau.offset, Npix, Nb, Nh, PFX);
     constexpr int NW = KP <= 16 ? QFA_P1_NW : 4;      // (L.spb1 = 16 NW spectra per block)
     if (zt.ZS)
         k_moments_x<KP, PREDICT, NW, true><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, zt.ZS, MOM);

@@ -31,8 +31,9 @@ struct XCfg {
     static constexpr int pstr(int j) { return nct(j) * 1024; }   // bytes of one piece of sub-image j: 32 px x bf16 per column
     static constexpr int PSTR = pstr(0);
     static constexpr int OFF_PSI = 3 * PSTR;                  // in sub-image 0: float32 Psi[32], omega[32], mu[32] (prediction),
-                                                              // ti[32], pwi[32] (factored-z form: ZP of qfa_common.h)
-    static constexpr int SUB0_B = (3 * PSTR + 640 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
+                                                              // ti[32], pwi[32], offp[32] (factored-z form: ZP of qfa_common.h;
+                                                              // all 0 for red pixels), blue[32] = 1.0 / 0.0
+    static constexpr int SUB0_B = (3 * PSTR + 896 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
     static constexpr int SUB1_B = NSW > 1 ? 3 * pstr(1) : 0;
     static constexpr int sub_off(int j) { return j == 0 ? 0 : SUB0_B; }
     static constexpr int sub_bytes(int j) { return j == 0 ? SUB0_B : SUB1_B; }
@@ -241,15 +242,17 @@ __device__ __forceinline__ void prep_pfx_body(int bid, const float *__restrict__
         else if (idx < 96) v = (mu && i < Npix) ? mu[i] : 0.f;      // mean continuum (prediction: delta = flux - mu A)
         else if (idx < 128) v = (ZP.on() && i < Nb) ? ZP.at(i).x : 0.f;     // factored-z form: ti
         else if (idx < 160) v = (ZP.on() && i < Nb) ? ZP.at(i).y : 0.f;     //                  pwi
+        else if (idx < 192) v = (ZP.on() && i < Nb) ? ZP.offp : 0.f;        //                  offset of the exponent of A (0: red pixel)
+        else if (idx < 224) v = i < Nb ? 1.f : 0.f;                         // 1 = blue pixel
         po[idx] = v;
     }
 }
 template <int KP>
 __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, const float *__restrict__ Psi,
                                                   const float *__restrict__ omega, const float *__restrict__ mu,
-                                                  const float4 *__restrict__ ZP, int Npix, int Nb, int Nh,
+                                                  const float4 *__restrict__ ZP, float offp, int Npix, int Nb, int Nh,
                                                   unsigned char *__restrict__ PFX) {
-    prep_pfx_body<KP>(blockIdx.x, F, Psi, omega, mu, zp_table(ZP), Npix, Nb, Nh, PFX);
+    prep_pfx_body<KP>(blockIdx.x, F, Psi, omega, mu, zp_table(ZP, offp), Npix, Nb, Nh, PFX);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -461,12 +464,19 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         // ---- phase 1 of a tile: per-element weights on the VALU (QFA/model.py:125-131), split into bf16 pieces
         auto weights = [&](int tg, const SpecRegsX &cur, const unsigned char *rows, Pieces &w) {
             const float *pp = reinterpret_cast<const float *>(rows) + 8 * g;      // the tile's parameter rows (OFF_PSI of its image)
-            float psi[8], om[8], muv[8], ti[8], pwi[8];
+            float psi[8], om[8], muv[8], ti[8], pwi[8], ofl[8], bluef[8];
             if (BLUE && ZF) {
                 const float4 a = *reinterpret_cast<const float4 *>(pp + 96), b = *reinterpret_cast<const float4 *>(pp + 100),
-                             c = *reinterpret_cast<const float4 *>(pp + 128), d = *reinterpret_cast<const float4 *>(pp + 132);
+                             c = *reinterpret_cast<const float4 *>(pp + 128), d = *reinterpret_cast<const float4 *>(pp + 132),
+                             e = *reinterpret_cast<const float4 *>(pp + 160), f = *reinterpret_cast<const float4 *>(pp + 164);
                 ti[0] = a.x; ti[1] = a.y; ti[2] = a.z; ti[3] = a.w; ti[4] = b.x; ti[5] = b.y; ti[6] = b.z; ti[7] = b.w;
                 pwi[0] = c.x; pwi[1] = c.y; pwi[2] = c.z; pwi[3] = c.w; pwi[4] = d.x; pwi[5] = d.y; pwi[6] = d.z; pwi[7] = d.w;
+                ofl[0] = e.x; ofl[1] = e.y; ofl[2] = e.z; ofl[3] = e.w; ofl[4] = f.x; ofl[5] = f.y; ofl[6] = f.z; ofl[7] = f.w;
+            }
+            if (BLUE) {
+                const float4 a = *reinterpret_cast<const float4 *>(pp + 192), b = *reinterpret_cast<const float4 *>(pp + 196);
+                bluef[0] = a.x; bluef[1] = a.y; bluef[2] = a.z; bluef[3] = a.w;
+                bluef[4] = b.x; bluef[5] = b.y; bluef[6] = b.z; bluef[7] = b.w;
             }
             if (PREDICT) {          // from the tile image: a global load here would sit in the counted vmcnt queue
                 const float4 a = *reinterpret_cast<const float4 *>(pp + 64), b = *reinterpret_cast<const float4 *>(pp + 68);
@@ -503,19 +513,28 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                     const int px = 32 * tg + 8 * g + e;
                     const unsigned mw = e < 4 ? mw0 : mw1;
                     float mf = (float)((mw >> (8 * (e & 3))) & 0xffu);       // (hipcc selects v_cvt_f32_ubyteN for this)
-                    mf = fminf(mf, 1.f);
+                    mf = fminf(fmaxf(mf, 0.f), 1.f);                         // (the clamp bit of that instruction: no op of its own)
                     float d = e < 4 ? cur.d0[e & 3] : cur.d1[e & 3];
                     const float sg = e < 4 ? cur.s0[e & 3] : cur.s1[e & 3];
-                    d = fmaxf(fminf(d, BIG), -BIG);
+                    d = __builtin_amdgcn_fmed3f(d, -BIG, BIG);              // (v_med3_f32 returns min3 when an operand is NaN: -BIG)
                     float D, wD;
                     if (BLUE) {
-                        const bool blue = px < Nb;
-                        const BlueTerms t = ZF ? blue_terms_zf(zs, ti[e], pwi[e], 0.f, k)
-                                               : blue_terms(e < 4 ? cur.z0[e & 3] : cur.z1[e & 3], k);
-                        float Ab = t.A;
-                        if (abase) Ab = abase[offB + min(px, Nb - 1)];        // custom tau callable (rare path)
-                        const float A = blue ? Ab : 1.f;
-                        const float zdom = blue ? t.zd * om[e] : 0.f;
+                        float A, zdom;
+                        if (ZF) {
+                            // factored-z form (never with a custom A_blue): a red pixel of the tile across the boundary has
+                            // ti = pwi = omega = offset 0 in the image -- A = exp2(0) = 1 and omega zd = 0 without a select
+                            const float pw = zs.pw * pwi[e];                                      // utils.py:73
+                            A = fast_exp2(fmaf(zs.ts, ti[e], ofl[e]));                            // QFA/model.py:125
+                            const float re = k.omc0 - fast_exp2(k.k1 * pw);                       // utils.py:91
+                            zdom = re * re * om[e];
+                        } else {
+                            const bool blue = px < Nb;
+                            const BlueTerms t = blue_terms(e < 4 ? cur.z0[e & 3] : cur.z1[e & 3], k);
+                            float Ab = t.A;
+                            if (abase) Ab = abase[offB + min(px, Nb - 1)];    // custom tau callable (rare path)
+                            A = blue ? Ab : 1.f;
+                            zdom = blue ? t.zd * om[e] : 0.f;
+                        }
                         D = fminf(A * A * psi[e] + zdom + sg * sg, BIG);
                         if (PREDICT) d = d - muv[e] * A;                     // QFA/model.py:166
                         wD = mf * fast_rcp(D);
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                             c3[h2] = c2[h2] * A;
                             cb2[h2] = c2[h2] * d;
                         }
-                        cblue += blue ? mf : 0.f;
+                        cblue = fmaf(mf, bluef[e], cblue);
                     } else {                                                 // red side: A = 1, no omega term
                         D = fminf(psi[e] + sg * sg, BIG);
                         if (PREDICT) d = d - muv[e];
@@ -535,7 +554,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                         cb[h2] = wD * d;
                     }
                     qd8 += wD * d * d;
-                    ld8 = fmaf(mf, fast_log(D), ld8);
+                    ld8 = fmaf(mf, fast_log2(D), ld8);                       // (log 2 once per tile, below)
                     cn += mf;
                 }
                 unsigned h, m, l;
@@ -553,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 __builtin_amdgcn_sched_barrier(0);
             }
             qd += (double)qd8;
-            ld += (double)ld8;
+            ld += (double)(ld8 * QFA_LN2);
             return;
 #endif
             // pixel pair by pixel pair: weights of two pixels, then their bf16 pieces (short live ranges)
