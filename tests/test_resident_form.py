@@ -100,6 +100,50 @@ def test_indexed_batch_is_bit_identical_to_the_gathered_batch(dev, npix, nh, N, 
         assert torch.equal(a, c)
 
 
+POISON_CASES = [
+    # npix, nh, N, flags, zabs form
+    (200, 16, 70, 0, False), (200, 16, 70, 0, True), (1913, 12, 300, _lib.F_PASS2_PIXRES, True), (1913, 12, 300, _lib.F_PASS2_PIXRES, False),
+    (1913, 8, 200, 0, False), (1000, 8, 200, _lib.F_PASS2_PIXRES, False), (1000, 8, 200, _lib.F_PASS2_PIXRES, True),
+    (640, 16, 48, _lib.F_PASS2_F32, False), (450, 24, 70, 0, False), (450, 24, 70, 0, True),
+]
+
+
+@pytest.mark.parametrize("npix,nh,N,flags,zform", POISON_CASES)
+def test_masked_pixels_may_hold_anything(dev, npix, nh, N, flags, zform):
+    """The reference marks bad pixels with -999 (QFA/dataloader.py:24,28) and never reads them; here a masked pixel may hold
+    NaN, +-inf or the largest float32 in delta, flux AND error: every sum, every per-spectrum NLL and every predicted value is
+    bit for bit what the sentinel batch gives (the kernels select or clamp, they do not multiply a NaN by zero)."""
+    import torch
+    m, rb0, b, p, mu = resident_set(dev, npix, nh, N, seed=5 * npix + nh, with_zabs=zform)
+    rb = rb0.with_rows(torch.arange(N, dtype=torch.int32, device=dev))
+    g = torch.Generator(device="cpu").manual_seed(npix + nh)
+    rb.mask[:, :npix] &= (torch.rand((N, npix), generator=g) > 0.05).to(dev)      # (5 % more masked pixels, scattered)
+    rb.mask[N // 2, :npix] = False                                                # and one spectrum without a valid pixel
+    m.flags, m.deterministic = flags, True
+    nll0 = torch.empty(N, dtype=torch.float32, device=dev)
+    acc0 = m.accumulate(batch=rb, nll=nll0).clone()
+    out0 = [x.clone() for x in m.predict(batch=rb)]
+    bad = ~rb.mask[:, :npix]
+    assert bad.any()
+    kind = torch.randint(0, 5, bad.shape, generator=g).to(dev)
+    poison = torch.tensor([float("nan"), float("inf"), -float("inf"), 3.4028234e38, -3.4028234e38], device=dev)[kind]
+    for arr in (rb.delta, rb.flux, rb.error):
+        v = arr[:, :npix]
+        v[bad] = poison[bad]
+    nll1 = torch.empty(N, dtype=torch.float32, device=dev)
+    acc1 = m.accumulate(batch=rb, nll=nll1).clone()
+    out1 = m.predict(batch=rb)
+    torch.cuda.synchronize()
+    assert torch.equal(nll0, nll1) and torch.isfinite(nll1).all()
+    assert torch.equal(acc0, acc1)
+    for a, c in zip(out0, out1):
+        assert torch.equal(a, c)
+    # and through the tensor form (gathered copies of the poisoned rows)
+    (d, e, z, mk), zfac = rb.materialize()
+    acc2 = m.accumulate(d, e, z, mk, zfac=zfac).clone()
+    assert torch.equal(acc0, acc2)
+
+
 @pytest.mark.parametrize("npix,nh,flags", [(1913, 8, 0), (1913, 8, _lib.F_PASS2_PIXRES), (1000, 16, _lib.F_PASS2_PIXRES), (450, 24, 0)])
 def test_padded_and_unpadded_rows_give_the_same_bits(dev, npix, nh, flags):
     """row_stride = N_pix (the reference's layout) against rows padded to 32 pixels: identical results"""
