@@ -47,8 +47,9 @@ def mock_parameters(n_pix, nb, nh, seed=0, mu=None):
     """Smooth random loadings and realistic noise scales (SURVEY 8(d) 'Parameters')."""
     rng = np.random.default_rng(seed)
     F = 0.1 * rng.standard_normal((n_pix, nh))
-    ker = np.ones(31) / 31.0
-    F = np.stack([np.convolve(F[:, a], ker, mode="same") for a in range(nh)], axis=1) * math.sqrt(31.0)
+    kw = 31 if n_pix >= 31 else max(1, n_pix - 1 + n_pix % 2)      # (odd, no longer than the axis: 'same' keeps n_pix rows)
+    ker = np.ones(kw) / kw
+    F = np.stack([np.convolve(F[:, a], ker, mode="same") for a in range(nh)], axis=1) * math.sqrt(kw)
     x = np.linspace(0.0, 1.0, n_pix)
     if mu is None:
         mu = 1.0 + 0.5 * np.exp(-0.5 * ((x - 0.32) / 0.03) ** 2) + 0.3 * np.exp(-0.5 * ((x - 0.9) / 0.05) ** 2)
