@@ -4,7 +4,8 @@ The fixed cases of test_hip_parity.py / test_resident_form.py pin the layouts so
 boundary inside a tile, N_h on both sides of 8 / 16, ...).  This file draws the shape instead: N_pix 1..1600 (log-uniform),
 N_b anywhere in 0..N_pix, N_h 1..32, 1..160 spectra, masks with runs and a fully masked spectrum now and then, the pass-2 form
 (default dispatch, pixel-resident, two-role XDL, float32 MFMA) and the input form (zabs tensors, factored-z tensors, resident rows
-picked by a permutation) -- the reference's own loop restated in oracle/qfa_oracle.py (model.py:74-158) is the judge of each.
+picked by a permutation) -- the reference's own loop restated in oracle/qfa_oracle.py (model.py:74-158) is the judge of each;
+then the posterior of the same rows (model.py:160-180) through the same input form.
 """
 import os
 
@@ -84,6 +85,17 @@ def test_random_shape_against_the_oracle(dev, seed):
                            torch.as_tensor(rows.astype(np.int32), device=dev), npix, nb)
         acc = m.accumulate(batch=rb, nll=nll)
     loss, gr = m._finalize(acc.clone(), True)
+    # the posterior of the same rows (reference QFA/model.py:160-180): raw flux in, five outputs
+    fx = torch.as_tensor(b["flux"], device=dev).to(f32)
+    m.flags = 0
+    if form == "zabs":
+        pred = m.predict(fx, e, z, mk)
+    elif form == "zfac":
+        pred = m.predict(fx, e, None, mk, zfac=(zq1, ratio))
+    else:
+        rb.flux = pad(fx, 3.0e9)
+        pred = m.predict(batch=rb)
+    pred = [x.cpu().numpy() for x in pred]
     sel = {k: b[k][rows] for k in ("delta", "error", "zabs", "mask")}
     oloss, ogr = O.forward(p, sel["delta"], sel["error"], sel["zabs"], sel["mask"])
     per = np.empty(B)
@@ -117,3 +129,14 @@ def test_random_shape_against_the_oracle(dev, seed):
             # bars of the realistic shapes apply from 8 elements and 4 spectra on, 1e-3 below that)
             tol = TOL_G[k] if (ok.sum() >= 8 and B >= 4) else 1e-3
             assert rel_l2(ours[ok], ref[ok]) < tol, (k, case, rel_l2(ours[ok], ref[ok]))
+    for s_ in range(min(B, 3)):
+        r = rows[s_]
+        o = O.predict_single(p, mu, b["flux"][r], b["error"][r], b["zabs"][r], b["mask"][r])
+        nvalid = int(b["mask"][r].sum())
+        assert abs(pred[0][s_] - o[0]) <= TOL_NLL * max(abs(o[0]), nvalid, 1.0), ("ll", case)
+        if nvalid == 0:
+            continue                                        # (no data: the posterior is the prior, compared through ll above)
+        assert rel_l2(pred[1][s_], o[1]) < 2e-4, ("hmean", case, rel_l2(pred[1][s_], o[1]))
+        assert rel_l2(pred[2][s_], o[2]) < 2e-4, ("hcov", case, rel_l2(pred[2][s_], o[2]))
+        assert np.max(np.abs(pred[3][s_] - o[3])) <= 1e-4 * np.max(np.abs(o[3])), ("cont", case)     # north_star: 1e-4
+        assert rel_l2(pred[4][s_], o[4]) < 1e-4, ("unc", case, rel_l2(pred[4][s_], o[4]))
