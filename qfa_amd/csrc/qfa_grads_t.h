@@ -244,16 +244,13 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const bool fastp = active && PXW * wt + PXW - 1 < Npix;
     const bool zblue = !ZF && blueTile;                     // the tile stages zabs
     const bool fastz = !zblue || PXW * wt + PXW - 1 < Nb;
-    const bool slow = active && !fastp;                     // the ragged last tile: 4-byte pieces
-    const bool zstrad = active && fastp && !fastz;          // zabs form, the tile across the end of the blue side: zabs as 4-byte pieces
+#ifndef QFA_GT_FASTONLY
+#define QFA_GT_FASTONLY 0  // register-pressure experiment (wrong results on ragged / straddling tiles): no general staging path
+#endif
+    const bool slow = !QFA_GT_FASTONLY && active && !fastp;                     // the ragged last tile: 4-byte pieces
+    const bool zstrad = !QFA_GT_FASTONLY && active && fastp && !fastz;          // zabs form, the tile across the end of the blue side: zabs as 4-byte pieces
     const bool zfb = ZF && blueTile;                        // the tile stages the per-spectrum factors of the factored-z form
-    // requests per group (the counted waits).  TPW = 1: fast tile 3 (+ 1: zabs or the factors); zabs tile across the boundary
-    // 3 + 4; ragged tile 4 + 4 + 1 (+ 4: zabs) (+ 1: the factors).  In general: 16-byte pieces TPW per array, 4-byte pieces
-    // 4 TPW per array, the masks TPW
-    // (+ 1 in the indexed form of ABI v3: the row indices of the group two groups later, stage_spectra)
-    const int nsp = !active ? 0
-                            : (slow ? 9 * TPW + (zblue ? 4 * TPW : 0) + (zfb ? 1 : 0)
-                                    : (zstrad ? 7 * TPW : 3 * TPW + (zblue ? TPW : 0) + (zfb ? 1 : 0))) + (IDX ? 1 : 0);
+    // (no counted waits any more, round 5: every wave waits for all of its requests in front of the step's barrier)
     // first byte of the 4-byte mask piece (half h of the tile, piece pc) in its row; the ragged tile clamps it to Npix - 4
     auto mask_start = [&](int h, int pc) __attribute__((always_inline)) {
         const int st = PXW * wt + 16 * h + 4 * pc;
@@ -292,6 +289,61 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             for (int i = 0; i < TPW; ++i) ri.r[i] = row_index(t, bufi, slot_row((64 / (4 * TPW)) * i + lane / (4 * TPW)), first_tag);
         }
         return ri;
+    };
+    // ---- round 5: the steady state of the staging requests without per-step address arithmetic.  A request of group t takes
+    // array base + (16 (g0 + t) + slot row) x row stride + the pixel of the lane's piece: in batch order (no row table), for a
+    // tile inside the pixel axis (zabs form: inside the blue side or the red one) and a FULL group of 16 spectra everything but
+    // 16 (g0 + t) x row stride is a per-lane constant of the launch.  That part lives in wave-uniform 64-bit pointers (SGPR pairs)
+    // which stage2 advances by 16 rows per call; the lane's offsets are three VGPRs formed once.  (The form it replaces rebuilt
+    // bases and offsets in every step: ~45 scalar instructions, a reload of a kernel argument and its wait -- 620 cycles per
+    // group and wave in the stamps; a scalar instruction outside an MFMA's shadow costs the wave 4 cycles like any other,
+    // tools/ubench/issue_mix.hip.)  The first two groups, the partial last group of a batch, ragged / straddling tiles, two
+    // tiles per wave and the indexed form keep the general path below.
+#ifndef QFA_GT_RUNPTR
+#define QFA_GT_RUNPTR 1
+#endif
+    constexpr bool RUNP = QFA_GT_RUNPTR && !IDX && TPW == 1 && !QFA_TRACKED_LOADS;
+    struct SpecRun {
+        const unsigned char *d, *e, *z, *m;       // group t + 2 of the next stage2 call; e, z, m biased by the LDS offsets of their arrays
+    } sr{nullptr, nullptr, nullptr, nullptr};
+    unsigned sr_vo = 0u, sr_vz = 0u, sr_om = 0u;  // byte offsets of the lane's pieces: delta / sigma, zabs (or the factors ZS), mask
+    const bool runok = RUNP && active && !slow && !zstrad;
+    if (RUNP) {
+        const size_t r2 = (size_t)16 * (size_t)(g0 + 2);
+        const unsigned q = (unsigned)lane >> 2, row = q ^ ((q >> 2) & 1u), pc = 16u * (unsigned)wt + 4u * ((unsigned)lane & 3u);
+        sr.d = uniform_ptr(reinterpret_cast<const unsigned char *>(bt.delta + r2 * RS));
+        sr.e = uniform_ptr(reinterpret_cast<const unsigned char *>(bt.error + r2 * RS) - GT::STG_ARR);
+        sr.m = uniform_ptr(reinterpret_cast<const unsigned char *>(bt.mask + r2 * RS) - GT::STG_MASK);
+        sr.z = zblue ? uniform_ptr(reinterpret_cast<const unsigned char *>(bt.zabs + r2 * (size_t)Nb) - 2 * GT::STG_ARR)
+                     : (zfb ? uniform_ptr(reinterpret_cast<const unsigned char *>(ZS + r2) - 2 * GT::STG_ARR) : sr.d);
+        sr_om = row * RS + pc;
+        sr_vo = 4u * sr_om;
+        sr_vz = zblue ? 4u * (row * (unsigned)Nb + pc) : 16u * ((unsigned)lane & 15u);
+    }
+    // the requests of one group from the running pointers (factored-z form: the 16 float4 factors as a request of all 64
+    // lanes, lanes 16.. repeat them -- the 1 KiB they fill is the slot the zabs tile has in the other form)
+    // Request k of the group the running pointers stand at: 0 delta (it writes M0 for all four), 1 sigma, 2 zabs / the factors,
+    // 3 the masks.  Round 5: they are issued ONE BY ONE between the MFMA groups of stage 3 -- back to back in stage 2 each waited
+    // until the texture path had taken the one before (4 requests: 625 cycles of the blue waves' 5 400 per group in the stamps,
+    // whatever the number of scalar instructions around them), between MFMAs they cost nothing (the state pieces never did).
+    auto stage_req = [&](int bufi, int k) __attribute__((always_inline)) {
+        if (k == 0) {
+            const unsigned dst = wave_uniform(lds_addr(stg + bufi * GT::STG_B));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(sr_vo), "s"(sr.d), "s"(dst) : "memory");
+        } else if (k == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(sr_vo), "s"(sr.e) : "memory");
+        else if (k == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(sr_vz), "s"(sr.z) : "memory");
+        else asm volatile("global_load_lds_dword %0, %1 offset:3072" ::"v"(sr_om), "s"(sr.m) : "memory");
+    };
+    const size_t sr_zinc = zblue ? (size_t)64 * (size_t)(unsigned)Nb : (zfb ? (size_t)256 : (size_t)0);
+    auto advance_run = [&]() __attribute__((always_inline)) {
+        if (!RUNP) return;
+#ifdef QFA_GT_ABL_L2
+        return;                // timing experiment (wrong results): every group re-reads the rows of group 2 -- the spectra come out of L2
+#endif
+        sr.d += (size_t)64 * RS;
+        sr.e += (size_t)64 * RS;
+        sr.m += (size_t)16 * RS;
+        sr.z += sr_zinc;
     };
     auto stage_spectra = [&](int t, int bufi, const RowIdx &ri, auto first_tag) __attribute__((always_inline)) {
         if (!active) return;
@@ -502,32 +554,53 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 
     // A part's pieces are issued one by one BETWEEN the MFMA groups of the stage that runs in the same half-step: eight waves
     // that issue their runs together behind the barrier fill the texture path's queue (16 cycles per piece) and wait in
-    // front of it -- 900 - 1 400 cycles per group and wave (tools/gt_stamps.sh).  j-th piece of this wave's run:
+    // front of it -- 900 - 1 400 cycles per group and wave (tools/gt_stamps.sh).
+    // Round 5: a piece is ONE instruction.  The wave's run of a part is contiguous in global memory and in LDS, so the stage
+    // writes M0 once (part_begin: LDS address of the run + 4096) and piece j moves both addresses by its immediate offset
+    // 1024 j - 4096 (signed 13 bits: eight pieces); the source pointers run along the walk (+ STATE_B per group, biased by
+    // 4096 as well) instead of being rebuilt from (g0 + t) per part, and the waves WITHOUT duty (the blue ones when there are
+    // five others) run instantiations of the walk that contain no piece code at all (NoPart) -- they used to execute a
+    // compare and a branch at each of the 22 piece sites of a step.
+    // (M0 belongs to these statements: nothing else in the walk may write it between part_begin and the stage's last piece --
+    // stage2 calls part_begin behind its spectra requests; tools/audit_asm_loads.py refuses a compiler-made write of M0.)
     struct Part {
-        const unsigned char *src;
-        unsigned dst;
+        const unsigned char *src;      // biased by + 4096 (tracked build: unbiased)
+        unsigned dst;                  // LDS byte address of the run, biased the same way
         int cnt;
     };
-    auto part_S1 = [&](int t) __attribute__((always_inline)) {          // (t >= n: nothing to issue)
-        return Part{uniform_ptr(PST + (size_t)(g0 + min(t, n - 1)) * GT::STATE_B + s1_first * 1024),
-                    (unsigned)wave_uniform(lds_addr(lds + GT::L_S1 + (t & 1) * GT::S1P_B + s1_first * 1024)), t < n ? s1_req : 0};
+    struct NoPart {};
+    constexpr unsigned PBIAS = QFA_TRACKED_LOADS ? 0u : 4096u;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto part_begin = [&](const auto &pt) __attribute__((always_inline)) {
+        if constexpr (std::is_same_v<std::decay_t<decltype(pt)>, Part>) {
+#if !QFA_TRACKED_LOADS
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(pt.dst));
+#endif
+        }
     };
-    auto part_Z = [&](int t) __attribute__((always_inline)) {
-        return Part{uniform_ptr(PST + (size_t)(g0 + min(t, n - 1)) * GT::STATE_B + GT::S1P_B + z_first * 1024),
-                    (unsigned)wave_uniform(lds_addr(lds + GT::L_Z + (t & 1) * GT::ZP_B + z_first * 1024)), t < n ? z_req : 0};
+    auto piece = [&](const auto &pt, int j) __attribute__((always_inline)) {
+        if constexpr (std::is_same_v<std::decay_t<decltype(pt)>, Part>) {
+            if (j < pt.cnt) {
+#if QFA_TRACKED_LOADS
+                glds16a(pt.src + 1024 * j, lane16, pt.dst + 1024 * j);
+#else
+#define QFA_PC(J) case J: asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane16), "s"(pt.src), "n"(1024 * J - 4096)); break;
+                switch (j) { QFA_PC(0) QFA_PC(1) QFA_PC(2) QFA_PC(3) QFA_PC(4) QFA_PC(5) QFA_PC(6) QFA_PC(7) default: break; }
+#undef QFA_PC
+#endif
+            }
+        }
     };
-    // (all pieces of a part as ONE run behind one write of M0 at the first slot: no different, tools/ab_pass2.sh)
-    auto piece = [&](const Part &pt, int j) __attribute__((always_inline)) {
-        if (j < pt.cnt) glds16a_nc(pt.src + 1024 * j, (unsigned)lane * 16u, pt.dst + 1024 * j);
-    };
+    static_assert((GT::Z_PCS + 4) / 5 <= 8 && (GT::S1_PCS + 4) / 5 <= 8, "a wave's run of a part: at most eight pieces (immediate offsets)");
 
     // ---- stage 1 of group t (its results wait in afy / aq for stage 2, one half-step later); the operands of a K block are
     // read once for the wave's TPW tiles
     f32x4 afy[TPW], aq[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) afy[j] = aq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto stage1 = [&](int t, const Part &pt) __attribute__((always_inline)) {
+    auto stage1 = [&](int t, const auto &pt) __attribute__((always_inline)) {
         if constexpr (QFA_GT_SETPRIO != 0 && (QFA_GT_PRIO_STAGES & 1) != 0) __builtin_amdgcn_s_setprio(QFA_GT_SETPRIO);
+        part_begin(pt);
         const unsigned char *sp = lds + GT::L_S1 + (t & 1) * GT::S1P_B + lane * 16;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) afy[j] = aq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -558,6 +631,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     // cycles.  Issued a stage ahead, in front of the MFMAs of stage 1, they made stage 1 2 400 cycles long instead of 1 100.)
     float dv[TPW][4], sgv[TPW][4], zv[TPW][4];
     unsigned mk[TPW][4];
+    RowIdx ri_next{};          // indexed form: the rows of group t + 2, read by stage 2 (t), used by stage 3 (t)
 #pragma unroll
     for (int j = 0; j < TPW; ++j)
 #pragma unroll
@@ -587,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         }
     };
     // ---- stage 2 of group t
-    auto stage2_t = [&](auto blue_tag, int t, const Part &pt) __attribute__((always_inline)) {
+    auto stage2_t = [&](auto blue_tag, int t, const auto &pt) __attribute__((always_inline)) {
         constexpr bool BLUE = decltype(blue_tag)::value;       // (the tile has blue pixels: wave-uniform, one branch per stage)
         const int s0 = 16 * (g0 + t);
         take(t);
@@ -600,8 +674,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                 zqx[r] = q.x; zqy[r] = q.y; zqz[r] = q.z;
             }
         }
-        RowIdx ri{};
-        if (t + 2 < n) ri = read_rows(t + 2, t & 1, std::false_type{});
+        if (IDX && t + 2 < n) ri_next = read_rows(t + 2, t & 1, std::false_type{});      // (for stage 3's requests)
         bool wvm[TPW][4];                                        // element counts: mask & spectrum < B & pixel < Npix (lane masks)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staging buffer read: it may be overwritten now
 #pragma unroll
@@ -614,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #pragma unroll
             for (int r = 0; r < 4; ++r) wvm[j][r] = inb[j] & (s0 + 4 * g + r < B) & (mk[j][r] != 0u);
         GTS(6)
-        if (t + 2 < n) stage_spectra(t + 2, t & 1, ri, std::false_type{});
+        part_begin(pt);
         piece(pt, 0);
         piece(pt, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -705,15 +778,26 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             d_beta += (double)t_beta;
         }
     };
-    auto stage2 = [&](int t, const Part &pt) __attribute__((always_inline)) {
+    auto stage2 = [&](int t, const auto &pt) __attribute__((always_inline)) {       // (the prologue's call)
         if (blueTile) stage2_t(std::true_type{}, t, pt);
         else stage2_t(std::false_type{}, t, pt);
     };
 
     // ---- stage 3 of group t: W[a] += Z pieces x the lane's own beta pieces (K = spectrum), the gamma term likewise; the Z
     // operands of a column tile are read once for the wave's TPW tiles
-    auto stage3 = [&](int t, const Part &pt) __attribute__((always_inline)) {
+    // The staging requests of group t + 2 (buffer t & 1, read for the last time by stage 2 (t)) are issued here: the running-pointer
+    // form one request per column tile in front of the part's pieces, every other form (the first two groups are the prologue's)
+    // as a block at the start.  They have the rest of the step to land: every wave waits for everything at the next barrier.
+    const int nfull = max(0, min(n, (B >> 4) - g0));         // groups of the range with 16 spectra
+    auto stage3 = [&](int t, const auto &pt) __attribute__((always_inline)) {
         if constexpr (QFA_GT_SETPRIO != 0 && (QFA_GT_PRIO_STAGES & 2) != 0) __builtin_amdgcn_s_setprio(QFA_GT_SETPRIO);
+        const bool run = RUNP && runok && t + 2 < nfull;
+        if (t + 2 < n && !run) {
+            // (batch order: the rows follow from t -- no LDS read; indexed form: stage 2 (t) read them out of the buffer)
+            const RowIdx ri = IDX ? ri_next : read_rows(t + 2, t & 1, std::false_type{});
+            stage_spectra(t + 2, t & 1, ri, std::false_type{});
+        }
+        if (!RUNP) part_begin(pt);
         const unsigned char *zp = lds + GT::L_Z + (t & 1) * GT::ZP_B + lane * 16;
         u32x4 bhl[TPW], bmm[TPW], bhh[TPW];
 #pragma unroll
@@ -723,25 +807,50 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             split2(betaR[j][2], betaR[j][3], h23, m23, l23);
             bhl[j] = u32x4{h01, h23, l01, l23}; bmm[j] = u32x4{m01, m23, m01, m23}; bhh[j] = u32x4{h01, h23, h01, h23};
         }
-        u32x4 zop[2][2];
-        zop[0][0] = *reinterpret_cast<const u32x4 *>(zp);
-        zop[0][1] = *reinterpret_cast<const u32x4 *>(zp + 1024);
+        // The Z operands of column tile a + ZD are requested in front of the MFMAs of tile a, and fences keep it that way (round 5):
+        // left to itself hipcc (which schedules this unit for register pressure) asks for tile a + 1 behind the first MFMA of
+        // tile a -- 32 cycles in front of its use, an LDS round trip in the open per column tile: 1 670 cycles for 816 of MFMAs.
+#ifndef QFA_GT_ZD
+#define QFA_GT_ZD 3
+#endif
+        constexpr int ZD = QFA_GT_ZD < GT::NWT ? QFA_GT_ZD : GT::NWT, ZR = ZD + 1;
+        u32x4 zop[ZR][2];
+        auto rdz = [&](int a) __attribute__((always_inline)) {                                   // (a == NWT: the p operands)
+            zop[a % ZR][0] = *reinterpret_cast<const u32x4 *>(zp + a * 2048);
+            zop[a % ZR][1] = *reinterpret_cast<const u32x4 *>(zp + a * 2048 + 1024);
+        };
+#pragma unroll
+        for (int a = 0; a < ZD; ++a) rdz(a);
 #pragma unroll
         for (int a = 0; a < GT::NWT; ++a) {
 #ifndef QFA_GT_ABL
 #define QFA_GT_ABL 0       // timing experiments (wrong results): 1 = stage 3 without its LDS reads, 2 = stage 3 without its DMA pieces
 #endif
-            if (QFA_GT_ABL & 1) { zop[(a + 1) & 1][0] = IBh[0][a % GT::NKQ]; zop[(a + 1) & 1][1] = IBm[0][a % GT::NKQ]; }
-            else {
-            zop[(a + 1) & 1][0] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048);          // (a + 1 == NWT: the p operands)
-            zop[(a + 1) & 1][1] = *reinterpret_cast<const u32x4 *>(zp + (a + 1) * 2048 + 1024);
-            }
-            if (a % 2 == 0 && !(QFA_GT_ABL & 2)) piece(pt, a / 2);
-            const u32x4 &Z1 = zop[a & 1][0], &Z2 = zop[a & 1][1];
+            if (QFA_GT_ABL & 1) { zop[(a + ZD) % ZR][0] = IBh[0][a % GT::NKQ]; zop[(a + ZD) % ZR][1] = IBm[0][a % GT::NKQ]; }
+            else if (a + ZD <= GT::NWT) rdz(a + ZD);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RUNP) {
+#ifndef QFA_GT_RQS
+#define QFA_GT_RQS 2       // column tiles between two staging requests
+#endif
+                // tiles 0, RQS, 2 RQS, 3 RQS: a request each (the third: blue tiles only); behind them the part's pieces (at most 7)
+                constexpr int RQS = QFA_GT_RQS, P0 = 3 * RQS + 1;
+                static_assert(P0 + 7 <= GT::NWT + (RQS == 1 ? 2 : 0) || RQS == 1, "piece sites");
+                if (a < P0) { if (a % RQS == 0 && run && (a / RQS != 2 || blueTile)) stage_req(t & 1, a / RQS); }
+                else if (!(QFA_GT_ABL & 2)) {
+                    if (a == P0) part_begin(pt);
+                    if (RQS == 1) {
+                        if ((a - P0) % 2 == 0) piece(pt, (a - P0) / 2);
+                        else if (a == GT::NWT - 1) piece(pt, (a - P0 + 1) / 2);
+                    } else if (a - P0 < 7) piece(pt, a - P0);
+                }
+            } else if (a % 2 == 0 && !(QFA_GT_ABL & 2)) piece(pt, a / 2);
+            const u32x4 &Z1 = zop[a % ZR][0], &Z2 = zop[a % ZR][1];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) W[j][a] = xdl(Z2, bhh[j], xdl(Z2, bmm[j], xdl(Z1, bhl[j], W[j][a])));
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const u32x4 &P1 = zop[GT::NWT & 1][0], &P2 = zop[GT::NWT & 1][1];
+        const u32x4 &P1 = zop[GT::NWT % ZR][0], &P2 = zop[GT::NWT % ZR][1];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
             unsigned h01, m01, l01, h23, m23, l23;
@@ -750,6 +859,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             const u32x4 ghl = {h01, h23, l01, l23}, gmm = {m01, m23, m01, m23}, ghh = {h01, h23, h01, h23};
             gacc[j] = xdl(P2, ghh, xdl(P2, gmm, xdl(P1, ghl, gacc[j])));                            // sum_s p_s[b] gamma[s][px]
         }
+        advance_run();
         if constexpr (QFA_GT_SETPRIO != 0 && (QFA_GT_PRIO_STAGES & 2) != 0) __builtin_amdgcn_s_setprio(0);
     };
 
@@ -777,46 +887,58 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     dma_wait<0>();
     step_barrier();
     const bool lead = wv8 < 4;
-    const Part none{nullptr, 0u, 0};
+    const NoPart none{};
     if (active && n > 0) {
         stage1(0, none);
         if (lead) stage2(0, none);
     }
-    if (!active) {
-        for (int t = 0; t < n; ++t) {
-            dma_wait<0>();
-            step_barrier();
-            if (t + 1 < n) issue_Z(t + 1);
-            if (t + 2 < n) issue_S1(t + 2);
-        }
-    } else if (lead) {
-        for (int t = 0; t < n; ++t) {
-            if (QFA_TRACKED_LOADS || t + 2 >= n) dma_wait<0>();
-            else dma_wait_n(nsp);
-            GTS(0)
-            step_barrier();
-            GTS(1)
-            stage3(t, part_Z(t + 1));
-            GTS(4)
-            if (t + 1 < n) {
-                stage1(t + 1, part_S1(t + 2));
-                stage2(t + 1, none);
+    // The parts' source pointers and ring slots run along the walk: the Z part of group t + 1 goes to slot (t + 1) & 1, the S1
+    // part of group t + 2 to slot t & 1.  (One walk for every kind of wave: instantiated per (blue, duty) -- six loops -- hipcc
+    // ran out of registers and spilled the image pieces.)
+    auto walk = [&]() __attribute__((always_inline)) {
+        // (biased by PBIAS; a part beyond the range has cnt = 0 and its pointer is never used)
+        const unsigned char *zsrc = uniform_ptr(PST + (size_t)(g0 + 1) * GT::STATE_B + GT::S1P_B + z_first * 1024 + PBIAS);
+        const unsigned char *ssrc = uniform_ptr(PST + (size_t)(g0 + 2) * GT::STATE_B + s1_first * 1024 + PBIAS);
+        const unsigned zd0 = wave_uniform(lds_addr(lds + GT::L_Z + z_first * 1024)) + PBIAS;
+        const unsigned sd0 = wave_uniform(lds_addr(lds + GT::L_S1 + s1_first * 1024)) + PBIAS;
+        unsigned zdst = zd0 + GT::ZP_B, sdst = sd0;                                        // t = 0: Z(1) -> slot 1, S1(2) -> slot 0
+        auto next = [&]() __attribute__((always_inline)) {
+            zsrc += GT::STATE_B; ssrc += GT::STATE_B;
+            zdst = 2 * zd0 + GT::ZP_B - zdst; sdst = 2 * sd0 + GT::S1P_B - sdst;
+        };
+        if (lead) {
+            for (int t = 0; t < n; ++t) {
+                dma_wait<0>();       // (round 5: the staging requests sit in stage 3, the first stage of the step -- nothing is left in flight)
+                GTS(0)
+                step_barrier();
+                GTS(1)
+                const Part pz{zsrc, zdst, t + 1 < n ? z_req : 0}, ps{ssrc, sdst, t + 2 < n ? s1_req : 0};
+                stage3(t, pz);
+                GTS(4)
+                if (t + 1 < n) {
+                    stage1(t + 1, ps);
+                    stage2(t + 1, none);
+                    GTS(3)
+                }
+                next();
+            }
+        } else {
+            for (int t = 0; t < n; ++t) {
+                dma_wait<0>();
+                GTS(0)
+                step_barrier();
+                GTS(1)
+                const Part pz{zsrc, zdst, t + 1 < n ? z_req : 0}, ps{ssrc, sdst, t + 2 < n ? s1_req : 0};
+                stage2(t, pz);
                 GTS(3)
+                stage3(t, ps);
+                GTS(4)
+                if (t + 1 < n) stage1(t + 1, none);
+                next();
             }
         }
-    } else {
-        for (int t = 0; t < n; ++t) {
-            dma_wait<0>();
-            GTS(0)
-            step_barrier();
-            GTS(1)
-            stage2(t, part_Z(t + 1));
-            GTS(3)
-            stage3(t, part_S1(t + 2));
-            GTS(4)
-            if (t + 1 < n) stage1(t + 1, none);
-        }
-    }
+    };
+    auto finish = [&]() __attribute__((always_inline)) {
 #if QFA_GT_STAMPS
     if (blockIdx.x == 100 && (wv8 == 0 || wv8 == 4) && lane == 0) {
         st_[7] = n;
@@ -899,4 +1021,14 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     } else {
         scal64_commit(sc64, s_tau0, s_c0, s_beta, gridDim.x * (unsigned)GT::NW, accS);
     }
+    };
+    if (!active) {
+        for (int t = 0; t < n; ++t) {
+            dma_wait<0>();
+            step_barrier();
+            if (t + 1 < n) issue_Z(t + 1);
+            if (t + 2 < n) issue_S1(t + 2);
+        }
+    } else walk();
+    finish();
 }

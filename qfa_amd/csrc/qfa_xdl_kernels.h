@@ -503,7 +503,11 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             // first (min / max drop a NaN: a masked pixel may hold anything, not only the reference's -999), so m = 0 times
             // them is 0.  For unmasked pixels every product is by exactly 1: the same bits as the select form.
             const unsigned mw0 = svalid ? cur.m[0] : 0u, mw1 = svalid ? cur.m[1] : 0u;
-            constexpr float BIG = 3.0e38f;
+            // D is clamped from BELOW too: a pad pixel of the ragged last tile has Psi = 0 in the image and clones
+            // sigma of pixel Npix - 1, a masked pixel may carry error = 0 under Psi = 0 -- D = 0, 1/D = inf, and 0 x inf = NaN
+            // would reach the MFMA operands and the NLL of the whole spectrum.  One v_med3 in the place of the v_min (a NaN
+            // makes it return the smallest operand: finite as well).
+            constexpr float BIG = 3.0e38f, TINY = 1.0e-37f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float c2[2], c3[2], cb[2], cb2[2];
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                             A = blue ? Ab : 1.f;
                             zdom = blue ? t.zd * om[e] : 0.f;
                         }
-                        D = fminf(A * A * psi[e] + zdom + sg * sg, BIG);
+                        D = __builtin_amdgcn_fmed3f(A * A * psi[e] + zdom + sg * sg, TINY, BIG);
                         if (PREDICT) d = d - muv[e] * A;                     // QFA/model.py:166
                         wD = mf * fast_rcp(D);
                         const float wDA = wD * A;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                         }
                         cblue = fmaf(mf, bluef[e], cblue);
                     } else {                                                 // red side: A = 1, no omega term
-                        D = fminf(psi[e] + sg * sg, BIG);
+                        D = __builtin_amdgcn_fmed3f(psi[e] + sg * sg, TINY, BIG);
                         if (PREDICT) d = d - muv[e];
                         wD = mf * fast_rcp(D);
                         c2[h2] = wD;

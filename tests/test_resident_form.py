@@ -144,6 +144,41 @@ def test_masked_pixels_may_hold_anything(dev, npix, nh, N, flags, zform):
     assert torch.equal(acc0, acc2)
 
 
+@pytest.mark.parametrize("npix,nh,masked,zform", [(1913, 8, True, False), (1913, 8, False, False), (1913, 12, True, True), (9243 // 8, 8, True, False),
+                                                  (77, 20, True, False)])
+def test_zero_error_in_the_last_pixel_of_a_ragged_row(dev, npix, nh, masked, zform):
+    """the pad pixels of the ragged last 32-pixel tile (N_pix = 1913, 9243: the reference's shapes) clone delta / sigma of
+    pixel N_pix - 1 and have Psi = 0 in pass 1's image; with error == 0 there (the pixel masked or not) D was 0, 1/D inf and the
+    mask FACTOR 0 made a NaN of it -- in every moment and the NLL of the spectrum.  The reference handles such a pixel (it is
+    simply masked, or its D is Psi A^2 > 0).  Tensor form with unpadded rows; results against the oracle, prediction finite."""
+    import torch
+    from oracle import qfa_oracle as O
+    N = 48
+    m, rb0, b, p, mu = resident_set(dev, npix, nh, N, seed=7 * npix + nh, stride=npix, with_zabs=zform)
+    rb = rb0.with_rows(torch.arange(N, dtype=torch.int32, device=dev))
+    rb.error[:, npix - 1] = 0.0
+    b["error"][:, npix - 1] = 0.0
+    if masked:
+        rb.mask[:, npix - 1] = False
+        b["mask"][:, npix - 1] = False
+    (d, e, z, mk), zfac = rb.materialize()
+    m.deterministic = True
+    nll = torch.empty(N, dtype=torch.float32, device=dev)
+    acc = m.accumulate(d, e, z, mk, zfac=zfac, nll=nll).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(nll).all() and torch.isfinite(acc).all()
+    oloss, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
+    loss, g = m._finalize(acc, True)
+    assert abs(loss.item() - oloss) / abs(oloss) < 5e-6
+    for key, tol in (("Psi", 2e-5), ("F", 1e-4)):
+        ref = np.asarray(og[key])
+        ok = ~np.isnan(ref)
+        assert rel_l2(g[key].cpu().numpy()[ok], ref[ok]) < tol, key
+    (fx, e2, z2, mk2), zfac2 = rb.materialize(raw_flux=True)
+    for a in m.predict(fx, e2, z2, mk2, zfac=zfac2):
+        assert torch.isfinite(a).all()
+
+
 @pytest.mark.parametrize("npix,nh,flags", [(1913, 8, 0), (1913, 8, _lib.F_PASS2_PIXRES), (1000, 16, _lib.F_PASS2_PIXRES), (450, 24, 0)])
 def test_padded_and_unpadded_rows_give_the_same_bits(dev, npix, nh, flags):
     """row_stride = N_pix (the reference's layout) against rows padded to 32 pixels: identical results"""

@@ -3,7 +3,8 @@ asm statements that hipcc does not track, so nothing but program order protects 
 such load (between ;;#ASMSTART / ;;#ASMEND) of every kernel check that no instruction reads or writes its destination
 registers before the next `s_waitcnt vmcnt(...)`; in k_grads_x and k_predict_x also require zero scratch (spills of
 loop-carried registers produced wrong results in k_grads_x once, and a scratch reload makes hipcc wait vmcnt(0) in the
-middle of the counted queue).  The scan is linear in program order (the code behind an unconditional branch starts
+middle of the counted queue); in k_grads_t no instruction outside the asm statements may touch M0 (a stage's LDS-DMA
+pieces share one write of it).  The scan is linear in program order (the code behind an unconditional branch starts
 with nothing pending; a counted wait is taken to retire every asm load before it): a build-time tripwire beside the
 dynamic check, tests/test_tracked_loads.py.  Exit code 1 on a violation.
 
@@ -37,6 +38,10 @@ for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", src, re.S | re.M):
             continue
         if "scratch_" in t and name.startswith(NO_SCRATCH):
             print(f"{name}: scratch access: {t}"); bad += 1
+        # k_grads_t (round 5) writes M0 once per stage and lets the stage's LDS-DMA pieces ride on it: no compiler-made
+        # instruction may touch M0 in that kernel
+        if not in_asm and name.startswith("_Z9k_grads_t") and re.search(r"\bm0\b", t):
+            print(f"{name}: M0 used outside the asm statements: {t}"); bad += 1
         if t.startswith("s_waitcnt") and "vmcnt" in t:
             pending.clear(); continue
         regs = set()
