@@ -378,7 +378,8 @@ def main():
         model.enable_data_parallel()
     opt = Adam(model.parameters, dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3, weight_decay=1e-1)
 
-    for _ in range(args.warmup):
+    # (at least two untimed steps: the second sighting of the zabs tensor runs the one-time structure test of QFA.auto_factor_zabs)
+    for _ in range(max(args.warmup, 2 if (model.auto_factor_zabs and nb > 0) else 0)):
         model.step(opt, *batch)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     for es in evs:
@@ -401,6 +402,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_rank = dt
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -472,6 +474,76 @@ def main():
               "note": "qfa_batch_t::zq1 / pix_ratio instead of zabs (B, Nb): 4 Nb bytes per spectrum and pass less, two "
                       "transcendentals per blue element instead of five; same results to float32 rounding "
                       "(tests/test_hip_parity.py::test_factored_z_input_form_matches_zabs_form_and_oracle)"}
+    # ---- the same tensors with QFA.auto_factor_zabs off: the kernels that READ zabs (every step of rounds 1-4's `value`)
+    zk = None
+    auto_on = bool(model.auto_factor_zabs) and nb > 0
+    ent = model._zf_seen.get(id(batch[2])) if auto_on else None
+    factored_headline = bool(ent is not None and isinstance(ent[2], tuple))
+    if auto_on:
+        model.auto_factor_zabs = False
+        for _ in range(2):
+            model.step(opt, *batch)
+        zev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+        for es in zev:
+            for e in es:
+                e.record()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            model.step(opt, *batch, events=zev[i])
+        torch.cuda.synchronize()
+        dtz = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([dtz], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtz = float(t.item())
+        model.auto_factor_zabs = True
+        zst = np.array([[es[j].elapsed_time(es[j + 1]) for j in range(4)] for es in zev]).mean(axis=0)
+        # what the structure test costs when it runs (once per repeated tensor): HIP events around the entry point
+        import ctypes as C
+        from qfa_amd import _lib as _L
+        zq_t, rt_t = torch.empty(B, device=dev), torch.empty(nb, device=dev)
+        nbad_t = torch.empty(1, dtype=torch.int32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        chk = lambda: _L.check(_L.lib().qfa_zabs_factor_f32(C.c_void_p(batch[2].data_ptr()), B, nb, 4e-7, C.c_void_p(zq_t.data_ptr()),
+                                                           C.c_void_p(rt_t.data_ptr()), C.c_void_p(nbad_t.data_ptr()),
+                                                           _L.current_stream(dev)), "qfa_zabs_factor_f32")
+        chk()
+        e0.record(); chk(); e1.record()
+        torch.cuda.synchronize()
+        zk = {"ms_per_step": dtz / args.steps * 1e3, "value": world * B * args.steps / dtz,
+              "stage_ms": {"pf_image": float(zst[0]), "pass1_moments": float(zst[1]), "solve": float(zst[2]), "pass2_grads": float(zst[3])},
+              "structure_test_ms": e0.elapsed_time(e1), "structure_test_bad_elements": int(nbad_t.item()),
+              "note": "QFA.auto_factor_zabs = False: pass 1 and pass 2 read zabs (B, Nb) and evaluate five transcendentals per blue "
+                      "element; `value` of this line in rounds 1-4.  structure_test_ms: one qfa_zabs_factor_f32 call on this batch "
+                      "(run once, at the second sighting of a tensor; not part of a timed step)"}
+    # ---- SURVEY 8(d) "also a run at random_init_func values" (QFA/model.py:67-72: F ~ U(-0.5, 0.5), Psi = omega = 1, tau0 0.02,
+    # c0 0.3, beta 2): the same batch through a freshly initialised model
+    rinit = None
+    if world == 1 and args.config in ("c3", "c4", "c2"):
+        torch.manual_seed(20220700)
+        m2 = QFA(nb, nr, nh, dev)
+        m2.flags, m2.deterministic = args.flags, bool(args.deterministic)
+        opt2 = Adam(m2.parameters, dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3, weight_decay=1e-1)
+        for _ in range(3):
+            l2 = m2.step(opt2, *batch)
+        rev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+        for es in rev:
+            for e in es:
+                e.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            l2 = m2.step(opt2, *batch, events=rev[i])
+        torch.cuda.synchronize()
+        dtr = time.perf_counter() - t1
+        rst = np.array([[es[j].elapsed_time(es[j + 1]) for j in range(4)] for es in rev]).mean(axis=0)
+        rinit = {"ms_per_step": dtr / args.steps * 1e3, "value": B * args.steps / dtr, "loss": float(l2.item()),
+                 "stage_ms": {"pf_image": float(rst[0]), "pass1_moments": float(rst[1]), "solve": float(rst[2]), "pass2_grads": float(rst[3])},
+                 "parameters": "random_init_func (reference QFA/model.py:57-72), three Adam steps in"}
+        del m2, opt2
     f1, f2 = alg_flops(npix, nh)
     by = alg_bytes(npix, nb)
     rate = world * B * args.steps / dt
@@ -492,10 +564,10 @@ def main():
     # The contractions are ISSUED as bf16 piece products on the XDL pipe: per spectrum
     #   pass 1                 4 n k^2 x 6
     #   pass 2, N_h <= 16      n k^2 x 6 (stage 1, diag Sigma^-1) + 2 n k^2 x 6 (stage 3, M Z; x 3 with QFA_F_S3_FAST)
-    #   pass 2, N_h = 17..32   n k^2 x 6 + 2 n k^2 x 4 (x 3 with QFA_F_S3_FAST)
+    #   pass 2, N_h = 17..32   n k^2 x 6 + 2 n k^2 x 6 (k_grads_s3<KP, 6> from round 4 on; x 3 with QFA_F_S3_FAST)
     # `roofline` prices the issued bf16 flops of the dominant kernel against the dense bf16 MFMA peak.
     nk2 = npix * nh * nh
-    s3 = 3 if fast else (6 if nh <= 16 else 4)
+    s3 = 3 if fast else 6
     if dominant in ("k_grads_x", "k_grads_t", "k_s12_x+2*k_grads_s3"):
         xdl_flops = (6 * 1 + s3 * 2) * nk2
     elif dominant == "k_moments_x":
@@ -518,10 +590,17 @@ def main():
                 traffic_src = {"traffic_source": f"profiles/traffic_{args.config}.json (builder's rocprofv3 --pmc run, tools/profile_round.sh)",
                                "traffic_stale": tj.get("libqfa_hip_sha256") != sha,
                                "traffic_measured_on_sha256": tj.get("libqfa_hip_sha256"), "libqfa_hip_sha256": sha}
-                traffic = tj.get(dominant.replace("k_moments_x", "k_moments") + "_hbm_bytes_per_launch")
+                zs_ = "_zfac" if factored_headline else ""
                 p2key = p2_name
-                parts = [tj.get(kk + "_hbm_bytes_per_launch") for kk in ("k_moments", "k_solve", p2key)]
+                traffic = tj.get((("k_moments_x" + zs_) if factored_headline else "k_moments") + "_hbm_bytes_per_launch") if dominant == "k_moments_x" \
+                    else tj.get(p2key + zs_ + "_hbm_bytes_per_launch")
+                parts = [tj.get(kk + "_hbm_bytes_per_launch") for kk in (("k_moments_x_zfac" if factored_headline else "k_moments"), "k_solve", p2key + zs_)]
                 traffic_step = sum(parts) if all(x is not None for x in parts) else None
+                if zk is not None:
+                    zparts = [tj.get(kk + "_hbm_bytes_per_launch") for kk in ("k_moments", "k_solve", p2key)]
+                    if all(x is not None for x in zparts):
+                        zk["measured_hbm_bytes_per_step"] = sum(zparts)
+                        zk["traffic_ratio"] = sum(zparts) / (by * B)
                 p2z = p2key + "_zfac"
                 if fz is not None and all((kk + "_hbm_bytes_per_launch") in tj for kk in ("k_moments_x_zfac", p2z, "k_solve")):
                     fz["measured_hbm_bytes_per_step"] = sum(tj[kk + "_hbm_bytes_per_launch"] for kk in ("k_moments_x_zfac", p2z, "k_solve"))
@@ -534,7 +613,7 @@ def main():
                 "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel_ms": dom_ms,
                 "flops_per_spectrum": xdl_flops,
                 "priced": "bf16 piece-product flops issued on the XDL pipe (six per float32 product"
-                          + (", three in stage 3: QFA_F_S3_FAST" if fast else (", four in stage 3 at N_h > 16" if nh > 16 else ""))
+                          + (", three in stage 3: QFA_F_S3_FAST" if fast else "")
                           + ") over the dense bf16 MFMA peak",
                 "alg_flops_per_spectrum": dom_flops, "achieved_alg_fp32": ach32,
                 "frac_vs_fp32_roof": ach32 / PEAK_FP32_TFLOPS}
@@ -555,12 +634,16 @@ def main():
                                f"{'random pixel masks' if masks else 'no masks'}, becker tau, "
                                f"forward + {'RCCL all-reduce + ' if world > 1 else ''}Adam + clip",
                    "spectra_per_gpu": B, "n_pix": npix, "n_b": nb, "n_h": nh, "parallelism": f"dp{world}",
+                   "input_form": ("the reference's forward signature (delta, error, zabs, mask: QFA/model.py:74).  The zabs tensor came back "
+                                  "unchanged, was tested ONCE for the structure the reference's loader gives it (1 + zabs = (1 + z_qso) wav / "
+                                  "1215.67, QFA/dataloader.py:102; qfa_zabs_factor_f32, during warm-up) and is served by the factored-z "
+                                  "kernels since (QFA.auto_factor_zabs; `zabs_kernels` = the same steps with that switched off)")
+                                 if factored_headline else "the reference's forward signature (delta, error, zabs, mask); the kernels read zabs",
                    "arithmetic": "float32 throughout; pass 1 (N_h <= 16) and pass 2 (N_h = 9..16) issue their contractions as "
                                  "bf16 XDL MFMAs over operands split into three bf16 pieces (float32-exact split, float32 "
                                  "accumulate): six piece products per float32 product (error vs float64 at or below the f32 "
                                  "MFMA's, tools/ubench/bf16x3_numerics.hip) in every stage"
                                  + (" EXCEPT stage 3 of pass 2, run here with three (--flags 0x4: operands carried to ~17 bits)" if fast else "")
-                                 + ("; at N_h > 16 stage 3 of pass 2 issues four products over two pieces" if nh > 16 and not fast else "")
                                  + "; k x k solve and scalar-gradient sums in float64", "flags": fl},
         "roofline": roof,
         "stage_ms": {"pf_image": ms_prep, "pass1_moments": ms_p1, "solve": ms_solve, "pass2_grads": ms_p2,
@@ -582,6 +665,21 @@ def main():
     }
     if fz is not None:
         out["factored_z"] = fz
+    if zk is not None:
+        out["zabs_kernels"] = zk
+    if rinit is not None:
+        out["random_init_values"] = rinit
+    # who ran: the collective's own view of the job, and every rank's clock (the line's value uses the slowest)
+    rk = {"rank": rank, "device": int(torch.cuda.current_device()), "device_name": torch.cuda.get_device_name(dev),
+          "ms_per_step": dt_rank / args.steps * 1e3, "stage_ms": [ms_prep, ms_p1, ms_solve, ms_p2]}
+    if use_dist:
+        allr = [None] * world
+        dist.all_gather_object(allr, rk)
+        out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "per_rank": allr,
+                        "max_over_ranks_ms": max(r["ms_per_step"] for r in allr), "min_over_ranks_ms": min(r["ms_per_step"] for r in allr)}
+    else:
+        out["ranks"] = {"world_size": 1, "backend": None, "per_rank": [rk], "max_over_ranks_ms": rk["ms_per_step"],
+                        "min_over_ranks_ms": rk["ms_per_step"]}
     if sustained is not None:
         out["sustained_ms_per_step"] = sustained["ms_per_step"]
         out["sustained"] = sustained

@@ -25,13 +25,15 @@
 extern "C" {
 #endif
 
-#define QFA_ABI_VERSION 3   /* v2: qfa_batch_t carries the factored-z input form; *_ex_f32 entry points with `flags`;
-                             * v3: qfa_batch_t carries the resident, indexed input form (rows, row_stride)          */
+#define QFA_ABI_VERSION 4   /* v2: qfa_batch_t carries the factored-z input form; *_ex_f32 entry points with `flags`;
+                             * v3: qfa_batch_t carries the resident, indexed input form (rows, row_stride);
+                             * v4: qfa_zabs_factor_f32, QFA_E_FLAGS                                                  */
 
 #define QFA_E_NULL      (-1)   /* a required pointer is NULL            */
 #define QFA_E_SIZE      (-2)   /* B/Npix/Nb/Nh out of range              */
 #define QFA_E_WORKSPACE (-3)   /* workspace smaller than qfa_workspace_bytes */
 #define QFA_E_TAU       (-4)   /* unknown tau model                      */
+#define QFA_E_FLAGS     (-5)   /* a `flags` bit that does not apply to this shape (QFA_F_S3_FAST at N_h <= 16) */
 
 /* Mean-optical-depth model tau(z) = (amp * ((1+z)*scale)^expo + offset) * series_coeff
  * (reference QFA/utils.py:95-141, 149-171).  qfa_tau_model() fills it for the four built-ins. */
@@ -270,6 +272,17 @@ int qfa_build_batch_f32(const float *flux, const float *error, const double *zqs
 int qfa_build_resident_f32(const float *flux, const float *error, const double *zqso, const double *wav, double wav0,
                            const double *mu, int which, int64_t nrow, int Npix, int Nb, int64_t row_stride,
                            float *delta, uint8_t *mask, float *zq1, void *stream);
+
+/* ABI v4.  Does a caller's zabs (B, Nb) have the structure the reference's loader gives it -- 1 + zabs[s][i] =
+ * (1 + z_qso[s]) wav_i / 1215.67 (reference QFA/dataloader.py:102) -- so that the factored-z input form (qfa_batch_t::zq1 /
+ * pix_ratio above) may stand in for it?  Writes zq1[s] = 1 + zabs[s][0] (B floats) and pix_ratio[i] = (1 + zabs[0][i]) /
+ * (1 + zabs[0][0]) (Nb floats; the quotient in float64, rounded once) and counts in *nbad (device memory, zeroed by the call)
+ * the elements with |(1 + zabs[s][i]) - zq1[s] pix_ratio[i]| > tol (1 + zabs[s][i]) (a NaN counts).  nbad == 0: every 1 + z the
+ * factored kernels form is within tol (relative) of the one the zabs kernels read -- at tol = 4e-7 (three float32 roundings) the
+ * results agree as the two forms of one loader's batch do (tests/test_hip_parity.py).  One pass over zabs: B Nb 4 bytes read.
+ * Asynchronous like every entry point: the caller reads *nbad behind the stream. */
+int qfa_zabs_factor_f32(const float *zabs, int B, int Nb, float tol, float *zq1, float *pix_ratio, unsigned *nbad,
+                        void *stream);
 
 /* Replaces the continuum-mean estimate of Dataloader.__init__ (reference QFA/dataloader.py:110-112):
  * mu_raw = sum_s flux exp(+tau_total) mask / #(flux != -999); mu_smooth = reflect-padded boxcar of

@@ -9,18 +9,19 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("QFA_HIP_LIB", os.path.join(_HERE, "libqfa_hip.so"))
+# (no environment switch: tools/with_lib.py sets this attribute before the first lib() call for A/B timing of library variants)
+LIB_PATH = os.path.join(_HERE, "libqfa_hip.so")
 
 EXPORTS = (
     "qfa_abi_version", "qfa_tau_model", "qfa_workspace_bytes", "qfa_accum_floats",
     "qfa_nll_grad_f32", "qfa_nll_grad_events_f32", "qfa_nll_grad_det_f32", "qfa_nll_grad_ex_f32", "qfa_predict_ex_f32", "qfa_det_slab_bytes", "qfa_finalize_grads_f32", "qfa_predict_f32", "qfa_predict_events_f32",
     "qfa_adam_clip_f32",
     "qfa_adam_clip_multi_f32", "qfa_clip_f32", "qfa_smooth_f32", "qfa_tau_f32", "qfa_tauhi_f32", "qfa_omega_func_f32", "qfa_woodbury_f32", "qfa_build_batch_f32", "qfa_mu_estimate_f64",
-    "qfa_mu_sums_f64", "qfa_mu_finish_f64", "qfa_build_resident_f32", "qfa_finalize_adam_clip_f32",
+    "qfa_mu_sums_f64", "qfa_mu_finish_f64", "qfa_build_resident_f32", "qfa_finalize_adam_clip_f32", "qfa_zabs_factor_f32",
 )
 
 TAU_IDS = {"becker": 0, "fg": 1, "kamble": 2, "mock": 3}
-ABI_VERSION = 3
+ABI_VERSION = 4
 # `flags` of qfa_nll_grad_ex_f32 / qfa_predict_ex_f32 (include/qfa_hip.h QFA_F_*)
 F_PASS2_F32, F_PASS2_XDL, F_S3_FAST, F_PREDICT_F32, F_SYNC = 0x1, 0x2, 0x4, 0x8, 0x20
 F_PASS2_PIXRES = 0x40
@@ -105,16 +106,15 @@ def lib():
         "qfa_mu_estimate_f64": (i, [p, p, p, p, d, i, i, i, i, i64, i, p, p, p, p]),
         "qfa_mu_sums_f64": (i, [p, p, p, p, d, i, i, i, i, i64, p, p]),
         "qfa_mu_finish_f64": (i, [p, i, i, p, p, p]),
+        "qfa_zabs_factor_f32": (i, [p, i, i, f, p, p, p, p]),
     }
     for name, (res, args) in sigs.items():
-        if not hasattr(h, name) and os.environ.get("QFA_HIP_ALLOW_ABI"):
-            continue                                            # (A/B timing of an older library: see below)
-        fn = getattr(h, name)
+        fn = getattr(h, name, None)
+        if fn is None:
+            raise QFAHipError(f"{LIB_PATH} does not export {name} (include/qfa_hip.h): rebuild it")
         fn.restype = res
         fn.argtypes = args
-    if h.qfa_abi_version() != ABI_VERSION and os.environ.get("QFA_HIP_ALLOW_ABI") != str(h.qfa_abi_version()):
-        # (QFA_HIP_ALLOW_ABI=2: same-box A/B timing of an older library through bench.py's tensor path only --
-        # qfa_batch_t grew at its END in v3, the loader entry points changed their signatures)
+    if h.qfa_abi_version() != ABI_VERSION:
         raise QFAHipError(f"libqfa_hip.so ABI version {h.qfa_abi_version()}, expected {ABI_VERSION}")
     _lib = h
     return h
@@ -124,7 +124,7 @@ def check(status, what):
     if status == 0:
         return
     if status < 0:
-        names = {-1: "QFA_E_NULL", -2: "QFA_E_SIZE", -3: "QFA_E_WORKSPACE", -4: "QFA_E_TAU"}
+        names = {-1: "QFA_E_NULL", -2: "QFA_E_SIZE", -3: "QFA_E_WORKSPACE", -4: "QFA_E_TAU", -5: "QFA_E_FLAGS"}
         raise QFAHipError(f"{what}: invalid argument ({names.get(status, status)})")
     raise QFAHipError(f"{what}: hipError_t {status}")
 

@@ -291,6 +291,18 @@ int qfa_build_resident_f32(const float *flux, const float *error, const double *
     return hip_status();
 }
 
+int qfa_zabs_factor_f32(const float *zabs, int B, int Nb, float tol, float *zq1, float *pix_ratio, unsigned *nbad,
+                        void *stream) {
+    if (!zabs || !zq1 || !pix_ratio || !nbad) return QFA_E_NULL;
+    if (B < 1 || Nb < 1 || !(tol >= 0.f)) return QFA_E_SIZE;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = B > Nb ? B : Nb;
+    k_zfactor_derive<<<(n + 255) / 256, 256, 0, st>>>(zabs, B, Nb, zq1, pix_ratio, nbad);
+    const dim3 grid((unsigned)((Nb + 255) / 256 < 8 ? (Nb + 255) / 256 : 8), (unsigned)((B + 7) / 8));
+    k_zfactor_check<<<grid, 256, 0, st>>>(zabs, B, Nb, zq1, pix_ratio, tol, nbad);
+    return hip_status();
+}
+
 int qfa_mu_estimate_f64(const float *flux, const float *error, const double *zqso, const double *wav, double wav0,
                         int which, int B, int Npix, int Nb, int64_t row_stride, int window_len, double *scratch,
                         double *mu_raw, double *mu_smooth, void *stream) {

@@ -389,7 +389,7 @@ int run_nll_grad(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t &t
     if constexpr (KP == 8 || KP == 16) pass2_xdl = pass2_use_xdl(KP, B, flags);
 #ifndef QFA_WITH_GFORM
     // the three-product form of stage 3 at N_h <= 16 (the G form of k_grads_x) is not part of the shipped library any more
-    if constexpr (KP <= 16) { if (flags & QFA_F_S3_FAST) return QFA_E_SIZE; }
+    if constexpr (KP <= 16) { if (flags & QFA_F_S3_FAST) return QFA_E_FLAGS; }    // (the three-product form exists at N_h = 17..32 only)
 #endif
     mark(0);
     const bool pixres = pass2_xdl && pass2_use_pixres(KP, B, Npix, flags);             // (its ragged-tile staging wants N_pix >= 4)

@@ -217,3 +217,37 @@ __global__ void k_wood_inv(const float *__restrict__ M, const float *__restrict_
     inv[idx] = (float)((i == j ? di : 0.0) - di * acc * dj);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// qfa_zabs_factor_f32 (ABI v4): is a caller's zabs (B, Nb) of the form the reference's loader builds,
+//   1 + zabs[s][i] = (1 + z_qso[s]) wav_i / 1215.67   (QFA/dataloader.py:102)?
+// k_zfactor_derive takes the two factors from row 0 and column 0 (float64 quotient, one rounding each):
+//   zq1[s] = 1 + zabs[s][0],   ratio[i] = (1 + zabs[0][i]) / (1 + zabs[0][0])
+// k_zfactor_check counts the elements with |(1 + zabs[s][i]) - zq1[s] ratio[i]| > tol (1 + zabs[s][i]); a NaN counts.
+// With nbad == 0 the factored-z kernels see every 1 + z within `tol` (a few float32 ulp) of what the zabs kernels would read.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_zfactor_derive(const float *__restrict__ zabs, int B, int Nb, float *__restrict__ zq1, float *__restrict__ ratio,
+                                 unsigned *__restrict__ nbad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *nbad = 0u;
+    if (i < B) zq1[i] = 1.0f + zabs[(size_t)i * Nb];
+    if (i < Nb) ratio[i] = (float)((1.0 + (double)zabs[i]) / (1.0 + (double)zabs[0]));
+}
+__global__ __launch_bounds__(256) void k_zfactor_check(const float *__restrict__ zabs, int B, int Nb, const float *__restrict__ zq1,
+                                                       const float *__restrict__ ratio, float tol, unsigned *__restrict__ nbad) {
+    // block = 8 spectra x a strip of pixels; 4 consecutive pixels per thread where the row allows 16-byte loads
+    const int s0 = blockIdx.y * 8;
+    unsigned bad = 0u;
+    for (int r = 0; r < 8; ++r) {
+        const int s = s0 + r;
+        if (s >= B) break;
+        const float zq = zq1[s];
+        const float *row = zabs + (size_t)s * Nb;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Nb; i += gridDim.x * blockDim.x) {
+            const float a = 1.0f + row[i], d = a - zq * ratio[i];
+            if (!(fabsf(d) <= tol * a)) ++bad;
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(nbad, bad);
+}

@@ -120,7 +120,7 @@ class DeviceDataloader(object):
         self._order_dev = None                                  # the epoch's row order on the device (int32), uploaded by rewind()
         self._step_off = None                                   # DP: offsets of the steps inside _order_dev
         self._prefetched = False                                # the next epoch's order is already drawn (prefetch_epoch)
-        self.sort_batches = True                                # rows of a batch in storage order (see _upload_order)
+        self._sort_batches = True                               # rows of a batch in storage order (see _upload_order; property below)
         self.cur = 0
         self._window = int(window_length_for_mu)
         self._mu_raw, self._mu = self._estimate_mu(self._window)
@@ -192,6 +192,20 @@ class DeviceDataloader(object):
             C.c_void_p(self._wav_dev.data_ptr()), float(self.wav_grid[0]), C.c_void_p(self._mu_dev.data_ptr()), self._which,
             n, self.Npix, self.Nb, self._stride, C.c_void_p(self._delta_pad.data_ptr()), C.c_void_p(self._mask_pad.data_ptr()),
             C.c_void_p(self._zq1_res.data_ptr()), _lib.current_stream(self.device)), "qfa_build_resident_f32")
+
+    @property
+    def sort_batches(self):
+        return self._sort_batches
+
+    @sort_batches.setter
+    def sort_batches(self, on):
+        """(the device copy of the epoch's order is what carries the sorting: a change re-uploads it, so that next_batch() and
+        next_batch_rows() keep describing the same rows)"""
+        on = bool(on)
+        if on != self._sort_batches:
+            self._sort_batches = on
+            if getattr(self, "_order_dev", None) is not None:
+                self._upload_order()
 
     def _upload_order(self):
         """The epoch's row order as ONE int32 device array (batches are contiguous slices of it).  ``sort_batches`` (default):
@@ -340,6 +354,8 @@ class DeviceDataloader(object):
             return
         self._draw_epoch()
         self._prefetched = True
+        # the drawn order belongs to the NEXT epoch: the current one is over for next_batch() / have_next_batch() until rewind()
+        self.cur = len(self._steps) if (self._plan is not None and self._steps is not None) else self.local_size
 
     def rewind(self):
         """shuffle and reset (reference QFA/dataloader.py:154-167); only the row order is permuted,

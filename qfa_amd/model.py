@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import time
+import weakref
 from functools import partial
 from typing import Callable, Dict
 
@@ -32,6 +33,10 @@ log2pi = 1.8378770664093453
 default_tau = partial(_utils.tau, which="becker")
 
 PARAM_KEYS = ("F", "Psi", "omega", "tau0", "c0", "beta")
+# default of QFA.auto_factor_zabs (tests/conftest.py turns it off: zabs tensors there are meant to exercise the zabs kernels) and
+# the relative tolerance of the structure test: three float32 roundings of 1 + z (zabs itself, zq1, pix_ratio)
+AUTO_FACTOR_ZABS = True
+AUTO_FACTOR_TOL = 4e-7
 
 
 def _resolve_tau(tau):
@@ -89,6 +94,13 @@ class QFA(object):
         # use the factored-z input form when a batch carries it (DeviceDataloader batches, or zfac=...): same results to
         # float32 rounding, 4 Nb bytes per spectrum and pass less HBM traffic, three transcendentals per blue element less
         self.use_factored_z = True
+        # A plain zabs tensor (the reference's forward signature, no zfac attached) that comes back a SECOND time -- the same live
+        # tensor object, unchanged (torch's version counter) -- is tested once for the structure the reference's loader gives it,
+        # 1 + zabs[s][i] = (1 + z_qso[s]) wav_i / 1215.67 (QFA/dataloader.py:102; qfa_zabs_factor_f32, one pass over it and one
+        # host synchronisation), and from then on the factored-z kernels run for it.  A loader that hands out fresh tensors every
+        # step never pays anything; zabs that does not factor within AUTO_FACTOR_TOL keeps the zabs kernels.
+        self.auto_factor_zabs = AUTO_FACTOR_ZABS
+        self._zf_seen = {}
 
     # ------------------------------------------------------------------ parameters
     def random_init_func(self) -> None:
@@ -162,6 +174,9 @@ class QFA(object):
         DeviceDataloader attaches to the zabs tensors it builds; None = the kernels read zabs."""
         if zfac is None:
             zfac = getattr(zabs, "zfac", None)
+        if (zfac is None and zabs is not None and self.auto_factor_zabs and self.use_factored_z and self.Nb > 0
+                and self._tau_callable is None):
+            zfac = self._auto_zfac(zabs)
         if mask.dtype != torch.bool:
             raise _lib.QFAHipError(f"mask: dtype {mask.dtype}, expected torch.bool (reference model.py:124)")
         bs = _lib.Batch()
@@ -194,6 +209,33 @@ class QFA(object):
             keep.append(a)
             bs.A_blue = _lib.require_device_tensor(a, f32, "A_blue").value
         return bs, keep
+
+    def _auto_zfac(self, zabs):
+        """(zq1, pix_ratio) derived from a zabs tensor that was seen before and factors (see __init__), else None"""
+        if zabs.dtype != f32 or not zabs.is_contiguous() or zabs.dim() != 2 or zabs.shape[1] != self.Nb or zabs.shape[0] < 1 \
+                or zabs.device != self.device:
+            return None
+        sig = (zabs.data_ptr(), tuple(zabs.shape), zabs._version)
+        ent = self._zf_seen.get(id(zabs))
+        if ent is None or ent[0]() is not zabs or ent[1] != sig:
+            if len(self._zf_seen) >= 64:                                  # (dead or stale entries)
+                self._zf_seen = {k: e for k, e in self._zf_seen.items() if e[0]() is not None and e[0]()._version == e[1][2]}
+                if len(self._zf_seen) >= 64:
+                    self._zf_seen.clear()
+            self._zf_seen[id(zabs)] = (weakref.ref(zabs), sig, "seen")
+            return None
+        if ent[2] == "seen":
+            B = int(zabs.shape[0])
+            zq1 = torch.empty(B, dtype=f32, device=self.device)
+            ratio = torch.empty(self.Nb, dtype=f32, device=self.device)
+            nbad = torch.empty(1, dtype=torch.int32, device=self.device)
+            _lib.check(_lib.lib().qfa_zabs_factor_f32(C.c_void_p(zabs.data_ptr()), B, self.Nb, AUTO_FACTOR_TOL, C.c_void_p(zq1.data_ptr()),
+                                                      C.c_void_p(ratio.data_ptr()), C.c_void_p(nbad.data_ptr()),
+                                                      _lib.current_stream(self.device)), "qfa_zabs_factor_f32")
+            ok = int(nbad.item()) == 0                                    # (the one host synchronisation per repeated tensor)
+            ent = (ent[0], sig, (zq1, ratio) if ok else None)
+            self._zf_seen[id(zabs)] = ent
+        return ent[2]
 
     def _batch_struct_rows(self, rb, raw_flux=False):
         """qfa_batch_t of a ``ResidentBatch`` (qfa_amd/resident.py; ABI v3 rows / row_stride): pointers to the WHOLE resident
@@ -444,7 +486,9 @@ class QFA(object):
         n = len(dataloader)
         written = []
         for s in range(0, n, batch_size):
-            if hasattr(dataloader, "rows_batch") and self._tau_callable is None:     # rows of the resident arrays: no copy
+            # rows of the resident arrays, no copy (the resident form carries the factors, never zabs: with use_factored_z off or
+            # a custom tau the loader materialises the four tensors)
+            if hasattr(dataloader, "rows_batch") and self._tau_callable is None and (self.use_factored_z or self.Nb == 0):
                 rb, paths = dataloader.rows_batch(s, min(s + batch_size, n))
                 res = self.predict(batch=rb)
             elif hasattr(dataloader, "get_rows"):                # one launch for the whole slice
@@ -543,7 +587,7 @@ class QFA(object):
         # A loader that keeps the data set resident (DeviceDataloader.next_batch_rows) hands over row numbers instead of a
         # materialised copy of every batch (the reference rebuilds delta per batch on the host, dataloader.py:124-138, although
         # it depends on mu and tau only); a custom tau callable needs the materialised zabs
-        resident = hasattr(dataloader, "next_batch_rows") and self._tau_callable is None
+        resident = hasattr(dataloader, "next_batch_rows") and self._tau_callable is None and (self.use_factored_z or self.Nb == 0)
         sg = None
         if use_graph and not self._dp:
             sg = StepGraph(self, optimizer, dataloader.batch_size, resident=dataloader if resident else None,

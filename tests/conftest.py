@@ -12,6 +12,11 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A zabs tensor handed to the model twice is tested for the reference loader's structure and then served by the factored-z
+    # kernels (QFA.auto_factor_zabs).  The suites pass zabs tensors to exercise the ZABS kernels: off by default here,
+    # tests/test_hip_parity.py::test_auto_factored_zabs_* turn it on.
+    import qfa_amd.model as M
+    M.AUTO_FACTOR_ZABS = False
 
 
 def golden(name):

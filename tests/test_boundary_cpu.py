@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(h, s), s
     assert sorted(_lib.EXPORTS) == syms
-    assert _lib.lib().qfa_abi_version() == 3
+    assert _lib.lib().qfa_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_host_only_entry_points():

@@ -806,3 +806,98 @@ def test_sync_flag_returns_the_calls_own_status(dev):
     assert np.array_equal(a0.cpu().numpy(), a1.cpu().numpy(), equal_nan=True)
     pr = m.predict(*batch_t(b, dev, "flux"))
     assert all(np.isfinite(x.cpu().numpy()).all() for x in pr)
+
+
+@pytest.mark.parametrize("npix,nh,B,flags", [(1000, 12, 130, 0), (1913, 8, 300, 0), (640, 16, 700, _lib.F_PASS2_PIXRES), (450, 24, 70, 0)])
+def test_auto_factored_zabs_tensor_second_sighting(dev, npix, nh, B, flags):
+    """QFA.auto_factor_zabs (round 5): a plain zabs tensor -- the reference's forward signature, QFA/model.py:74 -- runs on the zabs
+    kernels the first time; the SAME live tensor, unchanged, is tested once (qfa_zabs_factor_f32) for the structure of
+    QFA/dataloader.py:102 and served by the factored-z kernels from then on: results as the two input forms of one batch agree
+    (sections 2e-5, NLL 5e-6), and the oracle on zabs.  An in-place write makes the tensor new again."""
+    import torch
+    from oracle import qfa_oracle as O
+    from qfa_amd import synthetic
+    from tools import parity_sections as PS
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=npix + 3 * nh)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=5 * npix + nh)
+    m = make_model(dev, p, mu)
+    m.flags, m.deterministic, m.auto_factor_zabs = flags, True, True
+    bt = batch_t(b, dev)
+    nll1, nll2 = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    acc1 = m.accumulate(*bt, nll=nll1).clone()
+    ent = m._zf_seen[id(bt[2])]
+    assert ent[2] == "seen"                                          # first sighting: the zabs kernels ran
+    m.auto_factor_zabs = False
+    assert torch.equal(acc1, m.accumulate(*bt).clone())              # ... bit for bit what the switch-off gives
+    m.auto_factor_zabs = True
+    acc2 = m.accumulate(*bt, nll=nll2).clone()
+    ent = m._zf_seen[id(bt[2])]
+    assert isinstance(ent[2], tuple), "a batch of the reference loader's structure must factor"
+    zq1, ratio = ent[2]
+    # (the split of the scale between the two factors is free: here pix_ratio[0] = 1 and zq1 = 1 + zabs[:, 0])
+    assert torch.allclose(zq1.double()[:, None] * ratio.double()[None, :], 1.0 + bt[2].double(), rtol=4e-7, atol=0)
+    assert torch.allclose(nll1, nll2, rtol=5e-6, atol=0)
+    assert not torch.equal(acc1, acc2)                               # (the other kernels did run)
+    for name, sl in PS.sections(m).items():
+        a, r = acc2[sl].double().cpu().numpy(), acc1[sl].double().cpu().numpy()
+        if name in ("cnt", "n_blue", "n_spectra"):
+            assert np.array_equal(a, r), name
+        elif a.size == 1:
+            assert abs(a[0] - r[0]) <= 2e-4 * abs(r[0]) + 1e-6, (name, a, r)
+        else:
+            assert rel_l2(a, r) < 2e-5, (name, rel_l2(a, r))
+    loss, g = m._finalize(acc2, True)
+    ol, og = O.forward(p, b["delta"], b["error"], b["zabs"], b["mask"])
+    assert abs(loss.item() - ol) <= TOL_NLL * abs(ol)
+    for k in KEYS:
+        ok = ~np.isnan(np.asarray(og[k], dtype=np.float64))
+        assert rel_l2(g[k].cpu().numpy()[ok], np.asarray(og[k])[ok]) < TOL_G[k], k
+    # the same decision serves predict (same tensor object), and a third call costs no check
+    ft = batch_t(b, dev, "flux")
+    pz = [x.cpu().numpy() for x in m.predict(ft[0], ft[1], bt[2], ft[3])]
+    m.auto_factor_zabs = False
+    pr = [x.cpu().numpy() for x in m.predict(ft[0], ft[1], bt[2], ft[3])]
+    m.auto_factor_zabs = True
+    for a, r, tol in zip(pz, pr, (5e-6, 2e-5, 2e-5, 2e-6, 5e-6)):
+        assert np.max(np.abs(a - r)) <= tol * np.max(np.abs(r)), tol
+    # an in-place write: torch's version counter moves, the tensor is new again (zabs kernels, bit for bit)
+    bt[2].mul_(1.0)
+    acc3 = m.accumulate(*bt).clone()
+    assert m._zf_seen[id(bt[2])][2] == "seen" and torch.equal(acc3, acc1)
+
+
+def test_auto_factored_zabs_refuses_what_does_not_factor(dev):
+    """zabs with ONE element moved by 2e-6 (five float32 ulp of 1 + z) does not factor: the zabs kernels keep serving it, bit for
+    bit; the C-ABI counts exactly the elements that were moved, and a NaN"""
+    import ctypes as C
+    import torch
+    from qfa_amd import synthetic
+    npix, nh, B = 640, 12, 90
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=9)
+    b = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=10)
+    b["zabs"] = b["zabs"].copy()
+    b["zabs"][37, 101] = (1.0 + b["zabs"][37, 101]) * (1.0 + 2e-6) - 1.0
+    m = make_model(dev, p, mu)
+    m.deterministic = True
+    bt = batch_t(b, dev)
+    ref = m.accumulate(*bt).clone()                                   # (conftest: auto_factor_zabs off)
+    m.auto_factor_zabs = True
+    a1 = m.accumulate(*bt).clone()
+    a2 = m.accumulate(*bt).clone()
+    a3 = m.accumulate(*bt).clone()
+    assert m._zf_seen[id(bt[2])][2] is None
+    assert torch.equal(a1, ref) and torch.equal(a2, ref) and torch.equal(a3, ref)
+    # the entry point itself
+    z = bt[2].clone()
+    z[5, 7] = float("nan")
+    z[80, 0] *= 1.00001                                              # column 0 defines zq1[80]: every other element of the row is off
+    zq1, ratio = torch.empty(B, device=dev), torch.empty(nb, device=dev)
+    nbad = torch.full((1,), 12345, dtype=torch.int32, device=dev)
+    rc = _lib.lib().qfa_zabs_factor_f32(C.c_void_p(z.data_ptr()), B, nb, 4e-7, C.c_void_p(zq1.data_ptr()), C.c_void_p(ratio.data_ptr()),
+                                        C.c_void_p(nbad.data_ptr()), _lib.current_stream(dev))
+    assert rc == 0
+    assert int(nbad.item()) == 1 + 1 + (nb - 1)
+    assert _lib.lib().qfa_zabs_factor_f32(None, B, nb, 4e-7, C.c_void_p(zq1.data_ptr()), C.c_void_p(ratio.data_ptr()),
+                                          C.c_void_p(nbad.data_ptr()), _lib.current_stream(dev)) == -1

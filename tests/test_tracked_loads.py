@@ -21,14 +21,9 @@ TRACKED = os.path.join(REPO, "qfa_amd", "libqfa_tracked.so")
 
 
 def run(lib, out, npix, nh, B, form="zabs", pixres=False):
-    env = dict(os.environ)
-    if lib:
-        env["QFA_HIP_LIB"] = lib
-    else:
-        env.pop("QFA_HIP_LIB", None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "dump_hot_path.py"), out, str(npix), str(nh), str(B),
-                        "deterministic"] + (["zfac"] if form == "zfac" else []) + (["pixres"] if pixres else []), env=env,
-                       capture_output=True, text=True,
+                        "deterministic"] + (["zfac"] if form == "zfac" else []) + (["pixres"] if pixres else [])
+                       + ([f"lib={lib}"] if lib else []), capture_output=True, text=True,
                        timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(out)

@@ -1,10 +1,9 @@
 #!/bin/bash
-# GPU box: pass-2 time of library variants (tools/build_gx_variant.sh), zabs form and factored-z form, back to back on one box.
-# usage: tools/ab_pass2.sh <variant> ...   ("default" = the shipped library; "r3" etc. = qfa_amd/libqfa_<variant>.so, an older
-# ABI is let through by QFA_HIP_ALLOW_ABI)
+# GPU box: pass-2 time of library variants (tools/build_gt_variant.sh etc.), zabs form and factored-z form, back to back on one box.
+# usage: tools/ab_pass2.sh <variant> ...   ("default" = the shipped library; else qfa_amd/libqfa_<variant>.so, same ABI)
 for v in "$@"; do
-  if [ "$v" != "default" ]; then export QFA_HIP_LIB="$PWD/qfa_amd/libqfa_$v.so" QFA_HIP_ALLOW_ABI=2; else unset QFA_HIP_LIB QFA_HIP_ALLOW_ABI; fi
-  timeout -k 10 120 python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-predict --no-epoch --sustain 0 ${BENCH_ARGS} > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { echo "$v failed"; tail -3 gpurun_out/ab_$v.err; continue; }
+  if [ "$v" != "default" ]; then L="qfa_amd/libqfa_$v.so"; else L="qfa_amd/libqfa_hip.so"; fi
+  timeout -k 10 120 python tools/with_lib.py $L bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-predict --no-epoch --sustain 0 ${BENCH_ARGS} > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { echo "$v failed"; tail -3 gpurun_out/ab_$v.err; continue; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$v.json"))

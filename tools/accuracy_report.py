@@ -68,7 +68,7 @@ def full(npix, nh, B, masks, seed, n_oracle):
 from tests.conftest import GOLDEN
 p, mu = O.load_params_npz(os.path.join(GOLDEN, "model_parameters.npz"))
 wav, nb, nr = synthetic.wavelength_grid()
-print("lib:", os.environ.get("QFA_HIP_LIB", "default"))
+from qfa_amd import _lib as _L; print("lib:", _L.LIB_PATH)
 case("sdss (1913, 8) B=8 (G4: red-only spectrum + dead range)", p, mu, wav, nb, 8, 20220704, red_only=(3,), dead_range=(900, 910))
 case("sdss (1913, 8) B=64", p, mu, wav, nb, 64, 1)
 for npix, nh, seed, B in ((2000, 8, 2, 24), (4000, 16, 3, 24), (8000, 32, 5, 12), (640, 16, 13, 24)):

@@ -1,8 +1,8 @@
 """Run the hot path once on seeded synthetic input and dump every output to an .npz (GPU box only).
 
-    python tools/dump_hot_path.py OUT.npz NPIX NH B [deterministic] [zfac] [pixres]
+    python tools/dump_hot_path.py OUT.npz NPIX NH B [deterministic] [zfac] [pixres] [lib=PATH]
 
-Used by tests/test_tracked_loads.py to compare two builds of the library (QFA_HIP_LIB selects the one this process
+Used by tests/test_tracked_loads.py to compare two builds of the library (lib=PATH selects the one this process
 loads) bit for bit: the packed accumulation buffer, the per-spectrum NLL and the five prediction outputs.
 """
 import sys
@@ -10,7 +10,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from qfa_amd import QFA, synthetic   # noqa: E402
+from qfa_amd import QFA, synthetic, _lib   # noqa: E402
+for a in sys.argv[5:]:
+    if a.startswith("lib="):
+        _lib.LIB_PATH = a[4:]
 
 out, npix, nh, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 det = "deterministic" in sys.argv[5:]
@@ -24,7 +27,6 @@ m = QFA(nb, nr, nh, dev, model_params=p)
 m.mu = T(mu)
 m.deterministic = det
 if "pixres" in sys.argv[5:]:              # N_h = 9..16: the pixel-resident form of pass 2 (k_grads_t)
-    from qfa_amd import _lib
     m.flags = _lib.F_PASS2_PIXRES
 nll = torch.empty(B, device=dev)
 zfac = (T(1.0 + b["zqso"].astype(np.float64)).float(), T((wav[:nb] / synthetic.LYA).astype(np.float32))) if zf else None

@@ -13,7 +13,7 @@ for line in open(summary):
         targs = [a.strip() for a in name[name.find("<") + 1:name.rfind(">")].split(",")] if "<" in name else []
         # the factored-z instantiations are kept apart: template argument ZF = the last one of k_grads_x<KP, HASA, TERMS, ZF> and
         # k_moments_x<KP, PREDICT, NW, ZF>, the third of k_grads_t<KP, HASA, ZF, IDX>
-        zf = (cur in ("k_grads_x", "k_moments_x") and targs and targs[-1] == "true") or (cur == "k_grads_t" and len(targs) >= 3 and targs[2] == "true")
+        zf = (cur in ("k_grads_x", "k_moments_x") and targs and targs[-1] == "true") or (cur in ("k_grads_t", "k_s12_x", "k_grads") and len(targs) >= 3 and targs[2] == "true")
         if zf:
             cur += "_zfac"
         if cur == "k_moments_x" and ", true, 4" in name:      # the prediction instantiation of pass 1
@@ -41,5 +41,15 @@ for k in ("k_grads", "k_grads_x", "k_grads_t", "k_moments", "k_solve", "k_grads_
         res[k + "_hbm_bytes_per_launch"] = 2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
         res[k + "_read_bytes_rdreq128"] = v.get("TCC_EA0_RDREQ_128B", 0) * 128 + v.get("TCC_EA0_RDREQ_64B", 0) * 64
         res[k + "_write_bytes"] = v["WRITE_SIZE"] * 1024
+# N_h = 17..32: pass 2 is three launches (k_s12_x, then k_grads_s3 once per 16 output columns: its mean per launch counts twice);
+# bench.py names the sum "k_s12_x+2*k_grads_s3"
+for zs in ("", "_zfac"):
+    a, b = vals.get("k_s12_x" + zs, {}), vals.get("k_grads_s3", {})
+    if "FETCH_SIZE" in a and "WRITE_SIZE" in a and "FETCH_SIZE" in b and "WRITE_SIZE" in b:
+        res["k_s12_x+2*k_grads_s3" + zs + "_hbm_bytes_per_launch"] = (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"] + 2 * (2 * b["FETCH_SIZE"] + b["WRITE_SIZE"])) * 1024
+for k in ("k_predict_x", "k_predict_x32", "k_moments_x_predict", "k_zfactor_check"):
+    v = vals.get(k, {})
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        res[k + "_hbm_bytes_per_launch"] = 2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

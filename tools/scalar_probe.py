@@ -1,6 +1,6 @@
 """GPU box: errors of the three scalar gradients (sums of strongly cancelling per-pixel terms) against the float64 oracle
 on the golden batches G4 / G5 and two mock shapes, next to the reference's own float32 result (golden files) and the
-float32 numpy oracle; also error / sum|terms| (the condition-number-free figure).  QFA_HIP_LIB selects a library variant."""
+float32 numpy oracle; also error / sum|terms| (the condition-number-free figure).  run through tools/with_lib.py for a library variant."""
 import os, sys
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,7 +41,7 @@ def run(name, p, mu, wav, nb, B, seed, gold=None, flags=0, **kw):
     print(name + "\n   " + "\n   ".join(out), flush=True)
 p, mu = O.load_params_npz(os.path.join(GOLDEN, "model_parameters.npz"))
 wav, nb, nr = synthetic.wavelength_grid()
-print("lib:", os.environ.get("QFA_HIP_LIB", "default"))
+from qfa_amd import _lib as _L; print("lib:", _L.LIB_PATH)
 g4 = np.load(os.path.join(GOLDEN, "g4_forward.npz")); g5 = np.load(os.path.join(GOLDEN, "g5_step.npz"))
 for fl in (0, 2):
     print("flags", fl)
