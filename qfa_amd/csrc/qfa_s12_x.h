@@ -507,6 +507,9 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
 // array behind the second half (128 contiguous bytes per row and wave instruction), eight requests per tile.
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) s12_pair { float v[2]; };       // 4-byte aligned 8-byte store
+typedef float s12_v2 __attribute__((ext_vector_type(2), aligned(4)));
+// (non-temporal, like k_predict_x's: the prediction outputs are not read back by the call)
+__device__ __forceinline__ void s12_store2(float *dst, float a, float b) { __builtin_nontemporal_store(s12_v2{a, b}, reinterpret_cast<s12_v2 *>(dst)); }
 template <int KP>
 __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int ntiles, WorkPlan wp,
                                                         const unsigned char *__restrict__ IMG,
@@ -639,8 +642,8 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const size_t o = (size_t)(s0 + 4 * g + r) * Npix + px;
-                                *reinterpret_cast<s12_pair *>(cont + o) = s12_pair{{co0[r], afy[r] + muH}};
-                                *reinterpret_cast<s12_pair *>(unc + o) = s12_pair{{un0[r], __builtin_amdgcn_sqrtf(aq[r])}};
+                                s12_store2(cont + o, co0[r], afy[r] + muH);
+                                s12_store2(unc + o, un0[r], __builtin_amdgcn_sqrtf(aq[r]));
                             }
                             rest = 8;
                         } else {
