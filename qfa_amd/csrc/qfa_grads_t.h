@@ -615,6 +615,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                     aop[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(sp + (ks + 1) * 3072 + pc * 1024);
             }
             piece(pt, ks);
+            if (ks == GT::NKS - 1) piece(pt, GT::NKS);             // (a seventh site: the Z part of the waves 4..7 rides here, QFA_GT_ZS1)
             const u32x4 &ah = aop[ks & 1][0], &am = aop[ks & 1][1], &al = aop[ks & 1][2];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
@@ -929,11 +930,24 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                 step_barrier();
                 GTS(1)
                 const Part pz{zsrc, zdst, t + 1 < n ? z_req : 0}, ps{ssrc, sdst, t + 2 < n ? s1_req : 0};
-                stage2(t, pz);
-                GTS(3)
-                stage3(t, ps);
-                GTS(4)
-                if (t + 1 < n) stage1(t + 1, none);
+#ifndef QFA_GT_ZS1
+#define QFA_GT_ZS1 1       // waves 4..7: the Z part's pieces between the MFMAs of stage 1 instead of between the elements of stage 2
+#endif
+                // (a piece issued in stage 2 -- VALU work, nothing to hide behind -- cost the issuing wave ~100 cycles: stage 2 of a RED
+                // duty wave, one reciprocal per element, took 1 134 cycles with its seven pieces; between MFMAs they are free)
+                if (QFA_GT_ZS1) {
+                    stage2(t, none);
+                    GTS(3)
+                    stage3(t, ps);
+                    GTS(4)
+                    if (t + 1 < n) stage1(t + 1, pz);
+                } else {
+                    stage2(t, pz);
+                    GTS(3)
+                    stage3(t, ps);
+                    GTS(4)
+                    if (t + 1 < n) stage1(t + 1, none);
+                }
                 next();
             }
         }

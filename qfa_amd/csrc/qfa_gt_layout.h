@@ -38,7 +38,7 @@ struct GTT {
     static constexpr int PXW = 16 * TPW;
     // a part moves as 1-KiB pieces, contiguous runs of them per wave (k_grads_t decides which waves)
     static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34 (KP = 8: 9, 10)
-    static_assert((Z_PCS + 4) / 5 <= 7 && (S1_PCS + 4) / 5 <= 6, "pieces per wave and stage: 7 slots in stage 2, 8 in stage 3, 6 in stage 1");
+    static_assert((Z_PCS + 4) / 5 <= 7 && (S1_PCS + 4) / 5 <= 6, "pieces per wave and stage: 7 slots in stage 2, 7+ in stage 3, NKS + 1 = 7 in stage 1 (4 at KP = 8)");
     // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
     // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
     // (TPW = 2: [16 slots][32 px] float x 3, mask bytes as two halves [2][16 slots][16])
