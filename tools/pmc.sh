@@ -14,4 +14,5 @@ for set in "$@"; do
 done
 cd $R
 python3 tools/pmc_agg.py gpurun_out/pmc_${tag}_ > gpurun_out/pmc_${tag}_summary.txt
+rm -rf gpurun_out/pmc_${tag}_[0-9]*          # (raw counter dumps: the summary is what profiles/ keeps)
 cat gpurun_out/pmc_${tag}_summary.txt

@@ -9,6 +9,7 @@ f=$(find $d -name "*kernel_stats.csv" | head -1)
 (head -1 $f; grep -E '"(void )?k_' $f) > $R/gpurun_out/${tag}_${cfg}_kernel_stats.csv
 cd $R
 python3 tools/launch_durations.py $d $d.json > gpurun_out/${tag}_${cfg}_kernel_launches.txt
+rm -rf $d          # (the raw trace: tens of MB per config; gpurun copies back at most 64 MiB)
 tools/pmc.sh ${tag}${cfg} $cfg "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_EA0_ATOMIC" "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B" "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_HIT TCC_MISS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" > /dev/null
 cp gpurun_out/pmc_${tag}${cfg}_summary.txt gpurun_out/${tag}_${cfg}_pmc_summary.txt
 cat gpurun_out/${tag}_${cfg}_kernel_stats.csv | cut -c1-150
