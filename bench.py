@@ -298,8 +298,10 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=5)
+    # (defaults: 40 untimed steps -- ~0.15 s at c3 -- let the clocks settle; the first steps after the data generation ran 1-5 %
+    # slower than the >= 3 s sustained leg of the same kernels in round 5's runs with 5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
                     help="default: c3 (100 000 spectra per GPU); with --gpus 8: c4 (BASELINE configs[3]: 1M spectra over 8 GPUs)")
     ap.add_argument("--batch", type=int, default=0, help="spectra per GPU (default: the config's)")

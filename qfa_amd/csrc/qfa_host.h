@@ -155,11 +155,8 @@ Layout make_layout_t(int B, int Npix) {
     // 20 000 spectra came out 3.6e-4 from the oracle.  So at N_h = 17..32 no chain is longer than QFA_P1_MAX_CHAIN tiles (the
     // partial records are 4.5 KB per spectrum and segment: 90 MB per segment at c5, against 1.7 ms of pass 1).
 #ifndef QFA_P1_MAX_CHAIN16
-#define QFA_P1_MAX_CHAIN16 0   // experiment (round 5): the same bound at N_h <= 16; 0 = chains of the whole pixel axis.  Measured on 24 613
-                               // spectra of c3's shape against the float64 oracle: F gradient 3.2e-5 whole, 7.4e-5 in two segments of 63
-                               // tiles, 4.2e-5 in four of 32 (loss 1.8e-7 / 3.5e-7 / 1.8e-7), pass 1 + 4 % -- on the red side T and C are the
-                               // SAME accumulators while a chain is whole (T starts as a copy of C), so their rounding errors cancel in the
-                               // gradient's differences; two partial records summed in float32 round T and C independently.  Not shipped.
+#define QFA_P1_MAX_CHAIN16 0   // experiment (round 5): the same bound at N_h <= 16; 0 = the work plan's own segmentation.  Superseded by
+                               // the fresh accumulators per tile of k_moments_x (QFA_P1_FRESH): profiles/r5_ablation.txt, section 2
 #endif
     L.wp1 = KP <= 16 ? (QFA_P1_NW == 8 ? plan_work(B, L.ntiles32, 1, NCU, 128) : plan_work(B, L.ntiles32, 1, 2 * NCU, 64, QFA_P1_MAX_CHAIN16))
                      : plan_work(B, L.ntiles32, 1, NCU, 64, QFA_P1_MAX_CHAIN);

@@ -316,6 +316,23 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
     c = xdl(ah, bm, c);
     return xdl(ah, bh, c);
 }
+// Fresh accumulators per tile (round 5).  v_mfma_f32_16x16x32_bf16 aligns its 32 products with the accumulator and truncates what
+// lies ~2 bits below its last place: a BIAS per instruction of ~2^-26 of the accumulator.  C, T, b, b2 of a spectrum used to run
+// through ONE accumulator chain over the whole pixel axis -- 125 tiles x 6 products = 750 instructions at c3 -- and the bias added
+// up to ~4e-6 of the sums: the F gradient of the bench's 100 000 spectra came out 1.9e-4 from the float64 oracle (cancellation 47x),
+// 3.2e-5 when the SAME spectra ran in launches small enough for the work plan to cut the pixel axis into 25-tile segments
+// (tools/c3_100k_vs_oracle.py, tools/sections_vs_chunks.py).  Now the six products of a tile start from C = 0 and their sum joins
+// the running sum by a float32 VALU add (round to nearest, no bias): the chain is six instructions long whatever N_pix is.
+// (N_h = 17..32 keeps its chains, cut at QFA_P1_MAX_CHAIN tiles by the work plan: its accumulators live in the AGPR half of the
+// file and the extra moves collide with the register prefetches.)
+#ifndef QFA_P1_FRESH
+#define QFA_P1_FRESH 1
+#endif
+__device__ __forceinline__ void acc_add(f32x4 &acc, const f32x4 &t) {
+    typedef float f32x2p __attribute__((ext_vector_type(2)));            // two v_pk_add_f32 instead of four v_add_f32
+    const f32x2p lo = f32x2p{acc[0], acc[1]} + f32x2p{t[0], t[1]}, hi = f32x2p{acc[2], acc[3]} + f32x2p{t[2], t[3]};
+    acc = f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
 #ifndef QFA_P1_SKIPT_KP
 #define QFA_P1_SKIPT_KP 16     // prediction leaves out the T-side moments from this KP on (8: measured equal to 2.5 % slower, with or without an occupancy cap)
 #endif
@@ -326,7 +343,11 @@ __device__ __forceinline__ f32x4 xdl_ct(const u32x4 &ah, const u32x4 &am, const 
 #define QFA_P1_PIPE_RED 1      // groups requested ahead on a red tile (a group = two column tiles, 12 MFMAs) ...
 #endif
 #ifndef QFA_P1_PIPE_BLUE
-#define QFA_P1_PIPE_BLUE 2     // ... and on a blue tile (a group = one column tile, 12 MFMAs)
+#define QFA_P1_PIPE_BLUE 1     // ... and on a blue tile (a group = one column tile, 12 MFMAs); 2 before the fresh accumulators of round 5
+                               // took eight registers
+#endif
+#ifndef QFA_P1_PIPE_BLUE_ZABS
+#define QFA_P1_PIPE_BLUE_ZABS 0
 #endif
 #ifndef QFA_P1_MULMASK
 #define QFA_P1_MULMASK 1       // pass 1: the pixel mask as a float factor instead of selects / exec-mask branches (weights())
@@ -654,16 +675,28 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             for (int t = 0; t < C::NFT; ++t) {
                 if (t >= CT0 && t < CTE) {
                     const u32x4 bh = rdB(0, t), bm = rdB(1, t), bl = rdB(2, t);
+                    if (QFA_P1_FRESH && KP <= 16) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        acc_add(accb[t], xdl6(w.w3h, w.w3m, w.w3l, bh, bm, bl, z));
+                        if (TSIDE) acc_add(accb2[t], xdl6(w.w4h, w.w4m, w.w4l, bh, bm, bl, z));
+                    } else {
                     accb[t] = xdl6(w.w3h, w.w3m, w.w3l, bh, bm, bl, accb[t]);
                     if (TSIDE) accb2[t] = xdl6(w.w4h, w.w4m, w.w4l, bh, bm, bl, accb2[t]);
+                    }
                 }
             }
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 if (C::NFT + t >= CT0 && C::NFT + t < CTE) {
                     const u32x4 bh = rdB(0, C::NFT + t), bm = rdB(1, C::NFT + t), bl = rdB(2, C::NFT + t);
+                    if (QFA_P1_FRESH && KP <= 16) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        acc_add(accC[t], xdl_ct(w.w1h, w.w1m, w.w1l, bh, bm, bl, z));
+                        if (TSIDE) acc_add(accT[t], xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, z));
+                    } else {
                     accC[t] = xdl_ct(w.w1h, w.w1m, w.w1l, bh, bm, bl, accC[t]);
                     if (TSIDE) accT[t] = xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
+                    }
                 }
             }
         };
@@ -678,7 +711,9 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             // column tiles in groups of GS whose MFMA chains alternate (a chain of six on one accumulator issues every
             // ~19 cycles, two alternating chains every 16): red tiles pair two column tiles, blue tiles the C-side and
             // the T-side chain of one; PFG groups are requested ahead
-            constexpr int NCT = X::NCT, PS = X::pstr(0), GS = TSIDE ? 1 : 2, PFG = TSIDE ? QFA_P1_PIPE_BLUE : QFA_P1_PIPE_RED;
+            // (the zabs instantiation -- two more spectra registers sets of 8 -- requests its blue operands one group later: it has no
+            // registers for the two fresh accumulators otherwise)
+            constexpr int NCT = X::NCT, PS = X::pstr(0), GS = TSIDE ? 1 : 2, PFG = TSIDE ? (ZF ? QFA_P1_PIPE_BLUE : QFA_P1_PIPE_BLUE_ZABS) : QFA_P1_PIPE_RED;
             constexpr int D = GS * (PFG + 1), NG = (NCT + GS - 1) / GS;
             constexpr int NR = (X::NCHUNK + NW - 1) / NW;                        // DMA requests per wave
             constexpr int RPG = (NR + NG - 2) / (NG - 1);                        // ... per group
@@ -693,6 +728,9 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 return t < C::NFT ? (second ? accb2[t] : accb[t]) : (second ? accT[t - C::NFT] : accC[t - C::NFT]);
             };
             // six_terms' order, two chains alternating
+            // (QFA_P1_FRESH: c0 / c1 are the group's two FRESH accumulators tm0 / tm1; their sums join the running sums behind the
+            // group's requests -- by then the MFMAs have delivered -- see the loop below)
+            f32x4 tm0 = {0.f, 0.f, 0.f, 0.f}, tm1 = {0.f, 0.f, 0.f, 0.f};
             auto six2 = [&](const u32x4 &ah, const u32x4 &am, const u32x4 &al, int q0, f32x4 &c0, const u32x4 &eh,
                             const u32x4 &em, const u32x4 &el, int q1, f32x4 &c1) __attribute__((always_inline)) {
                 c0 = xdl(ah, bl[q0], c0); c1 = xdl(eh, bl[q1], c1);
@@ -713,15 +751,19 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                     if (GS * (gi + PFG) + j < NCT) rd(GS * (gi + PFG) + j);
                 __builtin_amdgcn_sched_barrier(0);
                 const int t = GS * gi;
+                // the group's two accumulators: (C side, T side) of column tile t on a blue tile, column tiles t and t + 1 on a red one
+                f32x4 &ga0 = acc_of(t, false), &ga1 = TSIDE ? acc_of(t, true) : acc_of(t + 1 < NCT ? t + 1 : t, false);
+                const bool two = TSIDE || t + 1 < NCT;
+                if (QFA_P1_FRESH) tm0 = tm1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 &c0 = QFA_P1_FRESH ? tm0 : ga0, &c1 = QFA_P1_FRESH ? tm1 : ga1;
                 if (TSIDE) {
-                    if (t < C::NFT) six2(w.w3h, w.w3m, w.w3l, t % D, acc_of(t, false), w.w4h, w.w4m, w.w4l, t % D, acc_of(t, true));
-                    else six2(w.w1h, w.w1m, w.w1l, t % D, acc_of(t, false), w.w2h, w.w2m, w.w2l, t % D, acc_of(t, true));
+                    if (t < C::NFT) six2(w.w3h, w.w3m, w.w3l, t % D, c0, w.w4h, w.w4m, w.w4l, t % D, c1);
+                    else six2(w.w1h, w.w1m, w.w1l, t % D, c0, w.w2h, w.w2m, w.w2l, t % D, c1);
                 } else if (t + 1 < NCT) {
                     const bool f0 = t < C::NFT, f1 = t + 1 < C::NFT;
-                    six2(f0 ? w.w3h : w.w1h, f0 ? w.w3m : w.w1m, f0 ? w.w3l : w.w1l, t % D, acc_of(t, false),
-                         f1 ? w.w3h : w.w1h, f1 ? w.w3m : w.w1m, f1 ? w.w3l : w.w1l, (t + 1) % D, acc_of(t + 1, false));
+                    six2(f0 ? w.w3h : w.w1h, f0 ? w.w3m : w.w1m, f0 ? w.w3l : w.w1l, t % D, c0,
+                         f1 ? w.w3h : w.w1h, f1 ? w.w3m : w.w1m, f1 ? w.w3l : w.w1l, (t + 1) % D, c1);
                 } else {
-                    f32x4 &c0 = acc_of(t, false);
                     c0 = t < C::NFT ? xdl6(w.w3h, w.w3m, w.w3l, bh[t % D], bm[t % D], bl[t % D], c0)
                                     : xdl6(w.w1h, w.w1m, w.w1l, bh[t % D], bm[t % D], bl[t % D], c0);
                 }
@@ -739,6 +781,10 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 if (!spec_done && (gi + 1) * RPG >= NR) {
                     spec_done = true;
                     if (reload) load_spec(tg_spec, cur);
+                }
+                if (QFA_P1_FRESH) {
+                    acc_add(ga0, tm0);
+                    if (two) acc_add(ga1, tm1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

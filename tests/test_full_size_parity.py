@@ -79,3 +79,41 @@ def test_config5_shape_20000(dev):
     """BASELINE configs[4] shape (8000 px, N_h = 32) at the 20 000 spectra per GPU bench.py --config c5 times; oracle on 192
     of them (float64 numpy at 8000 x 32 runs ~10 spectra/s)."""
     run_config(dev, 8000, 32, 20000, True, 20220705, 192)      # (round 4: six piece products in stage 3 at N_h = 17..32 too: F 1e-4)
+
+
+def test_config3_100k_one_launch_vs_float64_oracle(dev, tmp_path):
+    """until round 5 the float64 oracle met the bench's kernels at 24 613 spectra at most.  Here ONE launch over
+    the bench's whole c3 batch (100 000 x 4000, N_h = 16, masks; the automatic k_grads_t dispatch) against the oracle summed over the
+    same 100 000 spectra on the host cores (tools/oracle_pool.py, ~40 s).  The normalised F gradient cancels 47x at this size (the data
+    are drawn from the model: the expected gradient is zero): with pass 1's moments in ONE MFMA accumulator chain over the pixel axis it
+    came out 1.9e-4 from the oracle (4.1e-6 of the cancelling sums); with the fresh accumulators per tile of round 5
+    (qfa_xdl_kernels.h, QFA_P1_FRESH) 6.4e-5 (1.4e-6).  Both input forms."""
+    import torch
+    from qfa_amd import QFA, synthetic
+    from tools import oracle_pool
+    npix, nh, B = 4000, 16, 100000
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=20220700)
+    parts = [synthetic.make_batch_torch(p, mu, wav, nb, 25000, 20220703 + 17 * i, dev, masks=True, return_zq=True) for i in range(4)]
+    batch = tuple(torch.cat([q[j] for q in parts]) for j in range(4))
+    zfac = ((1.0 + torch.cat([q[4] for q in parts])).contiguous(), torch.tensor((wav[:nb] / synthetic.LYA).astype(np.float32), device=dev))
+    del parts
+    host = {k: x.cpu().numpy() for k, x in zip(("delta", "error", "zabs", "mask"), batch)}
+    ol, og, sums, counts = oracle_pool.oracle_sums(p, host, str(tmp_path / "oracle"))
+    del host
+    for name, zf in (("zabs", None), ("factored", zfac)):
+        m = QFA(nb, nr, nh, dev, model_params=p)
+        m.mu = torch.tensor(mu, device=dev)
+        acc = m.accumulate(batch[0], batch[1], batch[2] if zf is None else None, batch[3], zfac=zf).clone()
+        loss, g = m._finalize(acc, True)
+        e = {}
+        for k in ("F", "Psi", "omega"):
+            ref = np.asarray(og[k], dtype=np.float64)
+            ok = ~np.isnan(ref)
+            e[k] = float(np.linalg.norm(g[k].cpu().numpy().astype(np.float64)[ok] - ref[ok]) / np.linalg.norm(ref[ok]))
+        e["loss"] = abs(loss.item() - ol) / abs(ol)
+        print("100 000 x 4000, N_h = 16, one launch vs float64 oracle:", name, e)
+        # achieved: F 6.4e-5, Psi 6.3e-6, omega 1.3e-5, loss 1.9e-7
+        assert e["F"] < 1e-4 and e["Psi"] < 2e-5 and e["omega"] < 2e-5 and e["loss"] < 2e-6, (name, e)
+    del batch
+    torch.cuda.empty_cache()
