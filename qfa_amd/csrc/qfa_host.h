@@ -45,7 +45,10 @@ namespace {
 #endif
 
 #ifndef QFA_P1_MAX_CHAIN
-#define QFA_P1_MAX_CHAIN 64  // longest accumulation chain of pass 1 at N_h = 17..32, in 32-pixel tiles (make_layout_t)
+#define QFA_P1_MAX_CHAIN 32  // longest accumulation chain of pass 1 at N_h = 17..32, in 32-pixel tiles (make_layout_t).  Round 5: 64 -> 32 --
+                             // F gradient of 4 096 c5-shape spectra against the float64 oracle 8.2e-5 -> 4.5e-5 (the chain bias of
+                             // qfa_xdl_kernels.h, QFA_P1_FRESH: N_h <= 16 has fresh accumulators instead), c5 step 5.32 -> 5.41 ms
+                             // (eight partial records per spectrum instead of four: k_sum_segments + 0.08 ms)
 #endif
 
 inline int kp_for(int Nh) { return Nh <= 8 ? 8 : (Nh <= 16 ? 16 : 32); }

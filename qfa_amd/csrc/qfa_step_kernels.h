@@ -533,8 +533,9 @@ __global__ __launch_bounds__(256, KP > 16 ? 1 : (KP == 8 ? QFA_G8_OCC : 2)) void
     //   ALL 16 spectra as bf16 pieces h, m (registers) and l (LDS); beta is applied to G_s on the VALU.
     constexpr int NZR = XS3 ? 1 : 4, NZA = XS3 ? 1 : KP, NZS = XS3 ? 16 : 1;
     float Zr[NZR][NZA], pr[4];
-    // (KP = 32: K = a = 32 per MFMA, 8 values per lane and piece, the two leading pieces only -- four products,
-    // <= 2^-17 each (the template argument TERMS of k_grads_s3; QFA_F_S3_FAST issues three): the third piece would take 16 KB of LDS per wave)
+    // (KP = 32, THIS kernel's own stage 3 -- the build-time fallback form QFA_P2_S12=0, not k_grads_s3, which issues six products
+    // from round 4 on: K = a = 32 per MFMA, 8 values per lane and piece, the two leading pieces only -- four products, <= 2^-17
+    // each; the third piece would take 16 KB of LDS per wave)
     using ZV = std::conditional_t<KP == 32, u32x4, u32x2>;
     constexpr int NZJ = KP == 32 ? 8 : 4;              // values of Z per lane and spectrum
     ZV Zh[NZS], Zm[NZS];

@@ -160,8 +160,8 @@ def test_headline_shape_24613_spectra_normalised_gradients_vs_float64_oracle(dev
     print("24613 x 4000, N_h = 16 vs float64 oracle:", out)
     six = out["six"]
     assert six["loss"] < 2e-6
-    # achieved: six F 2.3e-5 (1.1e-6 of the cancelling sums, which are 21x the gradient); round 2's three-product form (no
-    # longer in the shipped library) was at 5.5e-5 (2.6e-6): at this batch size the narrow product IS visible
+    # achieved (round 5, fresh accumulators per tile in pass 1): F 1.6e-5 (6.7e-7 of the cancelling sums, which are 24x the gradient);
+    # 3.2e-5 with pass 1's chains of rounds 1-4; round 2's three-product form (no longer in the shipped library) was at 5.5e-5
     assert six["F"] < 6e-5 and six["F_over_terms"] < 3e-6, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
     # the pixel-resident form (k_grads_t: W accumulated in float32 MFMA registers over 2 500 spectra per range, F applied once
@@ -206,9 +206,9 @@ def test_c5_shape_4096_spectra_normalised_gradients_vs_float64_oracle(dev, tmp_p
     print("4096 x 8000, N_h = 32 vs float64 oracle:", out)
     six, fast = out["six"], out["fast"]
     assert six["loss"] < 2e-6
-    # achieved: F 8.2e-5 here (1.2e-5 of the cancelling sums, which are 7x the gradient at 4 096 spectra) and 8.3e-5 on 20 000
-    # spectra (5.4e-6 of the sums, 15x the gradient): the error of the sums averages down as the batch grows
-    assert six["F"] < 1e-4 and six["F_over_terms"] < 2e-5, six
+    # achieved: F 4.5e-5 here (6.4e-6 of the cancelling sums, which are 7x the gradient at 4 096 spectra) with pass 1's chains cut
+    # at 32 tiles (round 5; 8.2e-5 at 63 tiles, 3.6e-4 uncut): the bar VERDICT r4 item 2 asked for
+    assert six["F"] < 8e-5 and six["F_over_terms"] < 1.2e-5, six
     assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
     assert six["F"] <= 1.05 * fast["F"] + 1e-6, (six["F"], fast["F"])      # six piece products are never the worse form
     del batch
