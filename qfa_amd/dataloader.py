@@ -309,6 +309,10 @@ class DeviceDataloader(object):
             C.c_void_p(self._mu_dev.data_ptr()), self._which, n, self.Npix, self.Nb, self._stride,
             C.c_void_p(delta.data_ptr()), C.c_void_p(err.data_ptr()), C.c_void_p(zabs.data_ptr()) if self.Nb > 0 else None,
             C.c_void_p(mask.data_ptr()), _lib.current_stream(self.device)), "qfa_build_batch_f32")
+        if out is not None:
+            # the kernel wrote the caller's tensors through raw pointers: tell torch (QFA.auto_factor_zabs keys on the version counter)
+            for t in out:
+                torch.autograd.graph.increment_version(t)
         if self.factored_z and out is None and self.Nb > 0:
             # QFA.forward / step / predict look for this attribute on the zabs tensor they are handed (the 4-tuple of the
             # reference's next_batch contract stays what it is; a sliced or copied zabs simply loses the attribute)

@@ -37,6 +37,7 @@ PARAM_KEYS = ("F", "Psi", "omega", "tau0", "c0", "beta")
 # the relative tolerance of the structure test: three float32 roundings of 1 + z (zabs itself, zq1, pix_ratio)
 AUTO_FACTOR_ZABS = True
 AUTO_FACTOR_TOL = 4e-7
+AUTO_FACTOR_RECHECK = 64
 
 
 def _resolve_tau(tau):
@@ -222,9 +223,16 @@ class QFA(object):
                 self._zf_seen = {k: e for k, e in self._zf_seen.items() if e[0]() is not None and e[0]()._version == e[1][2]}
                 if len(self._zf_seen) >= 64:
                     self._zf_seen.clear()
-            self._zf_seen[id(zabs)] = (weakref.ref(zabs), sig, "seen")
+            self._zf_seen[id(zabs)] = (weakref.ref(zabs), sig, "seen", 0)
             return None
-        if ent[2] == "seen":
+        # A tensor written behind torch's back (raw pointers: another library, a captured graph's input buffer filled by a kernel)
+        # keeps its version counter: the factors are re-derived and re-tested every AUTO_FACTOR_RECHECK uses, which bounds how long a
+        # stale pair could serve (qfa_amd's own writers bump the counter: DeviceDataloader.next_batch(out=...)).
+        uses = ent[3] + 1 if len(ent) > 3 else 1
+        recheck = isinstance(ent[2], tuple) and uses % AUTO_FACTOR_RECHECK == 0
+        if (ent[2] == "seen" or recheck) and torch.cuda.is_current_stream_capturing():
+            return ent[2] if isinstance(ent[2], tuple) else None          # (no host synchronisation inside a graph capture)
+        if ent[2] == "seen" or recheck:
             B = int(zabs.shape[0])
             zq1 = torch.empty(B, dtype=f32, device=self.device)
             ratio = torch.empty(self.Nb, dtype=f32, device=self.device)
@@ -233,8 +241,15 @@ class QFA(object):
                                                       C.c_void_p(ratio.data_ptr()), C.c_void_p(nbad.data_ptr()),
                                                       _lib.current_stream(self.device)), "qfa_zabs_factor_f32")
             ok = int(nbad.item()) == 0                                    # (the one host synchronisation per repeated tensor)
-            ent = (ent[0], sig, (zq1, ratio) if ok else None)
-            self._zf_seen[id(zabs)] = ent
+            if ok and recheck:                                            # same tensors (a captured graph may hold their addresses)
+                ent[2][0].copy_(zq1)
+                ent[2][1].copy_(ratio)
+                ent = (ent[0], sig, ent[2], uses)
+            else:
+                ent = (ent[0], sig, (zq1, ratio) if ok else None, uses)
+        else:
+            ent = (ent[0], ent[1], ent[2], uses)
+        self._zf_seen[id(zabs)] = ent
         return ent[2]
 
     def _batch_struct_rows(self, rb, raw_flux=False):

@@ -901,3 +901,53 @@ def test_auto_factored_zabs_refuses_what_does_not_factor(dev):
     assert int(nbad.item()) == 1 + 1 + (nb - 1)
     assert _lib.lib().qfa_zabs_factor_f32(None, B, nb, 4e-7, C.c_void_p(zq1.data_ptr()), C.c_void_p(ratio.data_ptr()),
                                           C.c_void_p(nbad.data_ptr()), _lib.current_stream(dev)) == -1
+
+
+def test_auto_factored_zabs_rechecks_what_was_written_behind_torchs_back(dev, monkeypatch):
+    """A tensor rewritten through raw pointers keeps torch's version counter, so the cached factors would be the OLD batch's: the
+    structure test is repeated every AUTO_FACTOR_RECHECK uses (here 3) and refreshes them in place; qfa_amd's own raw writer
+    (DeviceDataloader.next_batch(out=...)) bumps the counter itself."""
+    import ctypes as C
+    import torch
+    import qfa_amd.model as M
+    from qfa_amd import synthetic
+    monkeypatch.setattr(M, "AUTO_FACTOR_RECHECK", 3)
+    npix, nh, B = 640, 12, 130
+    wav, nb, nr = synthetic.wavelength_grid(npix)
+    p, mu = synthetic.mock_parameters(npix, nb, nh, seed=21)
+    b1 = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=22)
+    b2 = synthetic.make_batch_numpy(p, mu, wav, nb, B, seed=23)
+    m = make_model(dev, p, mu)
+    m.deterministic, m.auto_factor_zabs = True, True
+    bt = batch_t(b1, dev)
+    for _ in range(2):
+        m.accumulate(*bt)
+    zq_old = m._zf_seen[id(bt[2])][2][0].clone()
+    # batch 2 into the SAME tensors through the C-ABI (qfa_clip_f32 with open bounds = a raw copy): no version bump
+    t2 = batch_t(b2, dev)
+    v0 = bt[2]._version
+    for dst, src in ((bt[0], t2[0]), (bt[1], t2[1]), (bt[2], t2[2])):
+        assert _lib.lib().qfa_clip_f32(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(), -3e38, 3e38,
+                                       _lib.current_stream(dev)) == 0
+    bt[3].copy_(t2[3])
+    assert bt[2]._version == v0
+    m.accumulate(*bt)                                  # use 2 of the cached pair: stale factors may still serve ...
+    acc = m.accumulate(*bt).clone()                    # ... use 3: re-derived and re-tested
+    zq_new = m._zf_seen[id(bt[2])][2][0]
+    assert not torch.equal(zq_old, zq_new)
+    m.auto_factor_zabs = False
+    ref = m.accumulate(*t2).clone()                    # the zabs kernels on batch 2
+    from tools import parity_sections as PS
+    for name, sl in PS.sections(m).items():
+        a, r = acc[sl].double().cpu().numpy(), ref[sl].double().cpu().numpy()
+        if a.size > 1 and name not in ("cnt",):
+            assert rel_l2(a, r) < 2e-5, (name, rel_l2(a, r))
+    # the loader's raw writer tells torch
+    from qfa_amd.dataloader import DeviceDataloader
+    dl = DeviceDataloader(torch.tensor(b1["flux"], device=dev), torch.tensor(b1["error"], device=dev), b1["zqso"], wav, 32, dev,
+                          tau="becker", shuffle=False)
+    out = dl.next_batch()
+    bufs = tuple(torch.empty_like(x) for x in out)
+    v = bufs[2]._version
+    dl.next_batch(out=bufs)
+    assert bufs[2]._version > v
