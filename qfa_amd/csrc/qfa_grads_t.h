@@ -23,9 +23,9 @@
 // XCD's L2 by the others (measured: 3.9 GB fetched per launch at c3 against 3.6 GB of spectra).
 // The schedule of a step (one barrier per group, the two waves of a SIMD a stage apart) is described at the walk below.
 // The spectra (delta, sigma, zabs rows -- or the per-spectrum factors of the factored-z form: 64 bytes per row and tile;
-// masks 16) are staged per wave, two groups ahead, as in k_grads_x.  All DMA is asm (untracked) with counted waits;
-// ragged tiles (the last tile of a pixel axis that is no multiple of 16, the tile that straddles the end of the blue side in
-// the zabs form) stage 4-byte pieces and wait for everything.
+// masks 16) are staged per wave, two groups ahead, as in k_grads_x.  All DMA is asm (untracked); every wave waits for all of its
+// requests in front of the step's barrier (round 5).  Ragged tiles (the last tile of a pixel axis that is no multiple of 16, the
+// tile that straddles the end of the blue side in the zabs form) stage 4-byte pieces through the general path.
 #pragma once
 #ifndef QFA_GT_SETPRIO
 #define QFA_GT_SETPRIO 2   // s_setprio around the MFMA stages of k_grads_t: the wave of a SIMD that is in stage 3 (or 1) issues ahead of its
@@ -244,11 +244,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const bool fastp = active && PXW * wt + PXW - 1 < Npix;
     const bool zblue = !ZF && blueTile;                     // the tile stages zabs
     const bool fastz = !zblue || PXW * wt + PXW - 1 < Nb;
-#ifndef QFA_GT_FASTONLY
-#define QFA_GT_FASTONLY 0  // register-pressure experiment (wrong results on ragged / straddling tiles): no general staging path
-#endif
-    const bool slow = !QFA_GT_FASTONLY && active && !fastp;                     // the ragged last tile: 4-byte pieces
-    const bool zstrad = !QFA_GT_FASTONLY && active && fastp && !fastz;          // zabs form, the tile across the end of the blue side: zabs as 4-byte pieces
+    const bool slow = active && !fastp;                     // the ragged last tile: 4-byte pieces
+    const bool zstrad = active && fastp && !fastz;          // zabs form, the tile across the end of the blue side: zabs as 4-byte pieces
     const bool zfb = ZF && blueTile;                        // the tile stages the per-spectrum factors of the factored-z form
     // (no counted waits any more, round 5: every wave waits for all of its requests in front of the step's barrier)
     // first byte of the 4-byte mask piece (half h of the tile, piece pc) in its row; the ragged tile clamps it to Npix - 4
@@ -870,8 +867,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     // so that one wave's VALU phase (stage 2) meets the other's MFMAs.  The barrier of step t says: the Z part of group t
     // and the S1 part of group t + 1 (requested during step t - 1) have landed, and nobody reads Z(t - 1) and S1(t) any
     // more -- their slots take Z(t + 1) and S1(t + 2), piece by piece between the MFMA groups / elements of the stages.
-    // Counted wait in front of the barrier: waves 0..3 end a step with the spectra requests of stage 2, which stay in flight;
-    // waves 4..7 issue theirs a whole step before the wait.
+    // Round 5: the staging requests of group t + 2 sit in stage 3 (t) of EVERY wave (one per second column tile, between its
+    // MFMAs) and the Z pieces of waves 4..7 in stage 1; every wave waits vmcnt(0) in front of the step's barrier -- nothing stays in
+    // flight across it (rounds 3-4: the requests were a block in stage 2 and waves 0..3 left theirs in flight by a counted wait).
     // (Measured forms of this loop, profiles/r3_ablation_pass2.txt: a barrier per half-step with waves 4..7 half a step
     // behind: 7 100 cycles per group -- the stages of a wave ALONE take 5 700 and are no slower beside a partner in another
     // phase, every barrier adds the skew between waves; all eight waves in the same phase, one barrier: 7 400 -- two waves of
