@@ -284,7 +284,7 @@ def dry_run(args, real_stdout):
         dist.barrier()
     if rank == 0:
         os.write(real_stdout, (json.dumps({"metric": "spectra/sec per EM step", "value": None, "dry_run": True,
-                                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                           "n_gpus": world, "steps": args.steps if args.steps >= 0 else 20, "warmup": args.warmup if args.warmup >= 0 else 40,
                                            "max_over_ranks": float(t.item())}) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
@@ -298,10 +298,11 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # (defaults: 40 untimed steps -- ~0.15 s at c3 -- let the clocks settle; the first steps after the data generation ran 1-5 %
-    # slower than the >= 3 s sustained leg of the same kernels in round 5's runs with 5)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=40)
+    # (defaults: >= 40 untimed steps / 0.25 s let the clocks settle; the first steps after the data generation ran 1-5 % slower than the
+    # >= 3 s sustained leg of the same kernels in round 5's runs with 5)
+    ap.add_argument("--steps", type=int, default=-1, help="timed steps; default: 20, or as many as 0.1 s of steps take (small batches)")
+    ap.add_argument("--warmup", type=int, default=-1,
+                    help="untimed steps in front of the timed ones; default: 40, or as many as 0.25 s of steps take (small batches)")
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
                     help="default: c3 (100 000 spectra per GPU); with --gpus 8: c4 (BASELINE configs[3]: 1M spectra over 8 GPUs)")
     ap.add_argument("--batch", type=int, default=0, help="spectra per GPU (default: the config's)")
@@ -380,6 +381,25 @@ def main():
         model.enable_data_parallel()
     opt = Adam(model.parameters, dev, scheduler=step_scheduler(0.9, 10), learning_rate=1e-3, weight_decay=1e-1)
 
+    if args.warmup < 0:
+        # default: 40 steps, or 0.25 s worth of them when a step is short (c2, c1b: 40 steps are 4 - 7 ms, the clocks have not settled)
+        for _ in range(3):
+            model.step(opt, *batch)
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        for _ in range(5):
+            model.step(opt, *batch)
+        torch.cuda.synchronize()
+        per = max((time.perf_counter() - t_w) / 5, 1e-6)
+        args.warmup = int(max(40, min(5000, 0.25 / per)))
+        if args.steps < 0:                                  # (20 steps of a 0.1-ms step are mostly the queue filling up)
+            args.steps = int(max(20, min(2000, 0.1 / per)))
+        if use_dist:                                        # (every rank the same counts)
+            tw = torch.tensor([args.warmup, args.steps], dtype=torch.int64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            args.warmup, args.steps = int(tw[0].item()), int(tw[1].item())
+    if args.steps < 0:
+        args.steps = 20
     # (at least two untimed steps: the second sighting of the zabs tensor runs the one-time structure test of QFA.auto_factor_zabs)
     for _ in range(max(args.warmup, 2 if (model.auto_factor_zabs and nb > 0) else 0)):
         model.step(opt, *batch)
