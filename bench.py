@@ -56,6 +56,9 @@ CONFIGS = {
 PEAK_FP32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (XDL) peak
 PEAK_HBM_GBS = 8000.0
+# What an MFMA + ds_read_b128 + two v_fma stream with no stall delivers once the chip has lowered its clock under the load
+# (tools/ubench/xdl_power.hip mode 4 on one MI355X: 1.49 GHz; profiles/r5_ubench_xdl_power.txt).  Informational, not `peak`.
+CAPPED_STREAM_TFLOPS = 1430.0
 # the true reference (imported in the survey container, SURVEY.md section 6 / BASELINE.md section 2): forward, 8 cores
 REFERENCE_8CORE = {"c1": 13.4, "c1b": 13.4, "c2": 12.2, "c3": 1.54, "c4": 1.54, "c5": 0.21}
 
@@ -638,7 +641,10 @@ def main():
                           + (", three in stage 3: QFA_F_S3_FAST" if fast else "")
                           + ") over the dense bf16 MFMA peak",
                 "alg_flops_per_spectrum": dom_flops, "achieved_alg_fp32": ach32,
-                "frac_vs_fp32_roof": ach32 / PEAK_FP32_TFLOPS}
+                "frac_vs_fp32_roof": ach32 / PEAK_FP32_TFLOPS,
+                "clock_capped_stream": {"tflops": CAPPED_STREAM_TFLOPS, "frac": ach / CAPPED_STREAM_TFLOPS,
+                                        "source": "profiles/r5_ubench_xdl_power.txt (mode 4: the chip holds 1.49 GHz, not 2.4, "
+                                                  "under a stall-free MFMA + LDS + VALU stream on random operands)"}}
     else:
         roof = {"bound": "mfma", "kernel": dominant, "achieved": ach32, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach32 / PEAK_FP32_TFLOPS, "traffic": traffic, "kernel_ms": dom_ms,
