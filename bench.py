@@ -171,12 +171,18 @@ def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
     by_total = 4 * (2 * npix + nh * nh + nh + 1) + 9 * npix + 4 * nb
     by_writer = 8 * npix
     w_ms = float(st[2])
+    kp = 8 if nh <= 8 else (16 if nh <= 16 else 32)
+    nks = 1 + (kp * (kp + 1) // 2 + 31) // 32               # K-steps of the writer's stage 1 ([hmean | hcov'] against [f | f_a f_b])
+    w_tf = npix * nks * 6 * 16384 / 256 * B / (w_ms * 1e-3) / 1e12     # issued bf16 piece-product flops (six MFMAs per K-step, 16 x 16 tile)
     return {"value": B / dt, "unit": "spectra/s", "ms_per_call": dt * 1e3, "spectra": B, "calls": n,
             "stage_ms": {"images_and_pass1": float(st[0]), "solve": float(st[1]), "writer": w_ms},
             "roofline": {"bound": "hbm", "kernel": "k_predict_x" if nh <= 16 else "k_predict_x32", "achieved": by_writer * B / (w_ms * 1e-3) / 1e9,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": by_writer * B / (w_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "alg_bytes_per_spectrum_writer": by_writer},
+                         "alg_bytes_per_spectrum_writer": by_writer,
+                         # the writer also runs stage 1 on the XDL pipe: at N_h > 16 that, not the stores, is what it waits for
+                         "xdl": {"tflops": w_tf, "frac_of_peak": w_tf / PEAK_BF16_TFLOPS,
+                                 "frac_of_clock_capped_stream": w_tf / CAPPED_STREAM_TFLOPS}},
             "call_hbm_frac": (B / dt) * by_total / (PEAK_HBM_GBS * 1e9), "alg_bytes_per_spectrum": by_total}
 
 
