@@ -36,6 +36,8 @@ __global__ __launch_bounds__(512) void k(const u32x4 *__restrict__ in, float *ou
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
 #define M(C, A, B) "v_mfma_f32_16x16x32_bf16 " C ", " A ", " B ", " C "\n"
 #define SIX M("%0", "%4", "%7") M("%1", "%4", "%8") M("%2", "%5", "%7") M("%3", "%4", "%9") M("%0", "%6", "%7") M("%1", "%5", "%8")
+#define SIXA M("%0", "%4", "%7") M("%1", "%4", "%8") M("%2", "%4", "%9") M("%3", "%5", "%7") M("%0", "%5", "%8") M("%1", "%6", "%7")
+#define SIXB M("%0", "%4", "%7") M("%1", "%5", "%8") M("%2", "%6", "%7") M("%3", "%4", "%9") M("%0", "%5", "%7") M("%1", "%4", "%8")
 // LDS modes: %0-3 accumulators, %4 %5 the B operands the ds_reads refill, %6 %7 the fma chains, %8-10 A pieces, %11 LDS address, %12 %13 p q
 #define SIXL(X) M("%0", "%8", "%4") X "ds_read_b128 %4, %11\n" M("%1", "%8", "%5") X "ds_read_b128 %5, %11 offset:1024\n" \
                 M("%2", "%9", "%4") X "ds_read_b128 %4, %11 offset:2048\n" M("%3", "%10", "%5") X "ds_read_b128 %5, %11 offset:3072\n" \
@@ -49,6 +51,14 @@ __global__ __launch_bounds__(512) void k(const u32x4 *__restrict__ in, float *ou
     for (int r = 0; r < reps; ++r) {
         if (MODE <= 2) {
             asm volatile(".rept 16\n" SIX ".endr\n"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
+        } else if (MODE == 9) {
+            asm volatile(".rept 16\n" SIXA ".endr\n"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
+        } else if (MODE == 10) {
+            asm volatile(".rept 16\n" SIXB ".endr\n"
                          : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
                          : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
         } else if (MODE == 3) {
@@ -133,5 +143,8 @@ int main() {
     run<6>(in, out, ticks, "as 4 + 24 idle issue cycles per MFMA and wave");
     run<7>(in, out, ticks, "as 4 + 48 idle issue cycles per MFMA and wave");
     run<8>(in, out, ticks, "as 4 + 80 idle issue cycles per MFMA and wave");
+    run<9>(in, out, ticks, "as 2, products ordered so that A repeats (hh hm hl mh mm lh)");
+    run<10>(in, out, ticks, "as 2, products ordered so that A and B both change every time");
+    run<2>(in, out, ticks, "mode 2 again");
     return 0;
 }
