@@ -328,6 +328,45 @@ __device__ __forceinline__ f32x4 xdl(const u32x4 &a, const u32x4 &b, f32x4 c) { 
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                    0, 0);
 }
+// ---- float16 pieces (round 5).  Where BOTH operands of a contraction are prepared images whose rows can be scaled by a power
+// of two (the pixel image and the per-spectrum state of stage 1 of pass 2), two float16 pieces (11 + 11 bits) and THREE
+// products (hh, hm, mh; mm is 2^-22) give the accuracy of the six bf16 piece products at half the MFMAs -- measured:
+// tools/ubench/bf16x3_numerics.hip, profiles/r5_ubench_f16x2_numerics.txt.  float16 has 5 exponent bits: the builder scales a
+// row so that its largest element is in [2^13, 2^14) (elements down to 2^-16 of it keep all 22 bits, smaller ones an absolute
+// 2^-38 of it) and the consumer multiplies the power of two back in.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned &h, unsigned &m) {      // |x| < 65 504
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 m0 = (_Float16)(x0 - (float)h0), m1 = (_Float16)(x1 - (float)h1);
+    h = __builtin_bit_cast(unsigned, f16x2{h0, h1});
+    m = __builtin_bit_cast(unsigned, f16x2{m0, m1});
+}
+__device__ __forceinline__ void split8h(const float (&x)[8], u32x4 &h, u32x4 &m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned a, b;
+        split2h(x[2 * q], x[2 * q + 1], a, b);
+        h[q] = a; m[q] = b;
+    }
+}
+__device__ __forceinline__ f32x4 xdlh(const u32x4 &a, const u32x4 &b, f32x4 c) {         // K = 32, float16 operands
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// (small terms first; the first product's A operand is used again, see six_terms)
+__device__ __forceinline__ f32x4 xdl3h(const u32x4 &ah, const u32x4 &am, const u32x4 &bh, const u32x4 &bm, f32x4 c) {
+    c = xdlh(ah, bm, c);
+    c = xdlh(am, bh, c);
+    return xdlh(ah, bh, c);
+}
+// the power of two that brings `amax` into [2^13, 2^14) (1 for amax = 0 or not finite), and its inverse
+__host__ __device__ __forceinline__ float f16_row_scale(float amax, float &inv) {
+    int e = 0;
+    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &e); else e = 14;      // amax = m 2^e, m in [0.5, 1)
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    inv = ldexpf(1.f, e - 14);
+    return ldexpf(1.f, 14 - e);
+}
 __device__ __forceinline__ f32x4 xdl16(const u32x2 &a, const u32x2 &b, f32x4 c) {        // K = 16
 #if QFA_ABL == 13          // timing only: no K = 16 XDL MFMA (stage 3 of pass 2)
     asm volatile("" ::"v"(a), "v"(b));

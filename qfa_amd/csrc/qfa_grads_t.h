@@ -63,14 +63,28 @@ __device__ __forceinline__ void prep_pgt_body(int bid, const float *__restrict__
     const int p0 = GT::PXW * (bid / GT::TPW) + bid % GT::TPW;
     auto pixel = [&](int lo) { return p0 + GT::TPW * lo; };
     __shared__ float f[16][KP + 1];
+    __shared__ float tsc[16][3];                                     // F16S1: the pixel's power of two t, 1 / t^2, 1 / t
     for (int i = threadIdx.x; i < 16 * KP; i += 256) {
         const int px = i / KP, a = i % KP;
         f[px][a] = (pixel(px) < Npix && a < Nh) ? F[(size_t)pixel(px) * Nh + a] : 0.f;
     }
     __syncthreads();
+    if (GT::F16S1 && threadIdx.x < 16) {
+        // t f_a in [2^6, 2^7) for the pixel's largest |f_a|: the pair products t^2 f_a f_b stay below 2^14 (float16: 65 504)
+        float mx = 0.f;
+        for (int a = 0; a < KP; ++a) mx = fmaxf(mx, fabsf(f[threadIdx.x][a]));
+        int e = 7;
+        if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);          // mx = m 2^e, m in [0.5, 1)
+        e = e < -50 ? -50 : (e > 60 ? 60 : e);
+        tsc[threadIdx.x][0] = ldexpf(1.f, 7 - e);
+        tsc[threadIdx.x][1] = ldexpf(1.f, 2 * (e - 7));
+        tsc[threadIdx.x][2] = ldexpf(1.f, e - 7);
+    }
+    if (GT::F16S1) __syncthreads();
     for (int i = threadIdx.x; i < GT::NKQ * 64; i += 256) {
         const int lane = i & 63, ks = i >> 6;
         const int px = lane & 15, g = lane >> 4;
+        const float t1 = GT::F16S1 ? tsc[px][0] : 1.f, t2 = t1 * t1;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -80,19 +94,26 @@ __device__ __forceinline__ void prep_pgt_body(int bid, const float *__restrict__
                 int a = 0;
                 while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
                 const int b = a + (q - pair_index(a, a, KP));
-                x = f[px][a] * f[px][b];
+                x = f[px][a] * f[px][b] * t2;                        // (a power of two: exact)
             } else {
                 const int a = q - (32 * (GT::NKQ - 1) + GT::YOFF);
-                if (a >= 0 && a < KP) x = f[px][a];
+                if (a >= 0 && a < KP) x = f[px][a] * t1;
             }
             v[j] = x;
         }
-        u32x4 ph, pm, pl;
-        split8(v, ph, pm, pl);
-        unsigned char *dst = tile + ks * 3072 + lane * 16;
-        *reinterpret_cast<u32x4 *>(dst) = ph;
-        *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
-        *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+        unsigned char *dst = tile + ks * GT::BLK_B + lane * 16;
+        if constexpr (GT::F16S1) {
+            u32x4 ph, pm;
+            split8h(v, ph, pm);
+            *reinterpret_cast<u32x4 *>(dst) = ph;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+        } else {
+            u32x4 ph, pm, pl;
+            split8(v, ph, pm, pl);
+            *reinterpret_cast<u32x4 *>(dst) = ph;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+            *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+        }
     }
     if (threadIdx.x < 128) {
         const int j = threadIdx.x, px = pixel(j & 15);
@@ -102,7 +123,7 @@ __device__ __forceinline__ void prep_pgt_body(int bid, const float *__restrict__
         else if (j < 80 && ZP.on() && px < Nb) {
             const float4 q = ZP.at(px);
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
-        }
+        } else if (GT::F16S1 && j >= 80 && j < 112) v = tsc[j & 15][j < 96 ? 1 : 2];
         reinterpret_cast<float *>(tile + GT::OFF_PAR)[j] = v;
     }
     float *fr = reinterpret_cast<float *>(tile + GT::OFF_F);
@@ -193,17 +214,19 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     const unsigned char *tile[TPW];
     u32x4 IBh[TPW][GT::NKQ], IBm[TPW][GT::NKQ], IBl[TPW][GT::NKQ];
     float Psi[TPW], om[TPW], ti[TPW], pwi[TPW], l2i[TPW], offl[TPW];
+    float it2[TPW], it1[TPW];                               // F16S1: the inverse powers of two of the lane's pixel (pairs, F)
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         tile[j] = PGT + (size_t)(active ? TPW * wt + j : 0) * GT::TILE_B;
 #pragma unroll
         for (int ks = 0; ks < GT::NKQ; ++ks) {
-            IBh[j][ks] = *reinterpret_cast<const u32x4 *>(tile[j] + ks * 3072 + lane * 16);
-            IBm[j][ks] = *reinterpret_cast<const u32x4 *>(tile[j] + ks * 3072 + 1024 + lane * 16);
-            IBl[j][ks] = *reinterpret_cast<const u32x4 *>(tile[j] + ks * 3072 + 2048 + lane * 16);
+            IBh[j][ks] = *reinterpret_cast<const u32x4 *>(tile[j] + ks * GT::BLK_B + lane * 16);
+            IBm[j][ks] = *reinterpret_cast<const u32x4 *>(tile[j] + ks * GT::BLK_B + 1024 + lane * 16);
+            IBl[j][ks] = GT::F16S1 ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4 *>(tile[j] + ks * GT::BLK_B + (GT::S1NP - 1) * 1024 + lane * 16);
         }
         const float *par = reinterpret_cast<const float *>(tile[j] + GT::OFF_PAR);
         Psi[j] = par[lo]; om[j] = par[16 + lo];
+        it2[j] = GT::F16S1 ? par[80 + lo] : 1.f; it1[j] = GT::F16S1 ? par[96 + lo] : 1.f;
         ti[j] = ZF ? par[32 + lo] : 0.f; pwi[j] = ZF ? par[48 + lo] : 0.f; l2i[j] = ZF ? par[64 + lo] : 0.f;
         // factored-z form: a red pixel of the tile that holds the boundary has omega = ti = pwi = 0 in its image
         // (prep_pgt_body) and offset 0 here: A = exp2(0) = 1 and omega zd = 0 come out of the blue arithmetic without a select
@@ -216,8 +239,11 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
 #pragma unroll
-        for (int ks = 0; ks < GT::NKQ; ++ks) asm volatile("" ::"v"(IBh[j][ks]), "v"(IBm[j][ks]), "v"(IBl[j][ks]));
-        asm volatile("" ::"v"(Psi[j]), "v"(om[j]), "v"(ti[j]), "v"(pwi[j]), "v"(l2i[j]));
+        for (int ks = 0; ks < GT::NKQ; ++ks) {
+            asm volatile("" ::"v"(IBh[j][ks]), "v"(IBm[j][ks]));
+            if (!GT::F16S1) asm volatile("" ::"v"(IBl[j][ks]));
+        }
+        asm volatile("" ::"v"(Psi[j]), "v"(om[j]), "v"(ti[j]), "v"(pwi[j]), "v"(l2i[j]), "v"(it2[j]), "v"(it1[j]));
     }
     asm volatile("" ::"v"(k.tau0), "v"(k.c0), "v"(k.beta), "v"(k.t_amp), "v"(k.t_lscale), "v"(k.t_expo), "v"(k.t_off), "v"(k.offp),
                  "v"(k.k1), "v"(k.omc0));
@@ -601,24 +627,46 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         const unsigned char *sp = lds + GT::L_S1 + (t & 1) * GT::S1P_B + lane * 16;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) afy[j] = aq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 aop[2][3];
+        constexpr int NP = GT::S1NP;
+        u32x4 aop[2][NP];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) aop[0][pc] = *reinterpret_cast<const u32x4 *>(sp + pc * 1024);
+        for (int pc = 0; pc < NP; ++pc) aop[0][pc] = *reinterpret_cast<const u32x4 *>(sp + pc * 1024);
+        // F16S1: the inverse powers of two of the lane's four spectra (Cinv', y), out of the y block's free K slots
+        f32x4 isc[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}};
+        if constexpr (GT::F16S1) {
+            const unsigned char *sq = lds + GT::L_S1 + (t & 1) * GT::S1P_B + GT::S1_SCALES + 32 * g;
+            isc[0] = *reinterpret_cast<const f32x4 *>(sq);          // 1 / scale(Cinv'), 1 / scale(y) of spectra 4 g, 4 g + 1
+            isc[1] = *reinterpret_cast<const f32x4 *>(sq + 16);     // ... of 4 g + 2, 4 g + 3
+        }
 #pragma unroll
         for (int ks = 0; ks < GT::NKS; ++ks) {
             if (ks + 1 < GT::NKS) {
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    aop[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(sp + (ks + 1) * 3072 + pc * 1024);
+                for (int pc = 0; pc < NP; ++pc)
+                    aop[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(sp + (ks + 1) * GT::BLK_B + pc * 1024);
             }
             piece(pt, ks);
             if (ks == GT::NKS - 1) piece(pt, GT::NKS);             // (a seventh site: the Z part of the waves 4..7 rides here, QFA_GT_ZS1)
-            const u32x4 &ah = aop[ks & 1][0], &am = aop[ks & 1][1], &al = aop[ks & 1][2];
+            const u32x4 &ah = aop[ks & 1][0], &am = aop[ks & 1][1], &al = aop[ks & 1][NP - 1];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-                if (ks < GT::NKQ) aq[j] = xdl6(ah, am, al, IBh[j][ks], IBm[j][ks], IBl[j][ks], aq[j]);
-                else afy[j] = xdl6(ah, am, al, IBh[j][GT::NKQ - 1], IBm[j][GT::NKQ - 1], IBl[j][GT::NKQ - 1], afy[j]);     // the y block
+                if constexpr (GT::F16S1) {
+                    if (ks < GT::NKQ) aq[j] = xdl3h(ah, am, IBh[j][ks], IBm[j][ks], aq[j]);
+                    else afy[j] = xdl3h(ah, am, IBh[j][GT::NKQ - 1], IBm[j][GT::NKQ - 1], afy[j]);                          // the y block
+                } else {
+                    if (ks < GT::NKQ) aq[j] = xdl6(ah, am, al, IBh[j][ks], IBm[j][ks], IBl[j][ks], aq[j]);
+                    else afy[j] = xdl6(ah, am, al, IBh[j][GT::NKQ - 1], IBm[j][GT::NKQ - 1], IBl[j][GT::NKQ - 1], afy[j]);     // the y block
+                }
             }
+        }
+        if constexpr (GT::F16S1) {             // the powers of two back in: element r <-> spectrum 4 g + r, the lane's pixel
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    aq[j][r] *= isc[r >> 1][2 * (r & 1)] * it2[j];
+                    afy[j][r] *= isc[r >> 1][2 * (r & 1) + 1] * it1[j];
+                }
         }
         GTS(5)
         if constexpr (QFA_GT_SETPRIO != 0 && (QFA_GT_PRIO_STAGES & 1) != 0) __builtin_amdgcn_s_setprio(0);

@@ -4,6 +4,10 @@
 #pragma once
 #include "qfa_common.h"
 
+#ifndef QFA_GT_F16S1
+#define QFA_GT_F16S1 1     // stage 1 of k_grads_t on TWO float16 pieces per operand and three products (18 MFMAs per group instead of 36;
+                           // qfa_common.h "float16 pieces"): the image carries a power of two per pixel, the state one per spectrum
+#endif
 template <int KP_>
 struct GTT {
     static constexpr int KP = KP_, KK2 = KP * (KP + 1) / 2;
@@ -15,13 +19,21 @@ struct GTT {
     static constexpr int YOFF = (KK2 % 32 + 7) / 8 * 8;      // 8
     static_assert(KK2 % 32 != 0 && YOFF + KP <= 32, "F / y share the last pair block");
     static constexpr int NKS = NKQ + 1;                      // blocks of the spectrum side (6)
+    static constexpr bool F16S1 = QFA_GT_F16S1 != 0;
+    static constexpr int S1NP = F16S1 ? 2 : 3;               // pieces per K block of stage 1 (float16 h, m | bf16 h, m, l)
+    static constexpr int BLK_B = S1NP * 1024;
     // per 16-pixel tile in global memory (k_prep_pgt)
-    static constexpr int IMG_B = NKQ * 3 * 1024;             // [ks][piece][lane (g, lo)][8 k] bf16: B[k = 32 ks + 8 g + j][px = lo]
-    static constexpr int OFF_PAR = IMG_B;                    // float Psi[16] | omega[16] | ti[16] | pwi[16] | l2i[16]
+    static constexpr int IMG_B = NKQ * BLK_B;                // [ks][piece][lane (g, lo)][8 k]: B[k = 32 ks + 8 g + j][px = lo]
+    // float Psi[16] | omega[16] | ti[16] | pwi[16] | l2i[16] | F16S1: 1 / t^2 [16] | 1 / t [16] (t = the pixel's power of two:
+    // the image holds t^2 f_a f_b and t f_a)
+    static constexpr int OFF_PAR = IMG_B;
     static constexpr int OFF_F = IMG_B + 512;                // float F[16 px][KP]
     static constexpr int TILE_B = (OFF_F + 16 * KP * 4 + 1023) / 1024 * 1024;
     // per group of 16 spectra in global memory (k_prep_pst)
-    static constexpr int S1_B = NKS * 3 * 1024;              // [block][piece][lane (g, lo = spectrum)][8 k]: A[s][k] of stage 1
+    // F16S1: Cinv' and y of a spectrum are scaled by powers of two of their own; their inverses sit as float32 in the h piece of
+    // the y block, lanes g = 3 (K slots 24..31, which meet zeros of the image): float 2 s = 1 / scale(Cinv'), 2 s + 1 = 1 / scale(y)
+    static constexpr int S1_B = NKS * BLK_B;                 // [block][piece][lane (g, lo = spectrum)][8 k]: A[s][k] of stage 1
+    static constexpr int S1_SCALES = NKQ * BLK_B + 48 * 16;  // (byte offset of those 32 floats in the S1 part)
     static constexpr int S1P_B = S1_B;                       // (the S1 part as the ring holds it)
     // stage 3: column tiles of W.  KP = 16: one per a (rows m = b).  KP = 8: the 8 rows b of TWO a fill one 16-row MFMA tile
     // (row m <-> a = 2 tile + (m >> 3), b = m & 7): half the MFMAs, operand reads and accumulator registers
@@ -37,7 +49,7 @@ struct GTT {
     static constexpr int TPW = KP == 8 ? 2 : 1;
     static constexpr int PXW = 16 * TPW;
     // a part moves as 1-KiB pieces, contiguous runs of them per wave (k_grads_t decides which waves)
-    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 18, 34 (KP = 8: 9, 10)
+    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 12 (bf16 pieces: 18), 34 (KP = 8: 6 (9), 10)
     static_assert((Z_PCS + 4) / 5 <= 7 && (S1_PCS + 4) / 5 <= 6, "pieces per wave and stage: 7 slots in stage 2, 7+ in stage 3, NKS + 1 = 7 in stage 1 (4 at KP = 8)");
     // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
     // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
@@ -64,10 +76,30 @@ template <int KP>
 __device__ __forceinline__ void build_state(const float *rows, int s0, int B, int Nh, unsigned char *__restrict__ st, int tid) {
     using C = Cfg<KP>;
     using GT = GTT<KP>;
+    // F16S1: the powers of two of the group's 16 spectra (16 threads per spectrum look at its Cinv' and y)
+    __shared__ float sc_[16][4];                                         // scale(Cinv'), scale(y), their inverses
+    if constexpr (GT::F16S1) {
+        __syncthreads();                                                 // (k_solve calls this per group: the previous call's readers)
+        const int s = tid >> 4, sub = tid & 15;
+        const bool v = s0 + s < B;
+        const float *sol = rows + (size_t)(v ? s : 0) * C::NSOL;
+        float mc = 0.f, my = 0.f;
+        for (int q = sub; q < GT::KK2; q += 16) mc = fmaxf(mc, fabsf(sol[C::SOL_CI + q]));
+        if (sub < KP) my = fabsf(sol[sub]);
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { mc = fmaxf(mc, __shfl_xor(mc, o)); my = fmaxf(my, __shfl_xor(my, o)); }
+        if (sub == 0) {
+            float ic, iy;
+            const float c_ = f16_row_scale(v ? mc : 0.f, ic), y_ = f16_row_scale(v ? my : 0.f, iy);
+            sc_[s][0] = c_; sc_[s][1] = y_; sc_[s][2] = ic; sc_[s][3] = iy;
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < GT::NKS * 64; i += 256) {
         const int lane = i & 63, ks = i >> 6, lo = lane & 15, g = lane >> 4;
         const bool v = s0 + lo < B;
         const float *sol = rows + (size_t)(v ? lo : 0) * C::NSOL;
+        const float scl = GT::F16S1 ? sc_[lo][ks < GT::NKQ ? 0 : 1] : 1.f;
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -79,14 +111,26 @@ __device__ __forceinline__ void build_state(const float *rows, int s0, int B, in
                 const int a = 8 * g + j - GT::YOFF;
                 if (v && a >= 0 && a < KP) val = sol[a];
             }
-            x[j] = val;
+            x[j] = val * scl;
         }
-        u32x4 h, m, l;
-        split8(x, h, m, l);
-        unsigned char *dst = st + ks * 3072 + lane * 16;
-        *reinterpret_cast<u32x4 *>(dst) = h;
-        *reinterpret_cast<u32x4 *>(dst + 1024) = m;
-        *reinterpret_cast<u32x4 *>(dst + 2048) = l;
+        unsigned char *dst = st + ks * GT::BLK_B + lane * 16;
+        if constexpr (GT::F16S1) {
+            u32x4 h, m;
+            split8h(x, h, m);
+            if (ks == GT::NKQ && g == 3) {                               // (zeros so far: the inverse scales of spectra 2 lo, 2 lo + 1)
+                static_assert(GT::YOFF + KP <= 24, "K slots 24..31 of the y block are free");
+                if (lo < 8) h = u32x4{__float_as_uint(sc_[2 * lo][2]), __float_as_uint(sc_[2 * lo][3]),
+                                      __float_as_uint(sc_[2 * lo + 1][2]), __float_as_uint(sc_[2 * lo + 1][3])};
+            }
+            *reinterpret_cast<u32x4 *>(dst) = h;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = m;
+        } else {
+            u32x4 h, m, l;
+            split8(x, h, m, l);
+            *reinterpret_cast<u32x4 *>(dst) = h;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = m;
+            *reinterpret_cast<u32x4 *>(dst + 2048) = l;
+        }
     }
     for (int i = tid; i < (GT::NWT + 1) * 64; i += 256) {
         const int lane = i & 63, wt = i >> 6, lo = lane & 15, g = lane >> 4;      // wt == NWT: the p operands

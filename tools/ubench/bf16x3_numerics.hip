@@ -1,7 +1,9 @@
 // Numerics check: 16x16 tile of sum_k A[m][k] B[k][n] accumulated over K, three ways:
 //   (a) v_mfma_f32_16x16x4_f32 (exact f32 fma chain), (b) operands split into three bf16 pieces (RNE), six
 //   v_mfma_f32_16x16x32_bf16 per K-step of 32 (hh, hm, mh, hl, lh, mm; small terms first), (c) the 3-term
-//   variant (hh, hm, mh).  Reference: float64 on the host.
+//   variant (hh, hm, mh), (d) round 5: operands split into TWO f16 pieces (11 + 11 bits; rows of A and columns of B scaled by a power
+//   of two so that their largest element is in [1, 2): f16 has 5 exponent bits), three v_mfma_f32_16x16x32_f16 (hm, mh, hh) and (e)
+//   four (+ mm).  Reference: float64 on the host.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -10,6 +12,17 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned &h, unsigned &m) {          // two f16 pieces, round to nearest
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 m0 = (_Float16)(x0 - (float)h0), m1 = (_Float16)(x1 - (float)h1);
+    h = __builtin_bit_cast(unsigned, f16x2{h0, h1});
+    m = __builtin_bit_cast(unsigned, f16x2{m0, m1});
+}
+__device__ __forceinline__ f32x4 xdlh(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     unsigned r;
@@ -29,7 +42,12 @@ __device__ __forceinline__ f32x4 xdl(u32x4 a, u32x4 b, f32x4 c) {
 
 __global__ void k(const float *A, const float *B, int K, float *out) {     // A [16][K], B [K][16]
     const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-    f32x4 c32 = {0, 0, 0, 0}, c6 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+    f32x4 c32 = {0, 0, 0, 0}, c6 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0}, h3 = {0, 0, 0, 0}, h4 = {0, 0, 0, 0};
+    float amax = 0.f, bmax = 0.f;                                 // row r of A, column r of B
+    for (int kk = 0; kk < K; ++kk) { amax = fmaxf(amax, fabsf(A[r * K + kk])); bmax = fmaxf(bmax, fabsf(B[kk * 16 + r])); }
+    int ea, eb;
+    frexpf(amax, &ea); frexpf(bmax, &eb);
+    const float sa = ldexpf(1.f, 1 - ea), sb = ldexpf(1.f, 1 - eb);
     for (int k0 = 0; k0 < K; k0 += 4) c32 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * K + k0 + g], B[(k0 + g) * 16 + r], c32, 0, 0, 0);
     for (int k0 = 0; k0 < K; k0 += 32) {
         u32x4 ah, am, al, bh, bm, bl;
@@ -43,11 +61,29 @@ __global__ void k(const float *A, const float *B, int K, float *out) {     // A 
         c6 = xdl(al, bh, c6); c6 = xdl(ah, bl, c6); c6 = xdl(am, bm, c6);
         c6 = xdl(am, bh, c6); c6 = xdl(ah, bm, c6); c6 = xdl(ah, bh, c6);
         c3 = xdl(am, bh, c3); c3 = xdl(ah, bm, c3); c3 = xdl(ah, bh, c3);
+        u32x4 fah, fam, fbh, fbm;
+        for (int j = 0; j < 4; ++j) {
+            unsigned h, m;
+            split2h(sa * A[r * K + k0 + 8 * g + 2 * j], sa * A[r * K + k0 + 8 * g + 2 * j + 1], h, m);
+            fah[j] = h; fam[j] = m;
+            split2h(sb * B[(k0 + 8 * g + 2 * j) * 16 + r], sb * B[(k0 + 8 * g + 2 * j + 1) * 16 + r], h, m);
+            fbh[j] = h; fbm[j] = m;
+        }
+        h3 = xdlh(fam, fbh, h3); h3 = xdlh(fah, fbm, h3); h3 = xdlh(fah, fbh, h3);
+        h4 = xdlh(fam, fbm, h4); h4 = xdlh(fam, fbh, h4); h4 = xdlh(fah, fbm, h4); h4 = xdlh(fah, fbh, h4);
+    }
+    // un-scale: element (row 4 g + i of A, column r of B): the row scale of A sits in lane (row), fetch it from there
+    for (int i = 0; i < 4; ++i) {
+        const float sra = __shfl(sa, 4 * g + i, 64);
+        h3[i] = h3[i] / (sra * sb);
+        h4[i] = h4[i] / (sra * sb);
     }
     for (int i = 0; i < 4; ++i) {
         out[(4 * g + i) * 16 + r] = c32[i];
         out[256 + (4 * g + i) * 16 + r] = c6[i];
         out[512 + (4 * g + i) * 16 + r] = c3[i];
+        out[768 + (4 * g + i) * 16 + r] = h3[i];
+        out[1024 + (4 * g + i) * 16 + r] = h4[i];
     }
 }
 
@@ -61,24 +97,24 @@ int main() {
             for (auto &x : A) x = mode == 0 ? nd(rng) : (mode == 1 ? ud(rng) : std::exp(6.f * nd(rng)));   // signed / positive / wide range
             for (auto &x : B) x = mode == 1 ? ud(rng) : nd(rng) * (mode == 2 ? std::exp(3.f * nd(rng)) : 1.f);
             float *dA, *dB, *dO;
-            hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dO, 768 * 4);
+            hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dO, 1280 * 4);
             hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
             hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
             k<<<1, 64>>>(dA, dB, K, dO);
-            std::vector<float> O(768);
-            hipMemcpy(O.data(), dO, 768 * 4, hipMemcpyDeviceToHost);
-            double e[3] = {0, 0, 0}, emax[3] = {0, 0, 0};
+            std::vector<float> O(1280);
+            hipMemcpy(O.data(), dO, 1280 * 4, hipMemcpyDeviceToHost);
+            double e[5] = {0, 0, 0, 0, 0}, emax[5] = {0, 0, 0, 0, 0};
             for (int m = 0; m < 16; ++m)
                 for (int n = 0; n < 16; ++n) {
                     double ref = 0, mag = 0;
                     for (int kk = 0; kk < K; ++kk) { ref += (double)A[m * K + kk] * B[kk * 16 + n]; mag += std::fabs((double)A[m * K + kk] * B[kk * 16 + n]); }
-                    for (int v = 0; v < 3; ++v) {
+                    for (int v = 0; v < 5; ++v) {
                         const double err = std::fabs(O[256 * v + m * 16 + n] - ref) / mag;
                         e[v] += err * err / 256; emax[v] = std::max(emax[v], err);
                     }
                 }
-            printf("K=%5d mode=%d  err/sum|ab|  f32 mfma: rms %.2e max %.2e | bf16x6: rms %.2e max %.2e | bf16x3: rms %.2e max %.2e\n", K, mode,
-                   std::sqrt(e[0]), emax[0], std::sqrt(e[1]), emax[1], std::sqrt(e[2]), emax[2]);
+            printf("K=%5d mode=%d  err/sum|ab|  f32 mfma: rms %.2e max %.2e | bf16x6: rms %.2e max %.2e | bf16x3: rms %.2e max %.2e | f16 2 pieces x3: rms %.2e max %.2e | x4: rms %.2e max %.2e\n", K, mode,
+                   std::sqrt(e[0]), emax[0], std::sqrt(e[1]), emax[1], std::sqrt(e[2]), emax[2], std::sqrt(e[3]), emax[3], std::sqrt(e[4]), emax[4]);
             hipFree(dA); hipFree(dB); hipFree(dO);
         }
     }
