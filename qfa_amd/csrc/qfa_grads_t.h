@@ -664,8 +664,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    aq[j][r] *= isc[r >> 1][2 * (r & 1)] * it2[j];
-                    afy[j][r] *= isc[r >> 1][2 * (r & 1) + 1] * it1[j];
+                    aq[j][r] = (aq[j][r] * isc[r >> 1][2 * (r & 1)]) * it2[j];          // (one after the other: the PRODUCT of the
+                    afy[j][r] = (afy[j][r] * isc[r >> 1][2 * (r & 1) + 1]) * it1[j];    // two powers may leave the float32 range)
                 }
         }
         GTS(5)

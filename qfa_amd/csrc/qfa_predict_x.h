@@ -13,11 +13,22 @@
 #include "qfa_common.h"
 #include "qfa_xdl_kernels.h"
 
+#ifndef QFA_PX_F16
+#define QFA_PX_F16 1
+#endif
 template <int KP>
 struct PX {
     static constexpr int KK2 = KP * (KP + 1) / 2;
     static constexpr int NKS = 1 + (KK2 + 31) / 32;          // K-steps: [hmean, 0 | pair products]; 3 at KP = 8, 6 at 16
-    static constexpr int S1_HALF = NKS * 3 * 1024;           // bytes of one 16-pixel half: [K-step][piece][lane][8 k] bf16
+    // Round 5 (QFA_PX_F16): both operands as TWO float16 pieces, three products per K-step (qfa_common.h "float16 pieces").
+    // The image holds t f_a and t^2 f_a f_b with t the pixel's power of two; 1 / t and 1 / t^2 sit as float32 in K-step 0's
+    // h piece, lanes g = 3 (K slots 24..31: they meet the zeros behind hmean).  [hmean] and [hcov'] of a spectrum get powers
+    // of two of their own where the kernel builds its A operand.
+    static constexpr bool F16 = QFA_PX_F16 != 0;
+    static constexpr int NP = F16 ? 2 : 3;                   // pieces per K-step
+    static constexpr int KS_B = NP * 1024;
+    static_assert(!F16 || KP <= 24, "the scales live in K slots 24..31 of K-step 0");
+    static constexpr int S1_HALF = NKS * KS_B;               // bytes of one 16-pixel half: [K-step][piece][lane][8 k]
     static constexpr int TILE_B = 2 * S1_HALF;               // per 32-pixel tile
     static constexpr int NCHUNK = TILE_B / 1024;
 };
@@ -35,38 +46,54 @@ __global__ __launch_bounds__(256) void k_prep_px(const float *__restrict__ F, in
         f[px][a] = (p0 + px < Npix && a < Nh) ? F[(size_t)(p0 + px) * Nh + a] : 0.f;
     }
     __syncthreads();
+    __shared__ float tsc[32][3];                                  // F16: the pixel's power of two t, 1 / t, 1 / t^2
+    if (X::F16 && threadIdx.x < 32) {
+        float mx = 0.f;
+        for (int a = 0; a < KP; ++a) mx = fmaxf(mx, fabsf(f[threadIdx.x][a]));
+        int e = 7;
+        if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);       // t f_a in [2^6, 2^7) for the largest: pairs below 2^14
+        e = e < -50 ? -50 : (e > 60 ? 60 : e);
+        tsc[threadIdx.x][0] = ldexpf(1.f, 7 - e);
+        tsc[threadIdx.x][1] = ldexpf(1.f, e - 7);
+        tsc[threadIdx.x][2] = ldexpf(1.f, 2 * (e - 7));
+    }
+    if (X::F16) __syncthreads();
     for (int i = threadIdx.x; i < 2 * X::NKS * 64; i += 256) {
         const int lane = i & 63, ks = (i >> 6) % X::NKS, h = i / (64 * X::NKS);
         const int lo = lane & 15, g = lane >> 4, px = 2 * lo + h;
+        const float t1 = X::F16 ? tsc[px][0] : 1.f, t2 = t1 * t1;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int kk = 8 * g + j;
             float x = 0.f;
             if (ks == 0) {
-                if (kk < KP) x = f[px][kk];
+                if (kk < KP) x = f[px][kk] * t1;
             } else {
                 const int q = 32 * (ks - 1) + kk;
                 if (q < X::KK2) {
                     int a = 0;
                     while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
                     const int b = a + (q - pair_index(a, a, KP));
-                    x = f[px][a] * f[px][b];
+                    x = f[px][a] * f[px][b] * t2;
                 }
             }
             v[j] = x;
         }
-        u32x4 ph, pm, pl;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned a, b, c;
-            split2(v[2 * q], v[2 * q + 1], a, b, c);
-            ph[q] = a; pm[q] = b; pl[q] = c;
+        unsigned char *dst = tile + h * X::S1_HALF + ks * X::KS_B + lane * 16;
+        if constexpr (X::F16) {
+            u32x4 ph, pm;
+            split8h(v, ph, pm);
+            if (ks == 0 && g == 3) ph = u32x4{__float_as_uint(tsc[px][1]), __float_as_uint(tsc[px][2]), 0u, 0u};
+            *reinterpret_cast<u32x4 *>(dst) = ph;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+        } else {
+            u32x4 ph, pm, pl;
+            split8(v, ph, pm, pl);
+            *reinterpret_cast<u32x4 *>(dst) = ph;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+            *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
         }
-        unsigned char *dst = tile + h * X::S1_HALF + ks * 3072 + lane * 16;
-        *reinterpret_cast<u32x4 *>(dst) = ph;
-        *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
-        *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
     }
 }
 
@@ -91,6 +118,9 @@ __device__ __forceinline__ void px_store2(float *dst, float a, float b) {
 #ifndef QFA_PX_ABL
 #define QFA_PX_ABL 0        // timing-only ablations of the whole-tile path: 1 no stores, 2 no MFMAs, 4 no image DMA behind the first
 #endif
+#ifndef QFA_PX_OCC2
+#define QFA_PX_OCC2 2       // workgroups per CU of the two-groups-per-wave form
+#endif
 #ifndef QFA_PX_SINGLE_B
 #define QFA_PX_SINGLE_B 1
 #endif
@@ -102,7 +132,7 @@ inline bool px_realign(int KP, int Npix, const void *cont, const void *unc) {
 template <int KP, int SPW = 1, bool RA = false>   // SPW: groups of 16 spectra per wave (2: every B-operand read from LDS feeds two
                                                   // MFMA chains); RA: re-aligned stores (N_h <= 8; its own instantiation: 156
                                                   // registers against 92 would cost the aligned shapes their fourth workgroup per CU)
-__global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 : 3) : ((KP == 8 && SPW == 1) ? 4 : 2)) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
+__global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 : 3) : ((KP == 8 && SPW == 1) ? 4 : QFA_PX_OCC2)) void k_predict_x(const float *__restrict__ mu, int B, int Npix, int ntiles,
                                                       WorkPlan wp, const unsigned char *__restrict__ PXI,
                                                       const float *__restrict__ SOL, float *__restrict__ cont,
                                                       float *__restrict__ unc) {
@@ -124,36 +154,73 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
     const bool active = s0 < B;
     const int lo = lane & 15, g = lane >> 4;
     // A operand: spectrum s0 + lo, k = 32 ks + 8 g + j  (SPW = 2: a second set for the spectra s0 + 16 + lo)
-    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::NKS];
-    u32x4 T1h[SPW == 2 ? X::NKS : 1], T1m[SPW == 2 ? X::NKS : 1], T1l[SPW == 2 ? X::NKS : 1];
+    constexpr bool F16 = X::F16;
+    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[F16 ? 1 : X::NKS];
+    u32x4 T1h[SPW == 2 ? X::NKS : 1], T1m[SPW == 2 ? X::NKS : 1], T1l[(SPW == 2 && !F16) ? X::NKS : 1];
+    // F16: the inverse powers of two of the spectra of the lane's OUTPUT rows (4 g + r): hmean, hcov'
+    float ism[SPW][4], isq[SPW][4];
 #pragma unroll
     for (int grp = 0; grp < SPW; ++grp) {
         const bool v = active && (s0 + 16 * grp + lo) < B;
         const float *sol = SOL + (size_t)(v ? s0 + 16 * grp + lo : 0) * C::NSOL;
+        auto value = [&](int ks, int j) __attribute__((always_inline)) {
+            const int kk = 8 * g + j;
+            float val = 0.f;
+            if (ks == 0) {
+                if (v && kk < KP) val = sol[kk];
+            } else {
+                const int q = 32 * (ks - 1) + kk;
+                if (v && q < X::KK2) val = sol[C::SOL_CI + q];
+            }
+            return val;
+        };
+        float scm = 1.f, scq = 1.f;
+        if constexpr (F16) {
+            float mm = 0.f, mq = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < X::NKS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fabsf(value(ks, j));
+                    if (ks == 0) mm = fmaxf(mm, a); else mq = fmaxf(mq, a);
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) { mm = fmaxf(mm, __shfl_xor(mm, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
+            float im, iq;
+            scm = f16_row_scale(mm, im);
+            scq = f16_row_scale(mq, iq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ism[grp][r] = __shfl(im, 4 * g + r); isq[grp][r] = __shfl(iq, 4 * g + r); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ism[grp][r] = isq[grp][r] = 1.f;
+        }
 #pragma unroll
         for (int ks = 0; ks < X::NKS; ++ks) {
             float x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int kk = 8 * g + j;
-                float val = 0.f;
-                if (ks == 0) {
-                    if (v && kk < KP) val = sol[kk];
-                } else {
-                    const int q = 32 * (ks - 1) + kk;
-                    if (v && q < X::KK2) val = sol[C::SOL_CI + q];
-                }
-                x[j] = val;
-            }
+            for (int j = 0; j < 8; ++j) x[j] = value(ks, j) * (ks == 0 ? scm : scq);
+            if constexpr (F16) {
+                u32x4 a, b;
+                split8h(x, a, b);
+                if (grp == 0) { S1h[ks] = a; S1m[ks] = b; }
+                else { T1h[SPW == 2 ? ks : 0] = a; T1m[SPW == 2 ? ks : 0] = b; }
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned a, b, c;
-                split2(x[2 * q], x[2 * q + 1], a, b, c);
-                if (grp == 0) { S1h[ks][q] = a; S1m[ks][q] = b; S1l[ks][q] = c; }
-                else { T1h[SPW == 2 ? ks : 0][q] = a; T1m[SPW == 2 ? ks : 0][q] = b; T1l[SPW == 2 ? ks : 0][q] = c; }
+                for (int q = 0; q < 4; ++q) {
+                    unsigned a, b, c;
+                    split2(x[2 * q], x[2 * q + 1], a, b, c);
+                    if (grp == 0) { S1h[ks][q] = a; S1m[ks][q] = b; S1l[F16 ? 0 : ks][q] = c; }
+                    else { T1h[SPW == 2 ? ks : 0][q] = a; T1m[SPW == 2 ? ks : 0][q] = b; T1l[(SPW == 2 && !F16) ? ks : 0][q] = c; }
+                }
             }
         }
     }
+    // F16: the lane's pixel of half h of the tile in ring slot `img`: 1 / t, 1 / t^2 (k_prep_px)
+    auto pixel_scales = [&](const unsigned char *half) __attribute__((always_inline)) {
+        typedef float f32x2t __attribute__((ext_vector_type(2)));
+        return F16 ? *reinterpret_cast<const f32x2t *>(half + (48 + lo) * 16) : f32x2t{1.f, 1.f};
+    };
     const bool full_wave = active && s0 + 16 * SPW <= B;
     // mu of the lane's two pixels of tile tg, requested one tile ahead by asm loads IN FRONT of the image DMA of that tile:
     // the counted wait that retires the DMA retires them (as ordinary loads in the loop they made hipcc wait vmcnt(0) in
@@ -220,14 +287,27 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
             const unsigned char *bp = lds + slot * X::S1_HALF + lane * 16;
             afy = f32x4{0.f, 0.f, 0.f, 0.f};
             aq = f32x4{0.f, 0.f, 0.f, 0.f};
+            const auto its = pixel_scales(lds + slot * X::S1_HALF);
 #pragma unroll
             for (int ks = 0; ks < X::NKS; ++ks) {
-                const u32x4 bh = *reinterpret_cast<const u32x4 *>(bp + ks * 3072),
-                            bm = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 1024),
-                            bl = *reinterpret_cast<const u32x4 *>(bp + ks * 3072 + 2048);
-                if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
-                else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
+                const u32x4 bh = *reinterpret_cast<const u32x4 *>(bp + ks * X::KS_B),
+                            bm = *reinterpret_cast<const u32x4 *>(bp + ks * X::KS_B + 1024);
+                if constexpr (F16) {
+                    if (ks == 0) afy = xdl3h(S1h[ks], S1m[ks], bh, bm, afy);
+                    else aq = xdl3h(S1h[ks], S1m[ks], bh, bm, aq);
+                } else {
+                    const u32x4 bl = *reinterpret_cast<const u32x4 *>(bp + ks * X::KS_B + 2048);
+                    if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[F16 ? 0 : ks], bh, bm, bl, afy);
+                    else aq = xdl6(S1h[ks], S1m[ks], S1l[F16 ? 0 : ks], bh, bm, bl, aq);
+                }
                 __builtin_amdgcn_sched_barrier(0);           // (four waves per SIMD hide the LDS latency: one B buffer)
+            }
+            if constexpr (F16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    afy[r] = (afy[r] * ism[0][r]) * its[0];
+                    aq[r] = (aq[r] * isq[0][r]) * its[1];
+                }
             }
         };
         for (int c = 0; c < n; ++c) {
@@ -376,29 +456,50 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
             for (int h = 0; h < 2; ++h) {
                 const unsigned char *bp = img + h * X::S1_HALF + lane * 16;
                 f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f}, afy2 = {0.f, 0.f, 0.f, 0.f}, aq2 = {0.f, 0.f, 0.f, 0.f};
-                u32x4 bq[2][3];
+                constexpr int NP = X::NP;
+                u32x4 bq[2][NP];
+                const auto its = pixel_scales(img + h * X::S1_HALF);
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
+                for (int pc = 0; pc < NP; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
 #pragma unroll
                 for (int ks = 0; ks < X::NKS; ++ks) {
                     if (ks + 1 < X::NKS) {
 #pragma unroll
-                        for (int pc = 0; pc < 3; ++pc)
-                            bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
+                        for (int pc = 0; pc < NP; ++pc)
+                            bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * X::KS_B + pc * 1024);
                     }
-                    const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
+                    const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][NP - 1];
                     if (QFA_PX_ABL & 2) {
                         afy[0] += __uint_as_float(bh[0] ^ bm[1] ^ bl[2]);
+                    } else if constexpr (F16) {
+                        f32x4 &c0 = ks == 0 ? afy : aq, &c1 = ks == 0 ? afy2 : aq2;
+                        if constexpr (SPW == 2) {       // two chains alternating (xdl3h's order)
+                            c0 = xdlh(S1h[ks], bm, c0); c1 = xdlh(T1h[ks], bm, c1);
+                            c0 = xdlh(S1m[ks], bh, c0); c1 = xdlh(T1m[ks], bh, c1);
+                            c0 = xdlh(S1h[ks], bh, c0); c1 = xdlh(T1h[ks], bh, c1);
+                        } else c0 = xdl3h(S1h[ks], S1m[ks], bh, bm, c0);
                     } else if constexpr (SPW == 2) {    // two chains alternating (six_terms' order)
                         f32x4 &c0 = ks == 0 ? afy : aq, &c1 = ks == 0 ? afy2 : aq2;
+                        constexpr int kl = F16 ? 0 : ks;
                         c0 = xdl(S1h[ks], bl, c0); c1 = xdl(T1h[ks], bl, c1);
-                        c0 = xdl(S1l[ks], bh, c0); c1 = xdl(T1l[ks], bh, c1);
+                        c0 = xdl(S1l[kl], bh, c0); c1 = xdl(T1l[kl], bh, c1);
                         c0 = xdl(S1m[ks], bm, c0); c1 = xdl(T1m[ks], bm, c1);
                         c0 = xdl(S1m[ks], bh, c0); c1 = xdl(T1m[ks], bh, c1);
                         c0 = xdl(S1h[ks], bm, c0); c1 = xdl(T1h[ks], bm, c1);
                         c0 = xdl(S1h[ks], bh, c0); c1 = xdl(T1h[ks], bh, c1);
-                    } else if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
-                    else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
+                    } else if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[F16 ? 0 : ks], bh, bm, bl, afy);
+                    else aq = xdl6(S1h[ks], S1m[ks], S1l[F16 ? 0 : ks], bh, bm, bl, aq);
+                }
+                if constexpr (F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        afy[r] = (afy[r] * ism[0][r]) * its[0];
+                        aq[r] = (aq[r] * isq[0][r]) * its[1];
+                        if (SPW == 2) {
+                            afy2[r] = (afy2[r] * ism[SPW - 1][r]) * its[0];
+                            aq2[r] = (aq2[r] * isq[SPW - 1][r]) * its[1];
+                        }
+                    }
                 }
                 const float m = mc[h];
 #pragma unroll

@@ -2,7 +2,7 @@
 //   (a) v_mfma_f32_16x16x4_f32 (exact f32 fma chain), (b) operands split into three bf16 pieces (RNE), six
 //   v_mfma_f32_16x16x32_bf16 per K-step of 32 (hh, hm, mh, hl, lh, mm; small terms first), (c) the 3-term
 //   variant (hh, hm, mh), (d) round 5: operands split into TWO f16 pieces (11 + 11 bits; rows of A and columns of B scaled by a power
-//   of two so that their largest element is in [1, 2): f16 has 5 exponent bits), three v_mfma_f32_16x16x32_f16 (hm, mh, hh) and (e)
+//   of two so that their largest element is in [2^13, 2^14): f16 has 5 exponent bits), three v_mfma_f32_16x16x32_f16 (hm, mh, hh) and (e)
 //   four (+ mm).  Reference: float64 on the host.
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -47,7 +47,7 @@ __global__ void k(const float *A, const float *B, int K, float *out) {     // A 
     for (int kk = 0; kk < K; ++kk) { amax = fmaxf(amax, fabsf(A[r * K + kk])); bmax = fmaxf(bmax, fabsf(B[kk * 16 + r])); }
     int ea, eb;
     frexpf(amax, &ea); frexpf(bmax, &eb);
-    const float sa = ldexpf(1.f, 1 - ea), sb = ldexpf(1.f, 1 - eb);
+    const float sa = ldexpf(1.f, 14 - ea), sb = ldexpf(1.f, 14 - eb);      // largest element in [2^13, 2^14), as the product path does
     for (int k0 = 0; k0 < K; k0 += 4) c32 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * K + k0 + g], B[(k0 + g) * 16 + r], c32, 0, 0, 0);
     for (int k0 = 0; k0 < K; k0 += 32) {
         u32x4 ah, am, al, bh, bm, bl;
@@ -90,12 +90,12 @@ __global__ void k(const float *A, const float *B, int K, float *out) {     // A 
 int main() {
     std::mt19937 rng(7);
     for (int K : {32, 512, 4096}) {
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             std::vector<float> A(16 * K), B(K * 16);
             std::normal_distribution<float> nd(0.f, 1.f);
             std::uniform_real_distribution<float> ud(0.f, 1.f);
-            for (auto &x : A) x = mode == 0 ? nd(rng) : (mode == 1 ? ud(rng) : std::exp(6.f * nd(rng)));   // signed / positive / wide range
-            for (auto &x : B) x = mode == 1 ? ud(rng) : nd(rng) * (mode == 2 ? std::exp(3.f * nd(rng)) : 1.f);
+            for (auto &x : A) x = mode == 0 ? nd(rng) : (mode == 1 ? ud(rng) : std::exp((mode == 2 ? 6.f : 2.f) * nd(rng)));   // signed / positive / wide range (2: e^(6 N), 3: e^(2 N))
+            for (auto &x : B) x = mode == 1 ? ud(rng) : nd(rng) * (mode == 2 ? std::exp(3.f * nd(rng)) : (mode == 3 ? std::exp(1.5f * nd(rng)) : 1.f));
             float *dA, *dB, *dO;
             hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dO, 1280 * 4);
             hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
