@@ -28,13 +28,23 @@
 #define QFA_S12_ABL 0        // timing-only ablations: 1 no beta / gamma stores, 2 no spectra loads (and their share of the waits), 4 no stage 2, 8 staging from cache
 #endif
 typedef float s12_f32x2 __attribute__((ext_vector_type(2)));
+#ifndef QFA_S12_F16
+#define QFA_S12_F16 1
+#endif
 template <int KP>
 struct S12 {
     static constexpr int KK2 = KP * (KP + 1) / 2;
     static constexpr int NKS = 1 + (KK2 + 31) / 32;          // 18 at KP = 32
     static_assert(NKS % 2 == 0, "two quarters of NKS / 2 K-steps");
     static constexpr int NKQ = NKS / 2;                        // K-steps per quarter
-    static constexpr int Q_B = NKQ * 3 * 1024;                 // bytes of a quarter image (27 KiB)
+    // Round 5 (QFA_S12_F16): stage 1 on TWO float16 pieces per operand and three products per K-step (qfa_common.h "float16
+    // pieces"): 54 MFMAs per 16 spectra x 16 pixels instead of 108.  The image holds t f_a and t^2 f_a f_b (t: the pixel's power of
+    // two, 1 / t and 1 / t^2 in the half's parameter KiB, floats 80.. and 96..); [y] and [C^-1'] (the writer: [hmean], [hcov'])
+    // of a spectrum get powers of two of their own where the kernels build their A operand.
+    static constexpr bool F16 = QFA_S12_F16 != 0;
+    static constexpr int NP = F16 ? 2 : 3;                     // pieces per K-step
+    static constexpr int KS_B = NP * 1024;
+    static constexpr int Q_B = NKQ * KS_B;                     // bytes of a quarter image (18 KiB; bf16 pieces: 27)
     static constexpr int SLOT_B = Q_B + 1024;                  // ring slot: + Psi[16], omega[16] of the half (float32, one KiB)
     static constexpr int HALF_B = 2 * Q_B + 1024;              // global: [quarter 0 | Psi/omega KiB | quarter 1]
     static constexpr int TILE_B = 2 * HALF_B;                  // 110 KiB per 32-pixel tile
@@ -61,39 +71,54 @@ __global__ __launch_bounds__(256) void k_prep_s12(const float *__restrict__ F, c
         f[px][a] = (p0 + px < Npix && a < Nh) ? F[(size_t)(p0 + px) * Nh + a] : 0.f;
     }
     __syncthreads();
+    __shared__ float tsc[32][3];                                  // F16: the pixel's power of two t, 1 / t, 1 / t^2
+    if (X::F16 && threadIdx.x < 32) {
+        float mx = 0.f;
+        for (int a = 0; a < KP; ++a) mx = fmaxf(mx, fabsf(f[threadIdx.x][a]));
+        int e = 7;
+        if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);       // t f_a in [2^6, 2^7) for the largest: pairs below 2^14
+        e = e < -50 ? -50 : (e > 60 ? 60 : e);
+        tsc[threadIdx.x][0] = ldexpf(1.f, 7 - e);
+        tsc[threadIdx.x][1] = ldexpf(1.f, e - 7);
+        tsc[threadIdx.x][2] = ldexpf(1.f, 2 * (e - 7));
+    }
+    if (X::F16) __syncthreads();
     for (int i = threadIdx.x; i < 2 * X::NKS * 64; i += 256) {
         const int lane = i & 63, ks = (i >> 6) % X::NKS, h = i / (64 * X::NKS);
         const int lo = lane & 15, g = lane >> 4, px = 2 * lo + h;
+        const float t1 = X::F16 ? tsc[px][0] : 1.f, t2 = t1 * t1;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int kk = 8 * g + j;
             float x = 0.f;
             if (ks == 0) {
-                if (kk < KP) x = f[px][kk];
+                if (kk < KP) x = f[px][kk] * t1;
             } else {
                 const int q = 32 * (ks - 1) + kk;
                 if (q < X::KK2) {
                     int a = 0;
                     while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
                     const int b = a + (q - pair_index(a, a, KP));
-                    x = f[px][a] * f[px][b];
+                    x = f[px][a] * f[px][b] * t2;
                 }
             }
             v[j] = x;
         }
-        u32x4 ph, pm, pl;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned a, b, c;
-            split2(v[2 * q], v[2 * q + 1], a, b, c);
-            ph[q] = a; pm[q] = b; pl[q] = c;
-        }
         const int qt = ks / X::NKQ, kq = ks % X::NKQ;
-        unsigned char *dst = tile + h * X::HALF_B + qt * (X::Q_B + 1024) + kq * 3072 + lane * 16;
-        *reinterpret_cast<u32x4 *>(dst) = ph;
-        *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
-        *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+        unsigned char *dst = tile + h * X::HALF_B + qt * (X::Q_B + 1024) + kq * X::KS_B + lane * 16;
+        if constexpr (X::F16) {
+            u32x4 ph, pm;
+            split8h(v, ph, pm);
+            *reinterpret_cast<u32x4 *>(dst) = ph;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+        } else {
+            u32x4 ph, pm, pl;
+            split8(v, ph, pm, pl);
+            *reinterpret_cast<u32x4 *>(dst) = ph;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+            *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+        }
     }
     for (int i = threadIdx.x; i < 512; i += 256) {            // Psi, omega of each half's pixels (+ zero padding of the KiB)
         const int h = i >> 8, j = i & 255;
@@ -105,7 +130,7 @@ __global__ __launch_bounds__(256) void k_prep_s12(const float *__restrict__ F, c
         else if (j < 80 && ZP && px < Nb) {                 // factored-z form: ti | pwi | l2i of the half's pixels
             const float4 q = ZP[px];
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
-        }
+        } else if (X::F16 && j >= 80 && j < 112) v = tsc[2 * (j & 15) + h][j < 96 ? 1 : 2];
         po[j] = v;
     }
 }
@@ -143,31 +168,46 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
     for (int i = tid; i < 2 * 4 * 4 * 32; i += 256) (&lpsum[0][0][0][0])[i] = 0.f;      // inactive waves' rows stay 0
 
     // A operand of stage 1: spectrum s0 + lo, k = 32 ks + 8 g + j
-    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::NKS];
+    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::F16 ? 1 : X::NKS];
+    float is0[4] = {1.f, 1.f, 1.f, 1.f}, is1[4] = {1.f, 1.f, 1.f, 1.f};      // F16: inverse powers of two of the spectra 4 g + r (y | C^-1')
     {
         const bool v = active && (s0 + lo) < B;
         const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+        auto value = [&](int ks, int kk) __attribute__((always_inline)) {
+            float val = 0.f;
+            if (ks == 0) {
+                if (v && kk < KP) val = sol[kk];
+            } else {
+                const int qq = 32 * (ks - 1) + kk;
+                if (v && qq < X::KK2) val = sol[C::SOL_CI + qq];
+            }
+            return val;
+        };
+        float sc0 = 1.f, sc1 = 1.f;                              // powers of two of the spectrum's K-step 0 values / its pair values
+        if constexpr (X::F16) {
+            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < X::NKS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fabsf(value(ks, 8 * g + j));
+                    if (ks == 0) m0 = fmaxf(m0, a); else m1 = fmaxf(m1, a);
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+            float i0, i1;
+            sc0 = f16_row_scale(m0, i0);
+            sc1 = f16_row_scale(m1, i1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { is0[r] = __shfl(i0, 4 * g + r); is1[r] = __shfl(i1, 4 * g + r); }
+        }
 #pragma unroll
         for (int ks = 0; ks < X::NKS; ++ks) {
+            float x[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float x[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int kk = 8 * g + 2 * q + e;
-                    float val = 0.f;
-                    if (ks == 0) {
-                        if (v && kk < KP) val = sol[kk];
-                    } else {
-                        const int qq = 32 * (ks - 1) + kk;
-                        if (v && qq < X::KK2) val = sol[C::SOL_CI + qq];
-                    }
-                    x[e] = val;
-                }
-                unsigned a, b, c;
-                split2(x[0], x[1], a, b, c);
-                S1h[ks][q] = a; S1m[ks][q] = b; S1l[ks][q] = c;
-            }
+            for (int j = 0; j < 8; ++j) x[j] = value(ks, 8 * g + j) * (ks == 0 ? sc0 : sc1);
+            if constexpr (X::F16) split8h(x, S1h[ks], S1m[ks]);
+            else split8(x, S1h[ks], S1m[ks], S1l[ks]);
         }
     }
     bool sv[4];
@@ -269,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
 
     double s_tau0 = 0.0, s_c0 = 0.0, s_beta = 0.0;
     f32x4 afy, aq;
-    float PsiH = 0.f, omH = 0.f, tiH = 0.f, pwiH = 0.f, l2iH = 0.f;
+    float PsiH = 0.f, omH = 0.f, tiH = 0.f, pwiH = 0.f, l2iH = 0.f, it1H = 1.f, it2H = 1.f;
     ZFac zs[4];                                   // factored-z form: per-spectrum factors of the lane's four spectra
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[r] = zfac_load(ZS, s0 + 4 * g + r, ZF && sv[r]);
@@ -284,28 +324,49 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
             const float *po = reinterpret_cast<const float *>(img + X::Q_B);
             PsiH = po[lo];
             omH = po[16 + lo];
+            if (X::F16) { it1H = po[80 + lo]; it2H = po[96 + lo]; }
             if (ZF) { tiH = po[32 + lo]; pwiH = po[48 + lo]; l2iH = po[64 + lo]; }
         }
-        u32x4 bq[2][3];
+        constexpr int NP = X::NP;
+        u32x4 bq[2][NP];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
+        for (int pc = 0; pc < NP; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
 #pragma unroll
         for (int kq = 0; kq < X::NKQ; ++kq) {
             if (kq + 1 < X::NKQ) {
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    bq[(kq + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (kq + 1) * 3072 + pc * 1024);
+                for (int pc = 0; pc < NP; ++pc)
+                    bq[(kq + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (kq + 1) * X::KS_B + pc * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const u32x4 &bh = bq[kq & 1][0], &bm = bq[kq & 1][1], &bl = bq[kq & 1][2];
+            const u32x4 &bh = bq[kq & 1][0], &bm = bq[kq & 1][1], &bl = bq[kq & 1][NP - 1];
             // (ks = NKQ j + kq is a compile-time constant per (j, kq): j is passed as a literal below)
-            if (j == 0) {
-                if (kq == 0) afy = xdl6(S1h[0], S1m[0], S1l[0], bh, bm, bl, afy);
-                else aq = xdl6(S1h[kq], S1m[kq], S1l[kq], bh, bm, bl, aq);
+            if constexpr (X::F16) {
+                if (j == 0) {
+                    if (kq == 0) afy = xdl3h(S1h[0], S1m[0], bh, bm, afy);
+                    else aq = xdl3h(S1h[kq], S1m[kq], bh, bm, aq);
+                } else {
+                    aq = xdl3h(S1h[X::NKQ + kq], S1m[X::NKQ + kq], bh, bm, aq);
+                }
             } else {
-                aq = xdl6(S1h[X::NKQ + kq], S1m[X::NKQ + kq], S1l[X::NKQ + kq], bh, bm, bl, aq);
+                constexpr int L0 = X::F16 ? 0 : 1;
+                if (j == 0) {
+                    if (kq == 0) afy = xdl6(S1h[0], S1m[0], S1l[0], bh, bm, bl, afy);
+                    else aq = xdl6(S1h[kq], S1m[kq], S1l[L0 * kq], bh, bm, bl, aq);
+                } else {
+                    aq = xdl6(S1h[X::NKQ + kq], S1m[X::NKQ + kq], S1l[L0 * (X::NKQ + kq)], bh, bm, bl, aq);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (X::F16) {
+            if (j == 1) {                      // the powers of two back in: element r <-> spectrum 4 g + r, the lane's pixel
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    afy[r] = (afy[r] * is0[r]) * it1H;
+                    aq[r] = (aq[r] * is1[r]) * it2H;
+                }
+            }
         }
     };
 
@@ -427,7 +488,9 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
         if (4 * n > 1) get_quarter(1);
         dma_wait<0>();
         step_barrier();
-        auto cnt_q = [&](int u) { return wv == 3 ? 6 + ((u & 1) ? 0 : 1) : 7; };      // pieces of quarter u moved by this wave
+        // pieces of quarter u moved by this wave (get_quarter: wave w moves the pieces w, w + 4, ...; piece NCH = the parameter KiB, j = 0)
+        constexpr int NCHQ = X::Q_B / 1024;
+        auto cnt_q = [&](int u) { return (NCHQ - wv + 3) / 4 + ((NCHQ % 4 == wv && !(u & 1)) ? 1 : 0); };
         int rest_prev = 0;                          // requests of the previous sub-step behind its image DMA
         Spec cur;
         auto tile_step = [&](int c, int &stag_cur) {
@@ -528,31 +591,46 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
     const int n = t1 - t0;
     if (n <= 0) return;
 
-    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::NKS];               // A operand: spectrum s0 + lo, k = 32 ks + 8 g + j
+    u32x4 S1h[X::NKS], S1m[X::NKS], S1l[X::F16 ? 1 : X::NKS];   // A operand: spectrum s0 + lo, k = 32 ks + 8 g + j
+    float is0[4] = {1.f, 1.f, 1.f, 1.f}, is1[4] = {1.f, 1.f, 1.f, 1.f};      // F16: inverse powers of two of the spectra 4 g + r (hmean | hcov')
     {
         const bool v = active && (s0 + lo) < B;
         const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+        auto value = [&](int ks, int kk) __attribute__((always_inline)) {
+            float val = 0.f;
+            if (ks == 0) {
+                if (v && kk < KP) val = sol[kk];
+            } else {
+                const int qq = 32 * (ks - 1) + kk;
+                if (v && qq < X::KK2) val = sol[C::SOL_CI + qq];
+            }
+            return val;
+        };
+        float sc0 = 1.f, sc1 = 1.f;                              // powers of two of the spectrum's K-step 0 values / its pair values
+        if constexpr (X::F16) {
+            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < X::NKS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fabsf(value(ks, 8 * g + j));
+                    if (ks == 0) m0 = fmaxf(m0, a); else m1 = fmaxf(m1, a);
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+            float i0, i1;
+            sc0 = f16_row_scale(m0, i0);
+            sc1 = f16_row_scale(m1, i1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { is0[r] = __shfl(i0, 4 * g + r); is1[r] = __shfl(i1, 4 * g + r); }
+        }
 #pragma unroll
         for (int ks = 0; ks < X::NKS; ++ks) {
+            float x[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float x[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int kk = 8 * g + 2 * q + e;
-                    float val = 0.f;
-                    if (ks == 0) {
-                        if (v && kk < KP) val = sol[kk];
-                    } else {
-                        const int qq = 32 * (ks - 1) + kk;
-                        if (v && qq < X::KK2) val = sol[C::SOL_CI + qq];
-                    }
-                    x[e] = val;
-                }
-                unsigned a, b, c;
-                split2(x[0], x[1], a, b, c);
-                S1h[ks][q] = a; S1m[ks][q] = b; S1l[ks][q] = c;
-            }
+            for (int j = 0; j < 8; ++j) x[j] = value(ks, 8 * g + j) * (ks == 0 ? sc0 : sc1);
+            if constexpr (X::F16) split8h(x, S1h[ks], S1m[ks]);
+            else split8(x, S1h[ks], S1m[ks], S1l[ks]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the operand loads above are the only tracked loads)
@@ -577,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
         }
     };
     f32x4 afy, aq;
-    float muH = 0.f;
+    float muH = 0.f, it1H = 1.f, it2H = 1.f;
     auto quarter = [&](auto jtag, const unsigned char *img) {
         constexpr int j = decltype(jtag)::value;
         const unsigned char *bp = img + lane * 16;
@@ -585,26 +663,47 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
             afy = f32x4{0.f, 0.f, 0.f, 0.f};
             aq = f32x4{0.f, 0.f, 0.f, 0.f};
             muH = reinterpret_cast<const float *>(img + X::Q_B)[lo];
+            if (X::F16) { it1H = reinterpret_cast<const float *>(img + X::Q_B)[80 + lo]; it2H = reinterpret_cast<const float *>(img + X::Q_B)[96 + lo]; }
         }
-        u32x4 bq[2][3];
+        constexpr int NP = X::NP;
+        u32x4 bq[2][NP];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
+        for (int pc = 0; pc < NP; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
 #pragma unroll
         for (int kq = 0; kq < X::NKQ; ++kq) {
             if (kq + 1 < X::NKQ) {
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    bq[(kq + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (kq + 1) * 3072 + pc * 1024);
+                for (int pc = 0; pc < NP; ++pc)
+                    bq[(kq + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (kq + 1) * X::KS_B + pc * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const u32x4 &bh = bq[kq & 1][0], &bm = bq[kq & 1][1], &bl = bq[kq & 1][2];
-            if (j == 0) {
-                if (kq == 0) afy = xdl6(S1h[0], S1m[0], S1l[0], bh, bm, bl, afy);
-                else aq = xdl6(S1h[kq], S1m[kq], S1l[kq], bh, bm, bl, aq);
+            const u32x4 &bh = bq[kq & 1][0], &bm = bq[kq & 1][1], &bl = bq[kq & 1][NP - 1];
+            if constexpr (X::F16) {
+                if (j == 0) {
+                    if (kq == 0) afy = xdl3h(S1h[0], S1m[0], bh, bm, afy);
+                    else aq = xdl3h(S1h[kq], S1m[kq], bh, bm, aq);
+                } else {
+                    aq = xdl3h(S1h[X::NKQ + kq], S1m[X::NKQ + kq], bh, bm, aq);
+                }
             } else {
-                aq = xdl6(S1h[X::NKQ + kq], S1m[X::NKQ + kq], S1l[X::NKQ + kq], bh, bm, bl, aq);
+                constexpr int L0 = X::F16 ? 0 : 1;
+                if (j == 0) {
+                    if (kq == 0) afy = xdl6(S1h[0], S1m[0], S1l[0], bh, bm, bl, afy);
+                    else aq = xdl6(S1h[kq], S1m[kq], S1l[L0 * kq], bh, bm, bl, aq);
+                } else {
+                    aq = xdl6(S1h[X::NKQ + kq], S1m[X::NKQ + kq], S1l[L0 * (X::NKQ + kq)], bh, bm, bl, aq);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (X::F16) {
+            if (j == 1) {                      // the powers of two back in: element r <-> spectrum 4 g + r, the lane's pixel
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    afy[r] = (afy[r] * is0[r]) * it1H;
+                    aq[r] = (aq[r] * is1[r]) * it2H;
+                }
+            }
         }
     };
 
@@ -612,7 +711,8 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
     if (4 * n > 1) get_quarter(1);
     dma_wait<0>();
     step_barrier();
-    auto cnt_q = [&](int u) { return wv == 3 ? 6 + ((u & 1) ? 0 : 1) : 7; };      // pieces of quarter u moved by this wave
+    constexpr int NCHQ = X::Q_B / 1024;            // pieces of quarter u moved by this wave (see k_s12_x)
+    auto cnt_q = [&](int u) { return (NCHQ - wv + 3) / 4 + ((NCHQ % 4 == wv && !(u & 1)) ? 1 : 0); };
     int rest_prev = 0;                              // stores of the previous sub-step, behind its image DMA in the queue
     float co0[4], un0[4];
     for (int c = 0; c < n; ++c) {
