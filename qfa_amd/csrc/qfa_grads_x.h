@@ -49,11 +49,19 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef QFA_GX_F16
+#define QFA_GX_F16 1
+#endif
 template <int KP_>
 struct GXT {                                             // KP = 16 (N_h = 9..16) or 8 (N_h <= 8)
     static constexpr int KP = KP_, KK2 = KP * (KP + 1) / 2;
     static constexpr int NKS = 1 + (KK2 + 31) / 32;      // K-steps of stage 1: [y, 0 | pair products, 32 per step]: 6 / 3
-    static constexpr int S1_HALF = NKS * 3 * 1024;       // bytes of the stage-1 image of one 16-pixel half
+    // Round 5 (QFA_GX_F16): stage 1 on TWO float16 pieces per operand, three products per K-step (qfa_common.h "float16 pieces");
+    // the image holds t f_a and t^2 f_a f_b, 1 / t and 1 / t^2 of a half's pixels in its parameter KiB (floats 80.., 96..)
+    static constexpr bool F16 = QFA_GX_F16 != 0;
+    static constexpr int NP = F16 ? 2 : 3;               // pieces per K-step
+    static constexpr int KS_B = NP * 1024;
+    static constexpr int S1_HALF = NKS * KS_B;           // bytes of the stage-1 image of one 16-pixel half
     static constexpr int HALF_B = S1_HALF + 1024;        // ring slot: + float32 Psi[16], omega[16] of its pixels (19 / 10 KiB)
     static constexpr int OFF_FP = 2 * HALF_B;            // F as bf16 pieces, A operand of stage 3: [piece][lane][8 a]
     static constexpr int TILE_B = OFF_FP + 3 * 1024;     // 41 / 23 KiB per 32-pixel tile in global memory
@@ -119,33 +127,53 @@ __device__ __forceinline__ void prep_pgx_body(int bid, const float *__restrict__
         f[px][a] = (p0 + px < Npix && a < Nh) ? F[(size_t)(p0 + px) * Nh + a] : 0.f;
     }
     __syncthreads();
+    __shared__ float tsc[32][3];                                  // F16: the pixel's power of two t, 1 / t, 1 / t^2
+    if (GX::F16 && threadIdx.x < 32) {
+        float mx = 0.f;
+        for (int a = 0; a < KP; ++a) mx = fmaxf(mx, fabsf(f[threadIdx.x][a]));
+        int e = 7;
+        if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);       // t f_a in [2^6, 2^7) for the largest: pairs below 2^14
+        e = e < -50 ? -50 : (e > 60 ? 60 : e);
+        tsc[threadIdx.x][0] = ldexpf(1.f, 7 - e);
+        tsc[threadIdx.x][1] = ldexpf(1.f, e - 7);
+        tsc[threadIdx.x][2] = ldexpf(1.f, 2 * (e - 7));
+    }
+    if (GX::F16) __syncthreads();
     for (int i = threadIdx.x; i < 2 * GX::NKS * 64; i += 256) {
         const int lane = i & 63, ks = (i >> 6) % GX::NKS, h = i / (64 * GX::NKS);
         const int lo = lane & 15, g = lane >> 4, px = 2 * lo + h;
+        const float t1 = GX::F16 ? tsc[px][0] : 1.f, t2 = t1 * t1;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int kk = 8 * g + j;
             float x = 0.f;
             if (ks == 0) {
-                if (kk < KP) x = f[px][kk];
+                if (kk < KP) x = f[px][kk] * t1;
             } else {
                 const int q = 32 * (ks - 1) + kk;
                 if (q < GX::KK2) {
                     int a = 0;
                     while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
                     const int b = a + (q - pair_index(a, a, KP));
-                    x = f[px][a] * f[px][b];
+                    x = f[px][a] * f[px][b] * t2;
                 }
             }
             v[j] = x;
         }
-        u32x4 ph, pm, pl;
-        split8(v, ph, pm, pl);
-        unsigned char *dst = tile + h * GX::HALF_B + ks * 3072 + lane * 16;
-        *reinterpret_cast<u32x4 *>(dst) = ph;
-        *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
-        *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+        unsigned char *dst = tile + h * GX::HALF_B + ks * GX::KS_B + lane * 16;
+        if constexpr (GX::F16) {
+            u32x4 ph, pm;
+            split8h(v, ph, pm);
+            *reinterpret_cast<u32x4 *>(dst) = ph;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+        } else {
+            u32x4 ph, pm, pl;
+            split8(v, ph, pm, pl);
+            *reinterpret_cast<u32x4 *>(dst) = ph;
+            *reinterpret_cast<u32x4 *>(dst + 1024) = pm;
+            *reinterpret_cast<u32x4 *>(dst + 2048) = pl;
+        }
     }
     // Psi, omega of each half's 16 pixels (+ zero padding of the KiB)
     for (int i = threadIdx.x; i < 512; i += 256) {
@@ -158,7 +186,7 @@ __device__ __forceinline__ void prep_pgx_body(int bid, const float *__restrict__
         else if (j < 80 && ZP.on() && px < Nb) {            // factored-z form: ti | pwi | l2i of the half's pixels
             const float4 q = ZP.at(px);
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
-        }
+        } else if (GX::F16 && j >= 80 && j < 112) v = tsc[2 * (j & 15) + h][j < 96 ? 1 : 2];
         po[j] = v;
     }
     if (wform) {       // stage 3 in its W form (role B, TERMS = 6): F of the tile as float32 rows [pixel 0..31][FROW]
@@ -273,26 +301,50 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
         // ================================================================ role A: stage 1 + stage 2
         const int lo = lane & 15, g = lane >> 4;
         // A operand of stage 1: spectrum s0 + lo, k = 32 ks + 8 g + j
-        u32x4 S1h[GX::NKS], S1m[GX::NKS], S1l[GX::NKS];
+        u32x4 S1h[GX::NKS], S1m[GX::NKS], S1l[GX::F16 ? 1 : GX::NKS];
+        float is0[4] = {1.f, 1.f, 1.f, 1.f}, is1[4] = {1.f, 1.f, 1.f, 1.f};      // F16: inverse powers of two of the spectra 4 g + r (y | C^-1')
         {
             const bool v = active && (s0 + lo) < B;
             const float *sol = SOL + (size_t)(v ? s0 + lo : 0) * C::NSOL;
+            auto value = [&](int ks, int kk) __attribute__((always_inline)) {
+                float val = 0.f;
+                if (ks == 0) {
+                    if (v && kk < KP) val = sol[kk];
+                } else {
+                    const int q = 32 * (ks - 1) + kk;
+                    if (v && q < GX::KK2) val = sol[C::SOL_CI + q];
+                }
+                return val;
+            };
+            float xs[GX::NKS][8];                         // (read once: small batches are latency-bound)
+#pragma unroll
+            for (int ks = 0; ks < GX::NKS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xs[ks][j] = value(ks, 8 * g + j);
+            float sc0 = 1.f, sc1 = 1.f;
+            if constexpr (GX::F16) {
+                float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < GX::NKS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (ks == 0) m0 = fmaxf(m0, fabsf(xs[ks][j])); else m1 = fmaxf(m1, fabsf(xs[ks][j]));
+                    }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+                float i0, i1;
+                sc0 = f16_row_scale(m0, i0);
+                sc1 = f16_row_scale(m1, i1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { is0[r] = __shfl(i0, 4 * g + r); is1[r] = __shfl(i1, 4 * g + r); }
+            }
 #pragma unroll
             for (int ks = 0; ks < GX::NKS; ++ks) {
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int kk = 8 * g + j;
-                    float val = 0.f;
-                    if (ks == 0) {
-                        if (v && kk < KP) val = sol[kk];
-                    } else {
-                        const int q = 32 * (ks - 1) + kk;
-                        if (v && q < GX::KK2) val = sol[C::SOL_CI + q];
-                    }
-                    x[j] = val;
-                }
-                split8(x, S1h[ks], S1m[ks], S1l[ks]);
+                for (int j = 0; j < 8; ++j) x[j] = xs[ks][j] * (ks == 0 ? sc0 : sc1);
+                if constexpr (GX::F16) split8h(x, S1h[ks], S1m[ks]);
+                else split8(x, S1h[ks], S1m[ks], S1l[ks]);
             }
         }
         bool sv[4];
@@ -441,21 +493,36 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             const unsigned char *img = lds + GX::L_IMG + slot * GX::HALF_B;
             const unsigned char *bp = img + lane * 16;
             f32x4 afy = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
-            u32x4 bq[2][3];
+            constexpr int NP = GX::NP;
+            u32x4 bq[2][NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
+            for (int pc = 0; pc < NP; ++pc) bq[0][pc] = *reinterpret_cast<const u32x4 *>(bp + pc * 1024);
 #pragma unroll
             for (int ks = 0; ks < GX::NKS; ++ks) {
                 if (ks + 1 < GX::NKS) {
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc)
-                        bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * 3072 + pc * 1024);
+                    for (int pc = 0; pc < NP; ++pc)
+                        bq[(ks + 1) & 1][pc] = *reinterpret_cast<const u32x4 *>(bp + (ks + 1) * GX::KS_B + pc * 1024);
                 }
-                const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][2];
-                if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, afy);
-                else aq = xdl6(S1h[ks], S1m[ks], S1l[ks], bh, bm, bl, aq);
+                const u32x4 &bh = bq[ks & 1][0], &bm = bq[ks & 1][1], &bl = bq[ks & 1][NP - 1];
+                if constexpr (GX::F16) {
+                    if (ks == 0) afy = xdl3h(S1h[ks], S1m[ks], bh, bm, afy);
+                    else aq = xdl3h(S1h[ks], S1m[ks], bh, bm, aq);
+                } else {
+                    constexpr int L0 = GX::F16 ? 0 : 1;
+                    if (ks == 0) afy = xdl6(S1h[ks], S1m[ks], S1l[L0 * ks], bh, bm, bl, afy);
+                    else aq = xdl6(S1h[ks], S1m[ks], S1l[L0 * ks], bh, bm, bl, aq);
+                }
             }
             const float *po = reinterpret_cast<const float *>(img + GX::S1_HALF);
+            if constexpr (GX::F16) {           // the powers of two back in: element r <-> spectrum 4 g + r, the lane's pixel
+                const float it1 = po[80 + lo], it2 = po[96 + lo];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    afy[r] = (afy[r] * is0[r]) * it1;
+                    aq[r] = (aq[r] * is1[r]) * it2;
+                }
+            }
             pp.Psi = po[lo]; pp.om = po[16 + lo];
             pp.ti = pp.pwi = pp.l2i = 0.f;
             if (ZF) { pp.ti = po[32 + lo]; pp.pwi = po[48 + lo]; pp.l2i = po[64 + lo]; }

@@ -174,6 +174,11 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
             }
             return val;
         };
+        float xs[X::NKS][8];                              // (read once)
+#pragma unroll
+        for (int ks = 0; ks < X::NKS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[ks][j] = value(ks, j);
         float scm = 1.f, scq = 1.f;
         if constexpr (F16) {
             float mm = 0.f, mq = 0.f;
@@ -181,8 +186,7 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
             for (int ks = 0; ks < X::NKS; ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float a = fabsf(value(ks, j));
-                    if (ks == 0) mm = fmaxf(mm, a); else mq = fmaxf(mq, a);
+                    if (ks == 0) mm = fmaxf(mm, fabsf(xs[ks][j])); else mq = fmaxf(mq, fabsf(xs[ks][j]));
                 }
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) { mm = fmaxf(mm, __shfl_xor(mm, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256, (KP == 16 && SPW == 1) ? (QFA_PX_SINGLE_B ? 4 
         for (int ks = 0; ks < X::NKS; ++ks) {
             float x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = value(ks, j) * (ks == 0 ? scm : scq);
+            for (int j = 0; j < 8; ++j) x[j] = xs[ks][j] * (ks == 0 ? scm : scq);
             if constexpr (F16) {
                 u32x4 a, b;
                 split8h(x, a, b);
