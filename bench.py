@@ -20,9 +20,10 @@ touches the GPU) and relays rank 0's line.  Rank 0 prints ONE JSON line.
 
 `roofline` describes the dominant kernel (pass 2: at N_h = 9..16 k_grads_t from 96 spectra per CU on and k_grads_x below,
 k_grads / k_grads_x at N_h <= 8, the three launches k_s12_x + 2 k_grads_s3 at N_h = 17..32; its mean duration is measured with HIP events recorded by the library on the
-launch stream inside the timed region).  The contractions are float32 products ISSUED as bf16 piece products on the XDL
-pipe (operands split into three bf16 pieces, six products per float32 product: DESIGN.md section 4), so `achieved` =
-the issued bf16 flops per launch / duration and `peak` = the dense bf16 MFMA peak (2.5 PFLOP/s); the algorithmic float32
+launch stream inside the timed region).  The contractions are float32 products ISSUED as 16-bit piece products on the XDL
+pipe (pass 1 and stage 3 of pass 2: operands split into three bf16 pieces, six products per float32 product; stage 1 of pass 2
+and of the writer, round 5: two float16 pieces, three products: DESIGN.md section 4), so `achieved` =
+the issued 16-bit flops per launch / duration and `peak` = the dense bf16 / f16 MFMA peak (2.5 PFLOP/s); the algorithmic float32
 flops against the float32 roof the survey names are kept as `achieved_alg_fp32` / `frac_vs_fp32_roof` (that fraction can
 exceed 1: the kernel does not run on that pipe).  `step_roofline` holds the step's HBM side: algorithmic bytes, the
 measured bytes (profiles/traffic_<config>.json, rocprofv3 PMC) and their ratio.  After the timed region the same step
@@ -173,7 +174,7 @@ def predict_leg(model, batch, mu, npix, nb, nh, seconds=1.0):
     w_ms = float(st[2])
     kp = 8 if nh <= 8 else (16 if nh <= 16 else 32)
     nks = 1 + (kp * (kp + 1) // 2 + 31) // 32               # K-steps of the writer's stage 1 ([hmean | hcov'] against [f | f_a f_b])
-    w_tf = npix * nks * 6 * 16384 / 256 * B / (w_ms * 1e-3) / 1e12     # issued bf16 piece-product flops (six MFMAs per K-step, 16 x 16 tile)
+    w_tf = npix * nks * 3 * 16384 / 256 * B / (w_ms * 1e-3) / 1e12     # issued float16 piece-product flops (three MFMAs per K-step, 16 x 16 tile)
     return {"value": B / dt, "unit": "spectra/s", "ms_per_call": dt * 1e3, "spectra": B, "calls": n,
             "stage_ms": {"images_and_pass1": float(st[0]), "solve": float(st[1]), "writer": w_ms},
             "roofline": {"bound": "hbm", "kernel": "k_predict_x" if nh <= 16 else "k_predict_x32", "achieved": by_writer * B / (w_ms * 1e-3) / 1e9,
@@ -594,13 +595,15 @@ def main():
     dom_ms, dom_flops = (ms_p2, f2) if dominant == p2_name else (ms_p1, f1)
     # The contractions are ISSUED as bf16 piece products on the XDL pipe: per spectrum
     #   pass 1                 4 n k^2 x 6
-    #   pass 2, N_h <= 16      n k^2 x 6 (stage 1, diag Sigma^-1) + 2 n k^2 x 6 (stage 3, M Z; x 3 with QFA_F_S3_FAST)
-    #   pass 2, N_h = 17..32   n k^2 x 6 + 2 n k^2 x 6 (k_grads_s3<KP, 6> from round 4 on; x 3 with QFA_F_S3_FAST)
-    # `roofline` prices the issued bf16 flops of the dominant kernel against the dense bf16 MFMA peak.
+    #   pass 2                 n k^2 x 3 (stage 1, diag Sigma^-1: TWO float16 pieces per operand, three products -- round 5)
+    #                          + 2 n k^2 x 6 (stage 3, M Z: three bf16 pieces, six products; x 3 with QFA_F_S3_FAST)
+    # `roofline` prices the issued 16-bit MFMA flops of the dominant kernel against the dense bf16 / f16 MFMA peak (the same
+    # 2.5 PF).  Until round 5 stage 1 issued six bf16 products (18 n k^2 in all): the step got faster by issuing FEWER
+    # flops, so `frac` of this round is not comparable with the earlier rounds' (`frac_vs_fp32_roof` and ms_per_step are).
     nk2 = npix * nh * nh
     s3 = 3 if fast else 6
     if dominant in ("k_grads_x", "k_grads_t", "k_s12_x+2*k_grads_s3"):
-        xdl_flops = (6 * 1 + s3 * 2) * nk2
+        xdl_flops = (3 * 1 + s3 * 2) * nk2
     elif dominant == "k_moments_x":
         xdl_flops = 6 * 4 * nk2
     else:
@@ -643,7 +646,8 @@ def main():
         roof = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel_ms": dom_ms,
                 "flops_per_spectrum": xdl_flops,
-                "priced": "bf16 piece-product flops issued on the XDL pipe (six per float32 product"
+                "priced": "16-bit piece-product flops issued on the XDL pipe (pass 1 and stage 3: three bf16 pieces, six products per "
+                          "float32 product; stage 1 of pass 2: two float16 pieces, three products"
                           + (", three in stage 3: QFA_F_S3_FAST" if fast else "")
                           + ") over the dense bf16 MFMA peak",
                 "alg_flops_per_spectrum": dom_flops, "achieved_alg_fp32": ach32,
@@ -673,10 +677,12 @@ def main():
                                   "1215.67, QFA/dataloader.py:102; qfa_zabs_factor_f32, during warm-up) and is served by the factored-z "
                                   "kernels since (QFA.auto_factor_zabs; `zabs_kernels` = the same steps with that switched off)")
                                  if factored_headline else "the reference's forward signature (delta, error, zabs, mask); the kernels read zabs",
-                   "arithmetic": "float32 throughout; pass 1 (N_h <= 16) and pass 2 (N_h = 9..16) issue their contractions as "
-                                 "bf16 XDL MFMAs over operands split into three bf16 pieces (float32-exact split, float32 "
-                                 "accumulate): six piece products per float32 product (error vs float64 at or below the f32 "
-                                 "MFMA's, tools/ubench/bf16x3_numerics.hip) in every stage"
+                   "arithmetic": "float32 throughout; the contractions are issued as 16-bit XDL MFMAs with float32 accumulate: pass 1 "
+                                 "and stage 3 of pass 2 over operands split exactly into three bf16 pieces, six piece products per "
+                                 "float32 product; stage 1 of pass 2 and of the posterior writer (both operands prepared images) over "
+                                 "two float16 pieces scaled by powers of two, three products (error vs float64 at or below the f32 "
+                                 "MFMA's for both, tools/ubench/bf16x3_numerics.hip; gradients vs the float64 oracle unchanged, "
+                                 "profiles/r5_ab_f16_stage1.txt)"
                                  + (" EXCEPT stage 3 of pass 2, run here with three (--flags 0x4: operands carried to ~17 bits)" if fast else "")
                                  + "; k x k solve and scalar-gradient sums in float64", "flags": fl},
         "roofline": roof,
