@@ -124,6 +124,18 @@ __device__ __forceinline__ void prep_pgt_body(int bid, const float *__restrict__
             const float4 q = ZP.at(px);
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
         } else if (GT::F16S1 && j >= 80 && j < 112) v = tsc[j & 15][j < 96 ? 1 : 2];
+        else if (GT::F16S3 && j >= 112) {
+            // beta = A^2 / D <= 1 / Psi (D >= A^2 Psi): the power of two that brings it below 2^12.  Psi = m 2^e, m in [0.5, 1):
+            // 1 / Psi <= 2^(1 - e).  (Psi <= 0 or not finite -- outside the reference's clip, model.py:238 -- : no scale)
+            const float ps = px < Npix ? Psi[px] : 0.f;
+            int e = 0;
+            v = 1.f;
+            if (ps > 0.f && ps < 3.0e38f) {
+                (void)frexpf(ps, &e);
+                e = e < -60 ? -60 : (e > 60 ? 60 : e);
+                v = ldexpf(1.f, 11 + e);
+            }
+        }
         reinterpret_cast<float *>(tile + GT::OFF_PAR)[j] = v;
     }
     float *fr = reinterpret_cast<float *>(tile + GT::OFF_F);
@@ -215,6 +227,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
     u32x4 IBh[TPW][GT::NKQ], IBm[TPW][GT::NKQ], IBl[TPW][GT::NKQ];
     float Psi[TPW], om[TPW], ti[TPW], pwi[TPW], l2i[TPW], offl[TPW];
     float it2[TPW], it1[TPW];                               // F16S1: the inverse powers of two of the lane's pixel (pairs, F)
+    float sbeta[TPW];                                       // F16S3: the power of two of the lane's pixel for beta (<= 2^12 / max beta)
+    f32x4 zfac = {1.f, 1.f, 1.f, 1.f};                      // F16S3: 2^(7 - zk) of the lane's four spectra of the group in stage 1 / 2
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         tile[j] = PGT + (size_t)(active ? TPW * wt + j : 0) * GT::TILE_B;
@@ -227,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         const float *par = reinterpret_cast<const float *>(tile[j] + GT::OFF_PAR);
         Psi[j] = par[lo]; om[j] = par[16 + lo];
         it2[j] = GT::F16S1 ? par[80 + lo] : 1.f; it1[j] = GT::F16S1 ? par[96 + lo] : 1.f;
+        sbeta[j] = GT::F16S3 ? par[112 + lo] : 1.f;
         ti[j] = ZF ? par[32 + lo] : 0.f; pwi[j] = ZF ? par[48 + lo] : 0.f; l2i[j] = ZF ? par[64 + lo] : 0.f;
         // factored-z form: a red pixel of the tile that holds the boundary has omega = ti = pwi = 0 in its image
         // (prep_pgt_body) and offset 0 here: A = exp2(0) = 1 and omega zd = 0 come out of the blue arithmetic without a select
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             asm volatile("" ::"v"(IBh[j][ks]), "v"(IBm[j][ks]));
             if (!GT::F16S1) asm volatile("" ::"v"(IBl[j][ks]));
         }
-        asm volatile("" ::"v"(Psi[j]), "v"(om[j]), "v"(ti[j]), "v"(pwi[j]), "v"(l2i[j]), "v"(it2[j]), "v"(it1[j]));
+        asm volatile("" ::"v"(Psi[j]), "v"(om[j]), "v"(ti[j]), "v"(pwi[j]), "v"(l2i[j]), "v"(it2[j]), "v"(it1[j]), "v"(sbeta[j]));
     }
     asm volatile("" ::"v"(k.tau0), "v"(k.c0), "v"(k.beta), "v"(k.t_amp), "v"(k.t_lscale), "v"(k.t_expo), "v"(k.t_off), "v"(k.offp),
                  "v"(k.k1), "v"(k.omc0));
@@ -637,6 +652,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
             const unsigned char *sq = lds + GT::L_S1 + (t & 1) * GT::S1P_B + GT::S1_SCALES + 32 * g;
             isc[0] = *reinterpret_cast<const f32x4 *>(sq);          // 1 / scale(Cinv'), 1 / scale(y) of spectra 4 g, 4 g + 1
             isc[1] = *reinterpret_cast<const f32x4 *>(sq + 16);     // ... of 4 g + 2, 4 g + 3
+            if constexpr (GT::F16S3)
+                zfac = *reinterpret_cast<const f32x4 *>(lds + GT::L_S1 + (t & 1) * GT::S1P_B + GT::S1_ZFAC + 16 * g);
         }
 #pragma unroll
         for (int ks = 0; ks < GT::NKS; ++ks) {
@@ -789,8 +806,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                 }
                 t_c0 -= e;                                                  // :144
                 cnt[j] += wv_ ? 1 : 0;
-                betaR[j][r] = wDA * Av;
-                sA[j] += betaR[j][r] * Av;
+                const float bb = wDA * Av;
+                sA[j] += bb * Av;
+                betaR[j][r] = GT::F16S3 ? bb * (sbeta[j] * zfac[r]) : bb;
                 gamR[j][r] = Av * uu;
             } else {                                                        // red tile: A = 1, zd = 0
                 const float D = Psi[j] + sg * sg;
@@ -799,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                 const float dS = wD - wD * wD * aq[j][r];
                 gPsi[j] += dS - uu * uu;
                 cnt[j] += wv_ ? 1 : 0;
-                betaR[j][r] = wD;
+                betaR[j][r] = GT::F16S3 ? wD * (sbeta[j] * zfac[r]) : wD;
                 sA[j] += wD;
                 gamR[j][r] = uu;
             }
@@ -845,13 +863,22 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         }
         if (!RUNP) part_begin(pt);
         const unsigned char *zp = lds + GT::L_Z + (t & 1) * GT::ZP_B + lane * 16;
+        // bf16: three MFMAs per column tile ({l | h} x {h | l}, {h | m} x {m | m}, {h | m} x {h | h}: six products, K = 16 spectra x 2
+        // piece slots); float16 (F16S3): two ({h | m} x {h | h} and {h | m} x {m | 0}: three products)
         u32x4 bhl[TPW], bmm[TPW], bhh[TPW];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-            unsigned h01, m01, l01, h23, m23, l23;
-            split2(betaR[j][0], betaR[j][1], h01, m01, l01);
-            split2(betaR[j][2], betaR[j][3], h23, m23, l23);
-            bhl[j] = u32x4{h01, h23, l01, l23}; bmm[j] = u32x4{m01, m23, m01, m23}; bhh[j] = u32x4{h01, h23, h01, h23};
+            if constexpr (GT::F16S3) {
+                unsigned h01, m01, h23, m23;
+                split2h(betaR[j][0], betaR[j][1], h01, m01);
+                split2h(betaR[j][2], betaR[j][3], h23, m23);
+                bhh[j] = u32x4{h01, h23, h01, h23}; bmm[j] = u32x4{m01, m23, 0u, 0u}; bhl[j] = bhh[j];
+            } else {
+                unsigned h01, m01, l01, h23, m23, l23;
+                split2(betaR[j][0], betaR[j][1], h01, m01, l01);
+                split2(betaR[j][2], betaR[j][3], h23, m23, l23);
+                bhl[j] = u32x4{h01, h23, l01, l23}; bmm[j] = u32x4{m01, m23, m01, m23}; bhh[j] = u32x4{h01, h23, h01, h23};
+            }
         }
         // The Z operands of column tile a + ZD are requested in front of the MFMAs of tile a, and fences keep it that way (round 5):
         // left to itself hipcc (which schedules this unit for register pressure) asks for tile a + 1 behind the first MFMA of
@@ -860,10 +887,12 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #define QFA_GT_ZD 3
 #endif
         constexpr int ZD = QFA_GT_ZD < GT::NWT ? QFA_GT_ZD : GT::NWT, ZR = ZD + 1;
+        constexpr int NZ = GT::F16S3 ? 1 : 2;                                                   // 16-byte operands per column tile
         u32x4 zop[ZR][2];
-        auto rdz = [&](int a) __attribute__((always_inline)) {                                   // (a == NWT: the p operands)
-            zop[a % ZR][0] = *reinterpret_cast<const u32x4 *>(zp + a * 2048);
-            zop[a % ZR][1] = *reinterpret_cast<const u32x4 *>(zp + a * 2048 + 1024);
+        auto rdz = [&](int a) __attribute__((always_inline)) {                                   // (a == NWT: the p operands, always two)
+            const unsigned char *q = zp + (a < GT::NWT ? a * GT::ZT_B : GT::Z_B);
+            zop[a % ZR][0] = *reinterpret_cast<const u32x4 *>(q);
+            if (NZ == 2 || a == GT::NWT) zop[a % ZR][1] = *reinterpret_cast<const u32x4 *>(q + 1024);
         };
 #pragma unroll
         for (int a = 0; a < ZD; ++a) rdz(a);
@@ -891,9 +920,12 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                     } else if (a - P0 < 7) piece(pt, a - P0);
                 }
             } else if (a % 2 == 0 && !(QFA_GT_ABL & 2)) piece(pt, a / 2);
-            const u32x4 &Z1 = zop[a % ZR][0], &Z2 = zop[a % ZR][1];
+            const u32x4 &Z1 = zop[a % ZR][0], &Z2 = zop[a % ZR][NZ - 1];
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) W[j][a] = xdl(Z2, bhh[j], xdl(Z2, bmm[j], xdl(Z1, bhl[j], W[j][a])));
+            for (int j = 0; j < TPW; ++j) {
+                if constexpr (GT::F16S3) W[j][a] = xdlh(Z1, bhh[j], xdlh(Z1, bmm[j], W[j][a]));
+                else W[j][a] = xdl(Z2, bhh[j], xdl(Z2, bmm[j], xdl(Z1, bhl[j], W[j][a])));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         const u32x4 &P1 = zop[GT::NWT % ZR][0], &P2 = zop[GT::NWT % ZR][1];
@@ -1012,7 +1044,9 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
             const float *fr = reinterpret_cast<const float *>(tile[j] + GT::OFF_F) + lo * KP;
-            f32x4 acc = gacc[j];
+            // F16S3: W holds 2^7 sbeta x the sum (Z as Z 2^zk, beta as beta sbeta 2^(7 - zk)); the gamma term is unscaled
+            const float winv = GT::F16S3 ? 0.0078125f / sbeta[j] : 1.f;          // (a power of two: the quotient is exact)
+            f32x4 acc = GT::F16S3 ? f32x4{0.f, 0.f, 0.f, 0.f} : gacc[j];
             if constexpr (GT::APT == 1) {
 #pragma unroll
                 for (int a4 = 0; a4 < KP / 4; ++a4) {
@@ -1034,6 +1068,10 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], 32);
+            }
+            if constexpr (GT::F16S3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(acc[r], winv, gacc[j][r]);
             }
             if (inb[j] && (GT::APT == 1 || g < 2)) {
 #pragma unroll

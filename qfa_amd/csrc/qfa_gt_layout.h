@@ -8,6 +8,13 @@
 #define QFA_GT_F16S1 1     // stage 1 of k_grads_t on TWO float16 pieces per operand and three products (18 MFMAs per group instead of 36;
                            // qfa_common.h "float16 pieces"): the image carries a power of two per pixel, the state one per spectrum
 #endif
+#ifndef QFA_GT_F16S3
+#define QFA_GT_F16S3 1     // stage 3 of k_grads_t: W += Z beta on TWO float16 pieces per operand, three products in two MFMAs per column tile
+                           // (35 MFMAs per group instead of 51).  beta = A^2 / D <= 1 / Psi of its PIXEL whatever the data (D >= A^2 Psi): the
+                           // image carries the power of two that brings beta below 2^12 and W is a per-pixel sum -- the scale leaves once, when F
+                           // enters.  Z of a spectrum is scaled by 2^7 (by less where its largest element exceeds 128; the factor rides with the
+                           // spectrum's stage-1 scales and multiplies its beta)
+#endif
 template <int KP_>
 struct GTT {
     static constexpr int KP = KP_, KK2 = KP * (KP + 1) / 2;
@@ -39,8 +46,12 @@ struct GTT {
     // (row m <-> a = 2 tile + (m >> 3), b = m & 7): half the MFMAs, operand reads and accumulator registers
     static constexpr int APT = 16 / KP;                      // a per tile (1 or 2)
     static constexpr int NWT = KP / APT;                     // tiles (16 or 4)
-    static constexpr int Z_B = NWT * 2 * 1024;               // [tile][operand 1, 2][lane (g, lo = row m)][4 dwords]
-    static constexpr int ZP_B = Z_B + 2 * 1024;              // + the p operands (gamma term)
+    static constexpr bool F16S3 = QFA_GT_F16S3 != 0;
+    static_assert(!F16S3 || F16S1, "the per-spectrum factor of stage 3 lives beside the stage-1 scales");
+    static constexpr int ZT_B = F16S3 ? 1024 : 2048;         // bytes per column tile of the Z part
+    static constexpr int Z_B = NWT * ZT_B;                   // bf16: [tile][operand 1, 2][lane (g, lo = row m)][4 dwords]; float16: [tile][lane][h01 h23 m01 m23]
+    static constexpr int ZP_B = Z_B + 2 * 1024;              // + the p operands (gamma term: bf16 pieces, six products)
+    static constexpr int S1_ZFAC = S1_SCALES + 128;          // F16S3: float32 2^(7 - zk) of the 16 spectra (Z is stored as Z 2^zk)
     static constexpr int STATE_B = S1P_B + ZP_B;
     static constexpr int NW = 8;                             // waves per workgroup
     // A wave owns TPW 16-pixel tiles = PXW pixels; tile j holds the pixels PXW wt + TPW lo + j (lo = the tile's column): a
@@ -49,7 +60,7 @@ struct GTT {
     static constexpr int TPW = KP == 8 ? 2 : 1;
     static constexpr int PXW = 16 * TPW;
     // a part moves as 1-KiB pieces, contiguous runs of them per wave (k_grads_t decides which waves)
-    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 12 (bf16 pieces: 18), 34 (KP = 8: 6 (9), 10)
+    static constexpr int S1_PCS = S1P_B / 1024, Z_PCS = ZP_B / 1024;     // 12 (bf16 pieces: 18), 18 (34) (KP = 8: 6 (9), 6 (10))
     static_assert((Z_PCS + 4) / 5 <= 7 && (S1_PCS + 4) / 5 <= 6, "pieces per wave and stage: 7 slots in stage 2, 7+ in stage 3, NKS + 1 = 7 in stage 1 (4 at KP = 8)");
     // per-wave staging of the spectra of one group: [16 slots][16 px] float x 3 (delta, sigma, zabs -- or, factored-z form,
     // the float4 factors ZS of the 16 spectra), then mask bytes [16 slots][16]
@@ -77,21 +88,29 @@ __device__ __forceinline__ void build_state(const float *rows, int s0, int B, in
     using C = Cfg<KP>;
     using GT = GTT<KP>;
     // F16S1: the powers of two of the group's 16 spectra (16 threads per spectrum look at its Cinv' and y)
-    __shared__ float sc_[16][4];                                         // scale(Cinv'), scale(y), their inverses
+    __shared__ float sc_[16][6];                                         // scale(Cinv'), scale(y), their inverses; F16S3: 2^zk of Z, 2^(7 - zk)
     if constexpr (GT::F16S1) {
         __syncthreads();                                                 // (k_solve calls this per group: the previous call's readers)
         const int s = tid >> 4, sub = tid & 15;
         const bool v = s0 + s < B;
         const float *sol = rows + (size_t)(v ? s : 0) * C::NSOL;
-        float mc = 0.f, my = 0.f;
+        float mc = 0.f, my = 0.f, mz = 0.f;
         for (int q = sub; q < GT::KK2; q += 16) mc = fmaxf(mc, fabsf(sol[C::SOL_CI + q]));
         if (sub < KP) my = fabsf(sol[sub]);
+        if (GT::F16S3) for (int q = sub; q < KP * KP; q += 16) mz = fmaxf(mz, fabsf(sol[C::SOL_Z + q]));
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) { mc = fmaxf(mc, __shfl_xor(mc, o)); my = fmaxf(my, __shfl_xor(my, o)); }
+        for (int o = 8; o >= 1; o >>= 1) {
+            mc = fmaxf(mc, __shfl_xor(mc, o)); my = fmaxf(my, __shfl_xor(my, o)); mz = fmaxf(mz, __shfl_xor(mz, o));
+        }
         if (sub == 0) {
             float ic, iy;
             const float c_ = f16_row_scale(v ? mc : 0.f, ic), y_ = f16_row_scale(v ? my : 0.f, iy);
             sc_[s][0] = c_; sc_[s][1] = y_; sc_[s][2] = ic; sc_[s][3] = iy;
+            // Z 2^zk with zk = 7 while |Z| < 128 (Z = C^-1 T: of order one), less beyond (|Z 2^zk| < 2^14 always)
+            int e = 0;
+            if (v && mz > 0.f && mz < 3.0e38f) (void)frexpf(mz, &e);                  // mz = m 2^e, m in [0.5, 1)
+            const int zk = e > 7 ? (e > 100 ? -86 : 14 - e) : 7;
+            sc_[s][4] = ldexpf(1.f, zk); sc_[s][5] = ldexpf(1.f, 7 - zk);
         }
         __syncthreads();
     }
@@ -121,6 +140,8 @@ __device__ __forceinline__ void build_state(const float *rows, int s0, int B, in
                 static_assert(GT::YOFF + KP <= 24, "K slots 24..31 of the y block are free");
                 if (lo < 8) h = u32x4{__float_as_uint(sc_[2 * lo][2]), __float_as_uint(sc_[2 * lo][3]),
                                       __float_as_uint(sc_[2 * lo + 1][2]), __float_as_uint(sc_[2 * lo + 1][3])};
+                else if (GT::F16S3 && lo < 12) h = u32x4{__float_as_uint(sc_[4 * (lo - 8)][5]), __float_as_uint(sc_[4 * (lo - 8) + 1][5]),
+                                                         __float_as_uint(sc_[4 * (lo - 8) + 2][5]), __float_as_uint(sc_[4 * (lo - 8) + 3][5])};
             }
             *reinterpret_cast<u32x4 *>(dst) = h;
             *reinterpret_cast<u32x4 *>(dst + 1024) = m;
@@ -141,12 +162,20 @@ __device__ __forceinline__ void build_state(const float *rows, int s0, int B, in
             const bool v = s0 + 4 * g + r < B && bcol < Nh && (wt < GT::NWT || lo < KP);
             const float *sol = rows + (size_t)(v ? 4 * g + r : 0) * C::NSOL;
             x[r] = v ? (wt < GT::NWT ? sol[C::SOL_Z + a * KP + bcol] : sol[C::SOL_P + bcol]) : 0.f;
+            if (GT::F16S3 && wt < GT::NWT) x[r] *= sc_[4 * g + r][4];
         }
-        unsigned h01, m01, l01, h23, m23, l23;
-        split2(x[0], x[1], h01, m01, l01);
-        split2(x[2], x[3], h23, m23, l23);
-        unsigned char *dst = st + GT::S1P_B + wt * 2048 + lane * 16;
-        *reinterpret_cast<u32x4 *>(dst) = u32x4{l01, l23, h01, h23};
-        *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{h01, h23, m01, m23};
+        if (GT::F16S3 && wt < GT::NWT) {
+            unsigned h01, m01, h23, m23;
+            split2h(x[0], x[1], h01, m01);
+            split2h(x[2], x[3], h23, m23);
+            *reinterpret_cast<u32x4 *>(st + GT::S1P_B + wt * GT::ZT_B + lane * 16) = u32x4{h01, h23, m01, m23};
+        } else {
+            unsigned h01, m01, l01, h23, m23, l23;
+            split2(x[0], x[1], h01, m01, l01);
+            split2(x[2], x[3], h23, m23, l23);
+            unsigned char *dst = st + GT::S1P_B + (wt < GT::NWT ? wt * GT::ZT_B : GT::Z_B) + lane * 16;
+            *reinterpret_cast<u32x4 *>(dst) = u32x4{l01, l23, h01, h23};
+            *reinterpret_cast<u32x4 *>(dst + 1024) = u32x4{h01, h23, m01, m23};
+        }
     }
 }
