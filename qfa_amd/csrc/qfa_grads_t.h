@@ -126,10 +126,11 @@ __device__ __forceinline__ void prep_pgt_body(int bid, const float *__restrict__
         } else if (GT::F16S1 && j >= 80 && j < 112) v = tsc[j & 15][j < 96 ? 1 : 2];
         else if (GT::F16S3 && j >= 112) {
             // beta = A^2 / D <= 1 / Psi (D >= A^2 Psi): the power of two that brings it below 2^12.  Psi = m 2^e, m in [0.5, 1):
-            // 1 / Psi <= 2^(1 - e).  (Psi <= 0 or not finite -- outside the reference's clip, model.py:238 -- : no scale)
-            const float ps = px < Npix ? Psi[px] : 0.f;
+            // 1 / Psi <= 2^(1 - e).  Psi <= 0 or not finite is outside the reference's clip (Psi >= 1e-3, QFA/model.py:44,238) and
+            // leaves beta without a bound: 2^-6 there (no overflow below beta = 4e6; elements under beta = 8 lose low bits gradually)
+            const float ps = px < Npix ? Psi[px] : 1.f;
             int e = 0;
-            v = 1.f;
+            v = 0.015625f;
             if (ps > 0.f && ps < 3.0e38f) {
                 (void)frexpf(ps, &e);
                 e = e < -60 ? -60 : (e > 60 ? 60 : e);

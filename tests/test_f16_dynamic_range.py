@@ -45,10 +45,13 @@ def stretched(kind, npix, nb, nh, seed):
         F[:, 0] = 1.0e-4 * F[:, 0]
         F[c:c + 12, 0] = 0.3
     p["F"] = F.astype(np.float32)
+    if kind == "psi_zero":                   # outside the reference's clip (Psi >= 1e-3): stage 3 of k_grads_t has no bound on beta there
+        p["Psi"] = p["Psi"].copy()
+        p["Psi"][::7] = 0.0
     return p, mu
 
 
-KINDS = ("tiny", "huge", "pixel_ramp", "component_ramp", "one_line")
+KINDS = ("tiny", "huge", "pixel_ramp", "component_ramp", "one_line", "psi_zero")
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -88,8 +91,11 @@ def test_stretched_parameters_against_the_oracle(dev, kind, nh, flag):
     assert np.all(np.isfinite(ours_nll)), case
     per = np.array([O.nll_and_grads_single(p, b["delta"][s], b["error"][s], b["zabs"][s], b["mask"][s])[0] for s in range(B)])
     scale = np.maximum(np.abs(per), b["mask"].sum(axis=1))
-    assert np.max(np.abs(ours_nll - per) / np.maximum(scale, 1.0)) < 1e-5, (case, np.max(np.abs(ours_nll - per) / np.maximum(scale, 1.0)))
-    for k, tol in (("F", 3e-4), ("Psi", 1e-4), ("omega", 1e-4)):
+    # (psi_zero: pixels whose only variance is a small sigma^2 -- weights 1e3 x the others', sums that cancel harder in every
+    # kernel, float16 or not: bars three to five times wider)
+    hard = kind == "psi_zero"
+    assert np.max(np.abs(ours_nll - per) / np.maximum(scale, 1.0)) < (5e-5 if hard else 1e-5), (case, np.max(np.abs(ours_nll - per) / np.maximum(scale, 1.0)))
+    for k, tol in (("F", 1e-3 if hard else 3e-4), ("Psi", 3e-4 if hard else 1e-4), ("omega", 3e-4 if hard else 1e-4)):
         ours, ref = gr[k].cpu().numpy(), np.asarray(ogr[k])
         assert np.all(np.isfinite(ours)), (k, case)
         assert rel_l2(ours, ref) < tol, (k, case, rel_l2(ours, ref))
