@@ -367,6 +367,18 @@ __host__ __device__ __forceinline__ float f16_row_scale(float amax, float &inv) 
     inv = ldexpf(1.f, e - 14);
     return ldexpf(1.f, 14 - e);
 }
+// The power of two for the per-element weights wD A^2 (beta of pass 2; the C / T weights of pass 1): A^2 / D <= 1 / Psi of the
+// PIXEL whatever the data (D >= A^2 Psi), so s = 2^(11 + e) with Psi = m 2^e, m in [0.5, 1), keeps s wD A^2 <= 2^12 -- in any flux
+// units (Psi scales with their square; tests/test_f16_dynamic_range.py).  Psi <= 0 or not finite is outside the reference's clip
+// (Psi >= 1e-3, QFA/model.py:44,238) and leaves the weight without a bound: 2^-6 there (no overflow below a weight of 4e6; precision
+// degrades: such a pixel's entries of the pass-1 image dominate their columns' scales).
+__host__ __device__ __forceinline__ float f16_weight_scale(float psi) {
+    if (!(psi > 0.f && psi < 3.0e38f)) return 0.015625f;
+    int e = 0;
+    (void)frexpf(psi, &e);
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    return ldexpf(1.f, 11 + e);
+}
 __device__ __forceinline__ f32x4 xdl16(const u32x2 &a, const u32x2 &b, f32x4 c) {        // K = 16
 #if QFA_ABL == 13          // timing only: no K = 16 XDL MFMA (stage 3 of pass 2)
     asm volatile("" ::"v"(a), "v"(b));

@@ -124,19 +124,7 @@ __device__ __forceinline__ void prep_pgt_body(int bid, const float *__restrict__
             const float4 q = ZP.at(px);
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
         } else if (GT::F16S1 && j >= 80 && j < 112) v = tsc[j & 15][j < 96 ? 1 : 2];
-        else if (GT::F16S3 && j >= 112) {
-            // beta = A^2 / D <= 1 / Psi (D >= A^2 Psi): the power of two that brings it below 2^12.  Psi = m 2^e, m in [0.5, 1):
-            // 1 / Psi <= 2^(1 - e).  Psi <= 0 or not finite is outside the reference's clip (Psi >= 1e-3, QFA/model.py:44,238) and
-            // leaves beta without a bound: 2^-6 there (no overflow below beta = 4e6; elements under beta = 8 lose low bits gradually)
-            const float ps = px < Npix ? Psi[px] : 1.f;
-            int e = 0;
-            v = 0.015625f;
-            if (ps > 0.f && ps < 3.0e38f) {
-                (void)frexpf(ps, &e);
-                e = e < -60 ? -60 : (e > 60 ? 60 : e);
-                v = ldexpf(1.f, 11 + e);
-            }
-        }
+        else if (GT::F16S3 && j >= 112) v = f16_weight_scale(px < Npix ? Psi[px] : 1.f);       // beta <= 1 / Psi (qfa_common.h)
         reinterpret_cast<float *>(tile + GT::OFF_PAR)[j] = v;
     }
     float *fr = reinterpret_cast<float *>(tile + GT::OFF_F);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_prep_step(qfa_params_t p, qfa_tau_t tau
     const int b = (int)blockIdx.x;
     if (b == 0 && threadIdx.x == 0) *tick1 = 0u;             // arrival counter of k_solve<.., NLLRED> later in this step
     const ZPSrc zp{nullptr, pix_ratio, p.beta, tau.expo, -QFA_LOG2E * tau.offset};      // (offp as load_consts forms it)
-    if (b < n_pfx) prep_pfx_body<KP>(b, p.F, p.Psi, p.omega, nullptr, zp, Npix, Nb, Nh, PFX);
+    if (b < n_pfx) prep_pfx_body<KP>(b, n_pfx, p.F, p.Psi, p.omega, nullptr, zp, Npix, Nb, Nh, PFX);
     else if (b < n_pfx + n_p2) {
         if constexpr (PIXRES) prep_pgt_body<KP>(b - n_pfx, p.F, p.Psi, p.omega, zp, Npix, Nb, Nh, P2);
         else prep_pgx_body<KP>(b - n_pfx, p.F, p.Psi, p.omega, zp, Npix, Nb, Nh, 1, P2);
@@ -92,6 +92,12 @@ void qfa_prep_step_launch(int KP, bool pixres, const qfa_params_t &p, const qfa_
     float4 *zs = reinterpret_cast<float4 *>(ZS);
     const float *zq1 = zf ? b.zq1 : nullptr, *ratio = zf ? b.pix_ratio : nullptr;
     auto go = [&](auto kp, auto px) {
+        constexpr int KPc = decltype(kp)::value;
+        if (XCfg<KPc>::F16) {         // the column maxima of the pass-1 image, in front of its builder
+            unsigned *cm = pfx_colmax<KPc>(PFX, n_pfx);
+            (void)hipMemsetAsync(cm, 0, sizeof(unsigned) * XCfg<KPc>::NCOL, st);
+            k_colmax<KPc><<<n_pfx, 1024, 0, st>>>(p.F, p.Psi, Npix, Nh, cm);
+        }
         k_prep_step<decltype(kp)::value, decltype(px)::value><<<grid, 256, 0, st>>>(p, tau, zq1, ratio, b.rows, B, Npix, Nb, Nh, n_pfx, n_p2,
                                                                                     n_zs, PFX, P2, zs, zero, nz, tick1);
     };

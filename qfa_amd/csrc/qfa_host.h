@@ -168,7 +168,7 @@ Layout make_layout_t(int B, int Npix) {
     L.oPF = take((size_t)L.ntiles * C::TILE_PF);
     L.oPFT = take((size_t)L.ntiles * C::TILE_PFT);
     L.oPFX = 0;
-    L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4));
+    L.oPFX = take((size_t)L.ntiles32 * (XCfg<KP>::TILE_B / 4) + 2 * (C::FW + C::PW));      // + the column maxima (pfx_colmax)
     L.oPGX = 0;
     L.wp2x = WorkPlan{0, 0, 1, 0};
     if constexpr (KP == 8 || KP == 16) {
@@ -330,7 +330,14 @@ void launch_moments(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau_t
                    int Nb, int Nh, const Layout &L, const ZTables &zt, float *ws, hipStream_t st, bool prep = true) {
     float *MOM = ws + L.oMOM;
     unsigned char *PFX = reinterpret_cast<unsigned char *>(ws + L.oPFX);
-    if (prep) k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, -QFA_LOG2E * tau.offset, Npix, Nb, Nh, PFX);
+    if (prep) {
+        if (XCfg<KP>::F16) {
+            unsigned *cm = pfx_colmax<KP>(PFX, L.ntiles32);
+            (void)hipMemsetAsync(cm, 0, sizeof(unsigned) * XCfg<KP>::NCOL, st);
+            k_colmax<KP><<<L.ntiles32, 1024, 0, st>>>(p.F, p.Psi, Npix, Nh, cm);
+        }
+        k_prep_pfx<KP><<<L.ntiles32, 256, 0, st>>>(p.F, p.Psi, p.omega, PREDICT ? mu : nullptr, zt.ZP, -QFA_LOG2E * tau.offset, Npix, Nb, Nh, PFX);
+    }
     constexpr int NW = KP <= 16 ? QFA_P1_NW : 4;      // (L.spb1 = 16 NW spectra per block)
     if (zt.ZS)
         k_moments_x<KP, PREDICT, NW, true><<<L.wp1.items(), 64 * NW, 0, st>>>(p, b, tau, mu, B, L.Bpad, Npix, Nb, L.ntiles32, L.wp1, PFX, zt.ZS, MOM);

@@ -18,6 +18,18 @@
 #pragma once
 #include "qfa_common.h"
 
+#ifndef QFA_P1_F16
+#define QFA_P1_F16 0       // pass 1 with the PAIR columns on two float16 pieces (C, T: three products; b, b2 stay on bf16).  Built, measured and
+                           // NOT shipped (round 5, profiles/r5_ab_f16_pass1.txt): pass 1 at c3 1.165 -> 1.005 ms, step 2.95 -> 2.79, but the
+                           // moments feed the k x k solve: the normalised F gradient against the float64 oracle goes from 1.6e-5 to 3.1e-5
+                           // at 25 000 spectra (6.4e-5 -> 6.9e-5 at 100 000; NLL, gPsi, gOmega unchanged) -- a contribution of 2.6e-5 that
+                           // does not average down with the number of spectra and is NOT the image's 22 bits (a third, exact float16 piece of
+                           // the image and a fourth product: the same 3.09e-5), and tests/test_stage3_precision.py::
+                           // test_f_columns_spanning_three_decades goes from under its 3e-4 bar to 3.5e-4.  The six bf16 products are BETTER
+                           // than a float32 MFMA (1.0e-8 against 2.9e-8 per 32-term sum), the three float16 ones equal to it (2.8e-8):
+                           // stages 1 and 3 of pass 2 do not notice, the solve does.  Two more launches per step (memset + k_colmax) cost a
+                           // small batch 4 % (c2).
+#endif
 template <int KP>
 struct XCfg {
     using C = Cfg<KP>;
@@ -30,10 +42,18 @@ struct XCfg {
     static constexpr int nct(int j) { return j == 0 ? CT1 : NCT - CT1; }
     static constexpr int pstr(int j) { return nct(j) * 1024; }   // bytes of one piece of sub-image j: 32 px x bf16 per column
     static constexpr int PSTR = pstr(0);
-    static constexpr int OFF_PSI = 3 * PSTR;                  // in sub-image 0: float32 Psi[32], omega[32], mu[32] (prediction),
+    // QFA_P1_F16 (N_h <= 16; an option, see the macro): the PAIR columns as two float16 pieces (C and T: three products per column
+    // tile instead of six), the F columns (b, b2: their weights wD A delta carry the data, no bound) as three bf16 pieces as before.
+    // Planes: [h: NCT KiB][m: NCT KiB][l: the NFT tiles of F only].  A pair column holds f_a f_b / s_px x cs: s_px =
+    // f16_weight_scale(Psi of the pixel) -- the C / T weights are multiplied by it and stay below 2^12 whatever the data, the two
+    // powers cancel inside the product (K = pixel) -- and cs = the column's power of two over the WHOLE pixel axis (k_colmax; its
+    // inverse multiplies the moment when it is stored).
+    static constexpr bool F16 = QFA_P1_F16 != 0 && NSW == 1;
+    static constexpr int OFF_PSI = F16 ? 2 * PSTR + C::NFT * 1024 : 3 * PSTR;
+                                                              // in sub-image 0: float32 Psi[32], omega[32], mu[32] (prediction),
                                                               // ti[32], pwi[32], offp[32] (factored-z form: ZP of qfa_common.h;
-                                                              // all 0 for red pixels), blue[32] = 1.0 / 0.0
-    static constexpr int SUB0_B = (3 * PSTR + 896 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
+                                                              // all 0 for red pixels), blue[32] = 1.0 / 0.0, F16: s_px[32]
+    static constexpr int SUB0_B = F16 ? (OFF_PSI + 1024 + 1023) / 1024 * 1024 : (3 * PSTR + 896 + 1023) / 1024 * 1024;   // whole 1-KiB LDS-DMA pieces
     static constexpr int SUB1_B = NSW > 1 ? 3 * pstr(1) : 0;
     static constexpr int sub_off(int j) { return j == 0 ? 0 : SUB0_B; }
     static constexpr int sub_bytes(int j) { return j == 0 ? SUB0_B : SUB1_B; }
@@ -193,13 +213,49 @@ __device__ __forceinline__ void step_barrier() {        // LDS writes of this st
 
 
 // ------------------------------------------------------------------------------------------------
+// The column scales of the pass-1 image (XCfg::F16).  COLMAX (NCOL unsigned behind the last tile of PFX, zeroed by the host) takes
+// max_px |f_a f_b| / s_px of every pair column as float32 bits (non-negative floats order like their bits: atomicMax); the image
+// builder and the epilogue of pass 1 derive the column's power of two from it (pfx_col_scale: largest entry in [2^13, 2^14)).
+// One block per 32-pixel tile, thread = (pair column, 8-pixel group).
 template <int KP>
-__device__ __forceinline__ void prep_pfx_body(int bid, const float *__restrict__ F, const float *__restrict__ Psi,
+__host__ __device__ inline unsigned *pfx_colmax(unsigned char *PFX, int ntiles32) {
+    return reinterpret_cast<unsigned *>(PFX + (size_t)ntiles32 * XCfg<KP>::TILE_B);
+}
+__device__ __forceinline__ float pfx_col_scale(unsigned maxbits, float &inv) { return f16_row_scale(__uint_as_float(maxbits), inv); }
+template <int KP>
+__global__ __launch_bounds__(1024) void k_colmax(const float *__restrict__ F, const float *__restrict__ Psi, int Npix, int Nh,
+                                                 unsigned *__restrict__ COLMAX) {
+    using C = Cfg<KP>;
+    __shared__ float f[32][KP + 1], isw[32];
+    const int tid = threadIdx.x, p0 = 32 * blockIdx.x;
+    for (int i = tid; i < 32 * KP; i += 1024) {
+        const int px = i / KP, a = i % KP;
+        f[px][a] = (p0 + px < Npix && a < Nh) ? F[(size_t)(p0 + px) * Nh + a] : 0.f;
+    }
+    if (tid < 32) isw[tid] = 1.f / f16_weight_scale(p0 + tid < Npix ? Psi[p0 + tid] : 1.f);
+    __syncthreads();
+    for (int i = tid; i < 4 * C::KK2; i += 1024) {
+        const int q = i >> 2, g8 = i & 3;
+        int a = 0;
+        while (a + 1 < KP && pair_index(a + 1, a + 1, KP) <= q) ++a;
+        const int b = a + (q - pair_index(a, a, KP));
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(f[8 * g8 + j][a] * f[8 * g8 + j][b]) * isw[8 * g8 + j]);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        if (g8 == 0 && m > 0.f && m < 3.0e38f) atomicMax(COLMAX + C::FW + q, __float_as_uint(m));
+    }
+}
+
+template <int KP>
+__device__ __forceinline__ void prep_pfx_body(int bid, int ntiles32, const float *__restrict__ F, const float *__restrict__ Psi,
                                               const float *__restrict__ omega, const float *__restrict__ mu,
                                               const ZPSrc &ZP, int Npix, int Nb, int Nh, unsigned char *__restrict__ PFX) {
     using C = Cfg<KP>;
     using X = XCfg<KP>;
     unsigned char *tile = PFX + (size_t)bid * X::TILE_B;
+    const unsigned *COLMAX = pfx_colmax<KP>(PFX, ntiles32);
     for (int idx = threadIdx.x; idx < X::NCOL * 16; idx += 256) {         // (column, pixel pair)
         const int c = idx >> 4, q = (idx & 15) * 2;
         float v[2] = {0.f, 0.f};
@@ -218,20 +274,33 @@ __device__ __forceinline__ void prep_pfx_body(int bid, const float *__restrict__
                 okc = b < Nh;
             }
         }
+        float cs = 1.f, ics_ = 1.f;
+        if (X::F16 && pairc) cs = pfx_col_scale(COLMAX[c], ics_);
+        (void)ics_;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int i = 32 * bid + q + e;
-            if (okc && i < Npix) v[e] = pairc ? F[(size_t)i * Nh + a] * F[(size_t)i * Nh + b] : F[(size_t)i * Nh + a];
+            if (okc && i < Npix) {
+                v[e] = pairc ? F[(size_t)i * Nh + a] * F[(size_t)i * Nh + b] : F[(size_t)i * Nh + a];
+                if (X::F16 && pairc) v[e] = (v[e] / f16_weight_scale(Psi[i])) * cs;          // (powers of two: exact)
+            }
         }
-        unsigned h, m, l;
-        split2(v[0], v[1], h, m, l);
         // lane-linear for the B-operand read: [16-column tile][8-pixel group][column][8 px]
         const int ct = c >> 4, sw = ct >= X::CT1 ? 1 : 0, ctl = ct - (sw ? X::CT1 : 0), ps = sw ? X::pstr(1) : X::pstr(0);
         unsigned *dst = reinterpret_cast<unsigned *>(tile + (sw ? X::SUB0_B : 0) + ctl * 1024 + (q >> 3) * 256 + (c & 15) * 16 +
                                                      (q & 7) * 2);
-        dst[0] = h;
-        dst[ps / 4] = m;
-        dst[2 * ps / 4] = l;
+        if (X::F16 && pairc) {
+            unsigned h, m;
+            split2h(v[0], v[1], h, m);
+            dst[0] = h;
+            dst[ps / 4] = m;
+        } else {
+            unsigned h, m, l;
+            split2(v[0], v[1], h, m, l);
+            dst[0] = h;
+            dst[ps / 4] = m;
+            dst[2 * ps / 4] = l;            // (F16: the l plane holds the NFT tiles of F only -- ct < NFT here)
+        }
     }
     float *po = reinterpret_cast<float *>(tile + X::OFF_PSI);
     for (int idx = threadIdx.x; idx < (X::SUB0_B - X::OFF_PSI) / 4; idx += 256) {
@@ -244,6 +313,7 @@ __device__ __forceinline__ void prep_pfx_body(int bid, const float *__restrict__
         else if (idx < 160) v = (ZP.on() && i < Nb) ? ZP.at(i).y : 0.f;     //                  pwi
         else if (idx < 192) v = (ZP.on() && i < Nb) ? ZP.offp : 0.f;        //                  offset of the exponent of A (0: red pixel)
         else if (idx < 224) v = i < Nb ? 1.f : 0.f;                         // 1 = blue pixel
+        else if (idx < 256) v = X::F16 ? f16_weight_scale(i < Npix ? Psi[i] : 1.f) : 0.f;      // s_px of the C / T weights
         po[idx] = v;
     }
 }
@@ -252,7 +322,7 @@ __global__ __launch_bounds__(256) void k_prep_pfx(const float *__restrict__ F, c
                                                   const float *__restrict__ omega, const float *__restrict__ mu,
                                                   const float4 *__restrict__ ZP, float offp, int Npix, int Nb, int Nh,
                                                   unsigned char *__restrict__ PFX) {
-    prep_pfx_body<KP>(blockIdx.x, F, Psi, omega, mu, zp_table(ZP, offp), Npix, Nb, Nh, PFX);
+    prep_pfx_body<KP>(blockIdx.x, gridDim.x, F, Psi, omega, mu, zp_table(ZP, offp), Npix, Nb, Nh, PFX);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -485,7 +555,11 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
         // ---- phase 1 of a tile: per-element weights on the VALU (QFA/model.py:125-131), split into bf16 pieces
         auto weights = [&](int tg, const SpecRegsX &cur, const unsigned char *rows, Pieces &w) {
             const float *pp = reinterpret_cast<const float *>(rows) + 8 * g;      // the tile's parameter rows (OFF_PSI of its image)
-            float psi[8], om[8], muv[8], ti[8], pwi[8], ofl[8], bluef[8];
+            float psi[8], om[8], muv[8], ti[8], pwi[8], ofl[8], bluef[8], swt[8];
+            if (X::F16) {           // s_px of the C / T weights (row 7 of the tile's parameters)
+                const float4 a = *reinterpret_cast<const float4 *>(pp + 224), b = *reinterpret_cast<const float4 *>(pp + 228);
+                swt[0] = a.x; swt[1] = a.y; swt[2] = a.z; swt[3] = a.w; swt[4] = b.x; swt[5] = b.y; swt[6] = b.z; swt[7] = b.w;
+            }
             if (BLUE && ZF) {
                 const float4 a = *reinterpret_cast<const float4 *>(pp + 96), b = *reinterpret_cast<const float4 *>(pp + 100),
                              c = *reinterpret_cast<const float4 *>(pp + 128), d = *reinterpret_cast<const float4 *>(pp + 132),
@@ -566,16 +640,15 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                         const float wDA = wD * A;
                         c2[h2] = wDA * A;
                         cb[h2] = wDA * d;
-                        if (TSIDE) {
-                            c3[h2] = c2[h2] * A;
-                            cb2[h2] = c2[h2] * d;
-                        }
+                        if (TSIDE) cb2[h2] = c2[h2] * d;
+                        if (X::F16) c2[h2] *= swt[e];                        // (<= 2^12: wD A^2 <= 1 / Psi)
+                        if (TSIDE) c3[h2] = c2[h2] * A;
                         cblue = fmaf(mf, bluef[e], cblue);
                     } else {                                                 // red side: A = 1, no omega term
                         D = __builtin_amdgcn_fmed3f(psi[e] + sg * sg, TINY, BIG);
                         if (PREDICT) d = d - muv[e];
                         wD = mf * fast_rcp(D);
-                        c2[h2] = wD;
+                        c2[h2] = X::F16 ? wD * swt[e] : wD;
                         cb[h2] = wD * d;
                     }
                     qd8 += wD * d * d;
@@ -583,13 +656,13 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                     cn += mf;
                 }
                 unsigned h, m, l;
-                split2(c2[0], c2[1], h, m, l);
-                w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = l;
+                if (X::F16) { split2h(c2[0], c2[1], h, m); w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = 0u; }
+                else { split2(c2[0], c2[1], h, m, l); w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = l; }
                 split2(cb[0], cb[1], h, m, l);
                 w.w3h[q] = h; w.w3m[q] = m; w.w3l[q] = l;
                 if (TSIDE) {
-                    split2(c3[0], c3[1], h, m, l);
-                    w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = l;
+                    if (X::F16) { split2h(c3[0], c3[1], h, m); w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = 0u; }
+                    else { split2(c3[0], c3[1], h, m, l); w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = l; }
                     split2(cb2[0], cb2[1], h, m, l);
                     w.w4h[q] = h; w.w4m[q] = m; w.w4l[q] = l;
                 }
@@ -628,17 +701,16 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                         const float wDA = wD * A;
                         c2[h2] = wDA * A;
                         cb[h2] = wDA * d;
-                        if (TSIDE) {
-                            c3[h2] = c2[h2] * A;
-                            cb2[h2] = c2[h2] * d;
-                        }
+                        if (TSIDE) cb2[h2] = c2[h2] * d;
+                        if (X::F16) c2[h2] *= swt[e];
+                        if (TSIDE) c3[h2] = c2[h2] * A;
                         cblue += (wv_ & blue) ? 1.f : 0.f;
                     } else {                                                 // red side: A = 1, no omega term
                         D = psi[e] + sg * sg;
                         if (PREDICT) d = d - muv[e];
                         wD = wv_ ? fast_rcp(D) : 0.f;
                         d = wv_ ? d : 0.f;
-                        c2[h2] = wD;
+                        c2[h2] = X::F16 ? wD * swt[e] : wD;
                         cb[h2] = wD * d;
                     }
                     qd8 += wD * d * d;
@@ -646,13 +718,13 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                     cn += wv_ ? 1.f : 0.f;
                 }
                 unsigned h, m, l;
-                split2(c2[0], c2[1], h, m, l);
-                w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = l;
+                if (X::F16) { split2h(c2[0], c2[1], h, m); w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = 0u; }
+                else { split2(c2[0], c2[1], h, m, l); w.w1h[q] = h; w.w1m[q] = m; w.w1l[q] = l; }
                 split2(cb[0], cb[1], h, m, l);
                 w.w3h[q] = h; w.w3m[q] = m; w.w3l[q] = l;
                 if (TSIDE) {
-                    split2(c3[0], c3[1], h, m, l);
-                    w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = l;
+                    if (X::F16) { split2h(c3[0], c3[1], h, m); w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = 0u; }
+                    else { split2(c3[0], c3[1], h, m, l); w.w2h[q] = h; w.w2m[q] = m; w.w2l[q] = l; }
                     split2(cb2[0], cb2[1], h, m, l);
                     w.w4h[q] = h; w.w4m[q] = m; w.w4l[q] = l;
                 }
@@ -671,6 +743,11 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             auto rdB = [&](int piece, int ct) {
                 return *reinterpret_cast<const u32x4 *>(bcol + piece * PS + (ct - CT0) * 1024);
             };
+            // (XCfg::F16: the pair column tiles are two float16 pieces -- three products)
+            auto ct_terms = [&](const u32x4 &ah, const u32x4 &am, const u32x4 &al, int ct, f32x4 c) __attribute__((always_inline)) {
+                if constexpr (X::F16) return xdl3h(ah, am, rdB(0, ct), rdB(1, ct), c);
+                else return xdl_ct(ah, am, al, rdB(0, ct), rdB(1, ct), rdB(2, ct), c);
+            };
 #pragma unroll
             for (int t = 0; t < C::NFT; ++t) {
                 if (t >= CT0 && t < CTE) {
@@ -688,14 +765,13 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 if (C::NFT + t >= CT0 && C::NFT + t < CTE) {
-                    const u32x4 bh = rdB(0, C::NFT + t), bm = rdB(1, C::NFT + t), bl = rdB(2, C::NFT + t);
                     if (QFA_P1_FRESH && KP <= 16) {
                         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                        acc_add(accC[t], xdl_ct(w.w1h, w.w1m, w.w1l, bh, bm, bl, z));
-                        if (TSIDE) acc_add(accT[t], xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, z));
+                        acc_add(accC[t], ct_terms(w.w1h, w.w1m, w.w1l, C::NFT + t, z));
+                        if (TSIDE) acc_add(accT[t], ct_terms(w.w2h, w.w2m, w.w2l, C::NFT + t, z));
                     } else {
-                    accC[t] = xdl_ct(w.w1h, w.w1m, w.w1l, bh, bm, bl, accC[t]);
-                    if (TSIDE) accT[t] = xdl_ct(w.w2h, w.w2m, w.w2l, bh, bm, bl, accT[t]);
+                    accC[t] = ct_terms(w.w1h, w.w1m, w.w1l, C::NFT + t, accC[t]);
+                    if (TSIDE) accT[t] = ct_terms(w.w2h, w.w2m, w.w2l, C::NFT + t, accT[t]);
                     }
                 }
             }
@@ -722,7 +798,7 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
             auto rd = [&](int ct) __attribute__((always_inline)) {
                 bh[ct % D] = *reinterpret_cast<const u32x4 *>(bcol + ct * 1024);
                 bm[ct % D] = *reinterpret_cast<const u32x4 *>(bcol + PS + ct * 1024);
-                bl[ct % D] = *reinterpret_cast<const u32x4 *>(bcol + 2 * PS + ct * 1024);
+                if (!X::F16 || ct < C::NFT) bl[ct % D] = *reinterpret_cast<const u32x4 *>(bcol + 2 * PS + ct * 1024);
             };
             auto acc_of = [&](int t, bool second) -> f32x4 & {
                 return t < C::NFT ? (second ? accb2[t] : accb[t]) : (second ? accT[t - C::NFT] : accC[t - C::NFT]);
@@ -740,6 +816,23 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 c0 = xdl(ah, bm[q0], c0); c1 = xdl(eh, bm[q1], c1);
                 c0 = xdl(ah, bh[q0], c0); c1 = xdl(eh, bh[q1], c1);
             };
+            // XCfg::F16: the chains of a PAIR column tile are three float16 products (xdl3h's order); the F tile keeps six bf16 ones
+            auto three2 = [&](const u32x4 &ah, const u32x4 &am, int q0, f32x4 &c0, const u32x4 &eh, const u32x4 &em, int q1,
+                              f32x4 &c1) __attribute__((always_inline)) {
+                c0 = xdlh(ah, bm[q0], c0); c1 = xdlh(eh, bm[q1], c1);
+                c0 = xdlh(am, bh[q0], c0); c1 = xdlh(em, bh[q1], c1);
+                c0 = xdlh(ah, bh[q0], c0); c1 = xdlh(eh, bh[q1], c1);
+            };
+            // red tile, group 0: the F tile (six bf16 products, chain c0) beside the first pair tile (three float16 products, c1)
+            auto six_three = [&](const u32x4 &ah, const u32x4 &am, const u32x4 &al, int q0, f32x4 &c0, const u32x4 &eh,
+                                 const u32x4 &em, int q1, f32x4 &c1) __attribute__((always_inline)) {
+                c0 = xdl(ah, bl[q0], c0); c1 = xdlh(eh, bm[q1], c1);
+                c0 = xdl(al, bh[q0], c0); c1 = xdlh(em, bh[q1], c1);
+                c0 = xdl(am, bm[q0], c0); c1 = xdlh(eh, bh[q1], c1);
+                c0 = xdl(am, bh[q0], c0);
+                c0 = xdl(ah, bm[q0], c0);
+                c0 = xdl(ah, bh[q0], c0);
+            };
 #pragma unroll
             for (int t = 0; t < GS * PFG; ++t)
                 if (t < NCT) rd(t);
@@ -756,7 +849,19 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
                 const bool two = TSIDE || t + 1 < NCT;
                 if (QFA_P1_FRESH) tm0 = tm1 = f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 &c0 = QFA_P1_FRESH ? tm0 : ga0, &c1 = QFA_P1_FRESH ? tm1 : ga1;
-                if (TSIDE) {
+                if constexpr (X::F16) {
+                    static_assert(!X::F16 || C::NFT == 1, "one F tile in front of the pair tiles");
+                    if (TSIDE) {
+                        if (t < C::NFT) six2(w.w3h, w.w3m, w.w3l, t % D, c0, w.w4h, w.w4m, w.w4l, t % D, c1);
+                        else three2(w.w1h, w.w1m, t % D, c0, w.w2h, w.w2m, t % D, c1);
+                    } else if (t + 1 < NCT) {
+                        if (t < C::NFT) six_three(w.w3h, w.w3m, w.w3l, t % D, c0, w.w1h, w.w1m, (t + 1) % D, c1);
+                        else three2(w.w1h, w.w1m, t % D, c0, w.w1h, w.w1m, (t + 1) % D, c1);
+                    } else {
+                        c0 = t < C::NFT ? xdl6(w.w3h, w.w3m, w.w3l, bh[t % D], bm[t % D], bl[t % D], c0)
+                                        : xdl3h(w.w1h, w.w1m, bh[t % D], bm[t % D], c0);
+                    }
+                } else if (TSIDE) {
                     if (t < C::NFT) six2(w.w3h, w.w3m, w.w3l, t % D, c0, w.w4h, w.w4m, w.w4l, t % D, c1);
                     else six2(w.w1h, w.w1m, w.w1l, t % D, c0, w.w2h, w.w2m, w.w2l, t % D, c1);
                 } else if (t + 1 < NCT) {
@@ -935,6 +1040,16 @@ __global__ __launch_bounds__(64 * NW, (KP > 16 || NW == 8) ? 1 : 2) void k_momen
 #endif
     if (!active) return;
     // C/D layout: col = lane&15, row = 4*(lane>>4) + r  -> spectrum s0 + 4g + r, column 16t + sl
+    if constexpr (X::F16) {            // the column scales of the pair part leave here (1 / cs: powers of two)
+        const unsigned *cmx = pfx_colmax<KP>(const_cast<unsigned char *>(PFX), ntiles) + C::FW + sl;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            float f;
+            (void)pfx_col_scale(cmx[16 * t], f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accC[t][r] *= f; accT[t][r] *= f; }
+        }
+    }
     float *momseg = mom_segment<C::NMOM>(MOM, wp, seg, Bpad, 16 * NW);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
