@@ -52,7 +52,12 @@ struct Cfg {
 #endif
     static constexpr bool XS3 = KP == 16 || (KP == 32 && QFA_XS3_32);
     static constexpr int PFT_MAIN = XS3 ? (NR * 16 + 255) / 256 * 256 : NR * 16;   // floats of the float32 part
-    static constexpr int PFT_FP = XS3 ? (KP == 32 ? 768 : 512) : 0;                // floats
+#ifndef QFA_S3_F16
+#define QFA_S3_F16 1       // k_grads_s3 (N_h = 17..32): F Z_s on two float16 pieces per operand, three products per spectrum instead of six
+#endif
+    // (KP = 32, QFA_S3_F16: behind the three bf16 pieces the same F as two float16 pieces of t_px F -- t_px the pixel's power of
+    // two -- and a KiB whose first 16 floats are 1 / t_px: floats 768.., 1024.., 1280..)
+    static constexpr int PFT_FP = XS3 ? (KP == 32 ? (QFA_S3_F16 ? 1536 : 768) : 512) : 0;                // floats
     static constexpr int TILE_PFT = PFT_MAIN + PFT_FP;
     // per-spectrum moment record: [C PW][T PW][b FW][b2 FW][qd, ld, n, nblue]
     static constexpr int NMOM = 2 * PW + 2 * FW + 4;

@@ -800,7 +800,11 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
                                                      int slab_stride) {
     static_assert(KP == 32, "k_grads_s3: N_h = 17..32");
     using C = Cfg<KP>;
-    constexpr int RING = 3, BUF_B = TERMS == 6 ? 5120 : 4096;   // per wave and tile: beta 1 KiB | gamma 1 KiB | Fh 1 KiB | Fm 1 KiB (| Fl 1 KiB)
+    // Round 5 (QFA_S3_F16, TERMS == 6 only): G_s = F_tile Z_s on TWO float16 pieces per operand, three products.  Both operands are
+    // prepared: F t_px (k_prep_pf; 1 / t_px rides as a fifth KiB) and Z_s 2^k of the wave's own spectra (scaled by their largest
+    // element below); beta multiplies G in float32 behind the MFMA as before, so nothing here depends on the range of the data.
+    constexpr bool F16 = QFA_S3_F16 != 0 && TERMS == 6;
+    constexpr int RING = 3, BUF_B = TERMS == 6 ? 5120 : 4096;   // per wave and tile: beta 1 KiB | gamma 1 KiB | Fh 1 KiB | Fm 1 KiB (| Fl 1 KiB; F16: 1 / t)
     constexpr int NREQ = TERMS == 6 ? 5 : 4;                    // input requests per wave and tile
     __shared__ __attribute__((aligned(16))) unsigned char lin[4][RING][BUF_B];
     __shared__ float ldspart[2][4][256];
@@ -817,7 +821,8 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
     for (int i = tid; i < 2 * 4 * 256; i += 256) (&ldspart[0][0][0])[i] = 0.f;      // inactive waves' slots stay 0
 
     // B operands: Z_s[a = 8g + j][col] of all 16 spectra as two bf16 pieces, p of the spectra 4g + j (gamma term)
-    u32x4 Zh[16], Zm[16], Zl[TERMS == 6 ? 16 : 1];
+    u32x4 Zh[16], Zm[16], Zl[(TERMS == 6 && !F16) ? 16 : 1];
+    float iz[16];                                               // F16: 1 / scale of Z_s (wave-uniform)
     u32x2 ph, pm, pl;
     {
         const int zcol = 16 * bhalf + lo;
@@ -830,15 +835,30 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
             for (int j = 0; j < 8; ++j) zraw[s][j] = v ? sol[(8 * g + j) * KP] : 0.f;
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int s = 0; s < 16; ++s) {
+            if constexpr (F16) {
+                float mx = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned h, m, l;
-                split2(zraw[s][2 * q], zraw[s][2 * q + 1], h, m, l);
-                Zh[s][q] = h;
-                Zm[s][q] = m;
-                if constexpr (TERMS == 6) Zl[s][q] = l;
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(zraw[s][j]));
+#pragma unroll
+                for (int o = 1; o <= 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));      // the 32 x 16 block of Z_s this wave holds
+                const float sc = f16_row_scale(mx, iz[s]);
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = zraw[s][j] * sc;
+                split8h(x, Zh[s], Zm[s]);
+            } else {
+                iz[s] = 1.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned h, m, l;
+                    split2(zraw[s][2 * q], zraw[s][2 * q + 1], h, m, l);
+                    Zh[s][q] = h;
+                    Zm[s][q] = m;
+                    if constexpr (TERMS == 6) Zl[F16 ? 0 : s][q] = l;
+                }
             }
+        }
         float pr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -868,9 +888,15 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
         glds16a(bgw, o, dst);
         glds16a(ggw, o, dst + 1024);
         const float *fg = uniform_ptr(PFT + (size_t)tg * C::TILE_PFT + C::PFT_MAIN);
-        glds16a(fg, (unsigned)lane * 16u, dst + 2048);
-        glds16a(fg + 256, (unsigned)lane * 16u, dst + 3072);
-        if constexpr (TERMS == 6) glds16a(fg + 512, (unsigned)lane * 16u, dst + 4096);
+        if constexpr (F16) {                    // float16 pieces h, m and the KiB with 1 / t_px
+            glds16a(fg + 768, (unsigned)lane * 16u, dst + 2048);
+            glds16a(fg + 1024, (unsigned)lane * 16u, dst + 3072);
+            glds16a(fg + 1280, (unsigned)lane * 16u, dst + 4096);
+        } else {
+            glds16a(fg, (unsigned)lane * 16u, dst + 2048);
+            glds16a(fg + 256, (unsigned)lane * 16u, dst + 3072);
+            if constexpr (TERMS == 6) glds16a(fg + 512, (unsigned)lane * 16u, dst + 4096);
+        }
     };
     auto flush = [&](int tg, const float (*pp)[256]) {
         const int idx = lane + 64 * wv;
@@ -899,7 +925,12 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
             const u32x4 Fh = *reinterpret_cast<const u32x4 *>(in + 2048 + lane * 16),
                         Fm = *reinterpret_cast<const u32x4 *>(in + 3072 + lane * 16);
             u32x4 Fl = Fh;
-            if constexpr (TERMS == 6) Fl = *reinterpret_cast<const u32x4 *>(in + 4096 + lane * 16);
+            if constexpr (TERMS == 6 && !F16) Fl = *reinterpret_cast<const u32x4 *>(in + 4096 + lane * 16);
+            float itp[4] = {1.f, 1.f, 1.f, 1.f};                              // F16: 1 / t of the pixels 4 g + r of the tile
+            if constexpr (F16) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(in + 4096 + 16 * g);
+                itp[0] = q4.x; itp[1] = q4.y; itp[2] = q4.z; itp[3] = q4.w;
+            }
 
             float *part = ldspart[pbuf][wv];
             if constexpr (QFA_S3_SETPRIO != 0) __builtin_amdgcn_s_setprio(QFA_S3_SETPRIO);
@@ -907,12 +938,22 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
             split2(gam[(4 * g + 0) * 16 + lo], gam[(4 * g + 1) * 16 + lo], h0, m0, l0);
             split2(gam[(4 * g + 2) * 16 + lo], gam[(4 * g + 3) * 16 + lo], h1, m1, l1);
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            f32x4 acc = xdl16_6(u32x2{h0, h1}, u32x2{m0, m1}, u32x2{l0, l1}, ph, pm, pl, zero);
+            const f32x4 gterm = xdl16_6(u32x2{h0, h1}, u32x2{m0, m1}, u32x2{l0, l1}, ph, pm, pl, zero);
+            f32x4 acc = F16 ? zero : gterm;
             const float4 *brow = reinterpret_cast<const float4 *>(bet) + g;          // beta[s][px = 4g .. 4g + 3]
 #pragma unroll
             for (int s = 0; s < ((QFA_S3_ABL & 4) ? 0 : 16); ++s) {
                 f32x4 G;
-                if constexpr (TERMS == 6) G = xdl6(Fh, Fm, Fl, Zh[s], Zm[s], Zl[s], zero);
+                if constexpr (F16) {
+                    G = xdl3h(Fh, Fm, Zh[s], Zm[s], zero);
+                    const float4 bq = brow[s * 4];
+                    const float z = iz[s];
+                    acc[0] = fmaf(bq.x * z, G[0], acc[0]);
+                    acc[1] = fmaf(bq.y * z, G[1], acc[1]);
+                    acc[2] = fmaf(bq.z * z, G[2], acc[2]);
+                    acc[3] = fmaf(bq.w * z, G[3], acc[3]);
+                    continue;
+                } else if constexpr (TERMS == 6) G = xdl6(Fh, Fm, Fl, Zh[s], Zm[s], Zl[F16 ? 0 : s], zero);
                 else {
                     G = xdl(Fm, Zh[s], zero);
                     if (TERMS >= 4) G = xdl(Fm, Zm[s], G);
@@ -924,6 +965,10 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
                 acc[1] = fmaf(bq.y, G[1], acc[1]);
                 acc[2] = fmaf(bq.z, G[2], acc[2]);
                 acc[3] = fmaf(bq.w, G[3], acc[3]);
+            }
+            if constexpr (F16) {                   // 1 / t of the row's pixel, then the (unscaled) gamma term
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) acc[rr] = fmaf(acc[rr], itp[rr], gterm[rr]);
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) part[(4 * g + rr) * 16 + lo] = acc[rr];

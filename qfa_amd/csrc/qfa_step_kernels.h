@@ -80,6 +80,27 @@ __global__ void k_prep_pf(const float *__restrict__ F, const float *__restrict__
                 split2(v0, v1, h, m, l);
                 fp[q] = h; fp[256 + q] = m; fp[512 + q] = l;
             }
+            if constexpr (QFA_S3_F16 != 0) {
+                // the same row as two float16 pieces of t F (k_grads_s3): t from the row's largest |f| (the four threads of a pixel are
+                // neighbours in a wave), 1 / t in the KiB behind the pieces
+                float mx = 0.f, x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    x[j] = (live && 8 * g + j < Nh) ? F[(size_t)i * Nh + 8 * g + j] : 0.f;
+                    mx = fmaxf(mx, fabsf(x[j]));
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 1));
+                mx = fmaxf(mx, __shfl_xor(mx, 2));
+                float it;
+                const float t = f16_row_scale(mx, it);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] *= t;
+                u32x4 h4, m4;
+                split8h(x, h4, m4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { fp[768 + q] = h4[q]; fp[1024 + q] = m4[q]; }
+                if (g == 0) reinterpret_cast<float *>(PFT + (size_t)(i >> 4) * C::TILE_PFT + C::PFT_MAIN)[1280 + (i & 15)] = it;
+            }
         }
     } else if constexpr (C::XS3) {
         // F of this pixel as bf16 pieces, A operand of stage 3: [piece][g][px][a = 4g + j], 8 bytes per (g, px)
