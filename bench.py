@@ -597,15 +597,15 @@ def main():
     #   pass 1                 4 n k^2 x 6
     #   pass 2                 n k^2 x 3 (stage 1, diag Sigma^-1: TWO float16 pieces per operand, three products -- round 5)
     #                          + 2 n k^2 x 6 (stage 3, M Z: three bf16 pieces, six products; x 3 with QFA_F_S3_FAST)
-    #                            k_grads_t (round 5): stage 3 on two float16 pieces as well: 2 n k^2 x 3
+    #                            k_grads_t and k_grads_s3 (round 5): stage 3 on two float16 pieces as well: 2 n k^2 x 3
     # `roofline` prices the issued 16-bit MFMA flops of the dominant kernel against the dense bf16 / f16 MFMA peak (the same
     # 2.5 PF).  Until round 5 pass 2 issued six bf16 products everywhere (18 n k^2; k_grads_t now 9 n k^2): the step got faster by
     # issuing FEWER flops, so `frac` of this round is not comparable with the earlier rounds' (`frac_vs_fp32_roof` and ms_per_step are).
     nk2 = npix * nh * nh
     s3 = 3 if fast else 6
-    if dominant == "k_grads_t":
-        xdl_flops = (3 * 1 + 3 * 2) * nk2
-    elif dominant in ("k_grads_x", "k_s12_x+2*k_grads_s3"):
+    if dominant in ("k_grads_t", "k_s12_x+2*k_grads_s3"):
+        xdl_flops = (3 * 1 + (3 if s3 == 6 else s3) * 2) * nk2      # (k_grads_s3<32, 6> runs three float16 products; the FAST form three bf16)
+    elif dominant == "k_grads_x":
         xdl_flops = (3 * 1 + s3 * 2) * nk2
     elif dominant == "k_moments_x":
         xdl_flops = 6 * 4 * nk2
@@ -649,8 +649,8 @@ def main():
         roof = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel_ms": dom_ms,
                 "flops_per_spectrum": xdl_flops,
-                "priced": "16-bit piece-product flops issued on the XDL pipe (pass 1; stage 3 of k_grads_x / k_grads_s3: three bf16 pieces, "
-                          "six products per float32 product; stage 1 of pass 2 and stage 3 of k_grads_t: two float16 pieces, three products"
+                "priced": "16-bit piece-product flops issued on the XDL pipe (pass 1; stage 3 of k_grads_x: three bf16 pieces, "
+                          "six products per float32 product; stage 1 of pass 2 and stage 3 of k_grads_t / k_grads_s3: two float16 pieces, three products"
                           + (", three in stage 3: QFA_F_S3_FAST" if fast else "")
                           + ") over the dense bf16 MFMA peak",
                 "alg_flops_per_spectrum": dom_flops, "achieved_alg_fp32": ach32,
@@ -681,9 +681,9 @@ def main():
                                   "kernels since (QFA.auto_factor_zabs; `zabs_kernels` = the same steps with that switched off)")
                                  if factored_headline else "the reference's forward signature (delta, error, zabs, mask); the kernels read zabs",
                    "arithmetic": "float32 throughout; the contractions are issued as 16-bit XDL MFMAs with float32 accumulate: pass 1 "
-                                 "(and stage 3 of the small-batch and N_h > 16 kernels) over operands split exactly into three bf16 pieces, "
+                                 "(and stage 3 of the small-batch kernel) over operands split exactly into three bf16 pieces, "
                                  "six piece products per float32 product; stage 1 of pass 2 and of the posterior writer and stage 3 of "
-                                 "k_grads_t over two float16 pieces scaled by powers of two, three products (error vs float64 at or below the f32 "
+                                 "k_grads_t / k_grads_s3 over two float16 pieces scaled by powers of two, three products (error vs float64 at or below the f32 "
                                  "MFMA's for both, tools/ubench/bf16x3_numerics.hip; gradients vs the float64 oracle unchanged, "
                                  "profiles/r5_ab_f16_stage1.txt)"
                                  + (" EXCEPT stage 3 of pass 2, run here with three (--flags 0x4: operands carried to ~17 bits)" if fast else "")
