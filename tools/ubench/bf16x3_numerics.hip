@@ -87,7 +87,12 @@ __global__ void k(const float *A, const float *B, int K, float *out) {     // A 
     }
 }
 
-int main() {
+static float f16_round(float x) { return (float)(_Float16)x; }
+// x as the two float16 pieces of the kernel hold it (scale s): exact afterwards
+static float quant2(float x, float s) { const float y = x * s, h = f16_round(y), m = f16_round(y - h); return (h + m) / s; }
+int main(int argc, char **argv) {
+    const bool quant = argc > 1 && argv[1][0] == 'q';       // "q": inputs pre-rounded to two float16 pieces -- what is left is the MFMA's own error and mm
+    if (quant) printf("inputs quantised to two float16 pieces (row / column scales as in the kernel): the float16 columns show the MFMA's own error\n");
     std::mt19937 rng(7);
     for (int K : {32, 512, 4096}) {
         for (int mode = 0; mode < 4; ++mode) {
@@ -96,6 +101,18 @@ int main() {
             std::uniform_real_distribution<float> ud(0.f, 1.f);
             for (auto &x : A) x = mode == 0 ? nd(rng) : (mode == 1 ? ud(rng) : std::exp((mode == 2 ? 6.f : 2.f) * nd(rng)));   // signed / positive / wide range (2: e^(6 N), 3: e^(2 N))
             for (auto &x : B) x = mode == 1 ? ud(rng) : nd(rng) * (mode == 2 ? std::exp(3.f * nd(rng)) : (mode == 3 ? std::exp(1.5f * nd(rng)) : 1.f));
+            if (quant) {
+                for (int m = 0; m < 16; ++m) {
+                    float mx = 0.f; for (int kk = 0; kk < K; ++kk) mx = std::max(mx, std::fabs(A[m * K + kk]));
+                    int e; std::frexp(mx, &e); const float sc = std::ldexp(1.f, 14 - e);
+                    for (int kk = 0; kk < K; ++kk) A[m * K + kk] = quant2(A[m * K + kk], sc);
+                }
+                for (int n = 0; n < 16; ++n) {
+                    float mx = 0.f; for (int kk = 0; kk < K; ++kk) mx = std::max(mx, std::fabs(B[kk * 16 + n]));
+                    int e; std::frexp(mx, &e); const float sc = std::ldexp(1.f, 14 - e);
+                    for (int kk = 0; kk < K; ++kk) B[kk * 16 + n] = quant2(B[kk * 16 + n], sc);
+                }
+            }
             float *dA, *dB, *dO;
             hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dO, 1280 * 4);
             hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
