@@ -5,17 +5,19 @@
 // reads them back and 0.54 GB of float atomics per launch at c3 -- and the kernel is bound by the instructions it
 // issues ("What binds pass 2").  Every output of pass 2 is a sum over SPECTRA per pixel, so here
 // the roles of the two axes are exchanged:
-//   * a wave owns ONE 16-pixel tile for the whole launch: the stage-1 image of its pixels (B operand, 60 registers),
-//     their Psi / omega / factored-z terms, and the running sums -- W[px][a][b] = sum_s Z_s[a][b] beta[s][px] as 16
-//     MFMA accumulator tiles (64 registers), the gamma term, gPsi, gOmega, sumA, the count;
+//   * a wave owns ONE 16-pixel tile for the whole launch: the stage-1 image of its pixels (B operand: two float16 pieces,
+//     40 registers -- three bf16 pieces, 60, until round 5), their Psi / omega / factored-z terms, and the running sums --
+//     W[px][a][b] = sum_s Z_s[a][b] beta[s][px] as 16 MFMA accumulator tiles (64 registers), the gamma term, gPsi, gOmega, sumA,
+//     the count;
 //   * the per-spectrum operands of a group of 16 spectra (the "state": [Cinv' | y] pieces for stage 1, Z and p pieces
-//     for stage 3, 52 KiB, written once per launch by k_prep_pst) stream through an LDS ring by LDS-DMA, shared by
-//     the workgroup's 8 waves (8 tiles = 128 pixels);
+//     for stage 3, 30 KiB (52 with bf16 pieces), written once per launch by k_solve) stream through an LDS ring by LDS-DMA,
+//     shared by the workgroup's 8 waves (8 tiles = 128 pixels);
 //   * beta / gamma never leave the lane: stage 2 leaves them in exactly the layout stage 3's B operand wants;
 //   * F enters once, at the end: accF[px][b] = sum_a F[px][a] W[px][a][b] + the gamma term, then ONE atomic (or slab
 //     store) per output element and spectra range -- no partial sums in LDS, no flush in the loop.
-// Per (16 spectra x 16 pixels) a wave issues 36 + 51 MFMAs (as before), 52 ds_read_b128 for their streamed operands,
-// stage 2 of four elements per lane and two bf16 splits.
+// Per (16 spectra x 16 pixels) a wave issues 18 + 35 MFMAs (round 5: two float16 pieces and three products per contraction,
+// qfa_common.h "float16 pieces", qfa_gt_layout.h QFA_GT_F16S1 / QFA_GT_F16S3; 36 + 51 with bf16 pieces), 12 + 19 ds_read_b128 for
+// their streamed operands, stage 2 of four elements per lane, one float16 split (beta) and one bf16 split (gamma).
 //
 // Workgroup = 512 threads = 8 waves = 8 tiles (strided over the pixel axis: tile pb + PB w, so that every workgroup
 // gets its share of blue tiles) x one RANGE of spectra groups; PB pixel blocks x R ranges, mapped to the grid so that the
