@@ -90,10 +90,9 @@ typedef struct {
 #define QFA_F_PASS2_XDL    0x2u  /* N_h <= 16: pass 2 in its two-role all-XDL form (k_grads_x: 64 spectra per workgroup
                                   * walk the pixel axis)                                                         */
 #define QFA_F_S3_FAST      0x4u  /* N_h = 17..32: stage 3 of pass 2 (k_grads_s3) with three bf16 piece products (operands
-                                    carried to ~17 bits, <= 1.1e-5 per product) instead of the float32-grade six.  At
-                                    N_h <= 16 the three-product form (round 2's G form of k_grads_x) left the shipped
-                                    library in round 4: the call returns QFA_E_SIZE (a variant build with
-                                    -DQFA_WITH_GFORM=1 still has it: tools/build_full_variant.sh)                   */
+                                    carried to ~17 bits, <= 1.1e-5 per product).  Kept for callers that set it; since
+                                    round 5 the default form runs three FLOAT16 piece products at float32 grade and is
+                                    as fast.  At N_h <= 16 there is no such form: the call returns QFA_E_FLAGS        */
 #define QFA_F_PREDICT_F32  0x8u  /* posterior writer in its float32-MFMA form (k_predict_out)                   */
 #define QFA_F_SYNC         0x20u /* debugging: synchronise `stream` before returning, so that an asynchronous fault of
                                     THIS call's kernels is returned by THIS call (positive hipError_t) instead of
