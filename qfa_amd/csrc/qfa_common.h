@@ -247,7 +247,7 @@ struct ZPSrc {
 __host__ __device__ inline ZPSrc zp_table(const float4 *ZP, float offp = 0.f) { return ZPSrc{ZP, nullptr, nullptr, 0.f, offp}; }
 
 #ifndef QFA_ABL
-#define QFA_ABL 0          // timing-only ablation builds (build with -DQFA_ABL=n: tools/build_full_variant.sh); 0 = product
+#define QFA_ABL 0          // timing-only ablation builds (build with make -C qfa_amd/csrc B=build/var_x OUT=../libqfa_x.so EXTRA=-DQFA_ABL=n); 0 = product
 #endif
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 #if QFA_ABL == 1           // no MFMA: keep operands alive, one VALU op instead

@@ -18,7 +18,7 @@ static void gx_launch(const qfa_params_t &p, const qfa_batch_t &b, const qfa_tau
                       int ntiles32, const WorkPlan &wp, unsigned char *PGX, const float *SOL, const float4 *ZS,
                       const float4 *ZP, float *accum, float *slab, double *slabS, int slab_stride, Scal64 *sc64,
                       unsigned flags, hipStream_t st, bool prep) {
-    // QFA_WITH_GFORM (a variant build, tools/build_full_variant.sh gform -DQFA_WITH_GFORM=1): the three-product G form of stage 3 behind QFA_F_S3_FAST --
+    // QFA_WITH_GFORM (a variant build, make -C qfa_amd/csrc B=build/var_gform OUT=../libqfa_gform.so EXTRA=-DQFA_WITH_GFORM=1): the three-product G form of stage 3 behind QFA_F_S3_FAST --
     // round 2's headline form, kept out of the shipped library from round 4 on (the host refuses the flag at N_h <= 16)
 #ifndef QFA_WITH_GFORM
 #define QFA_WITH_GFORM 0
