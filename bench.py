@@ -655,6 +655,9 @@ def main():
                           + ") over the dense bf16 MFMA peak",
                 "alg_flops_per_spectrum": dom_flops, "achieved_alg_fp32": ach32,
                 "frac_vs_fp32_roof": ach32 / PEAK_FP32_TFLOPS,
+                "frac_note": "`frac` counts ISSUED piece products: the round-5 kernels issue 9 (k_grads_t, k_grads_s3) or 15 n k^2 where "
+                             "rounds 1-4 issued 18 for the same float32 result, so `frac` fell while the kernel got faster; compare rounds "
+                             "by kernel_ms / ms_per_step or by frac_vs_fp32_roof (algorithmic flops, DESIGN.md section 5)",
                 "clock_capped_stream": {"tflops": CAPPED_STREAM_TFLOPS, "frac": ach / CAPPED_STREAM_TFLOPS,
                                         "source": "profiles/r5_ubench_xdl_power.txt (mode 4: the chip holds 1.49 GHz, not 2.4, "
                                                   "under a stall-free MFMA + LDS + VALU stream on random operands)"}}
