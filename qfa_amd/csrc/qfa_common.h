@@ -58,6 +58,7 @@ struct Cfg {
     // (KP = 32, QFA_S3_F16: behind the three bf16 pieces the same F as two float16 pieces of t_px F -- t_px the pixel's power of
     // two -- and a KiB whose first 16 floats are 1 / t_px: floats 768.., 1024.., 1280..)
     static constexpr int PFT_FP = XS3 ? (KP == 32 ? (QFA_S3_F16 ? 1536 : 768) : 512) : 0;                // floats
+    static constexpr int PFT_F16H = 768, PFT_F16M = 1024, PFT_F16IT = 1280;      // (floats from PFT_MAIN: the float16 pieces and 1 / t)
     static constexpr int TILE_PFT = PFT_MAIN + PFT_FP;
     // per-spectrum moment record: [C PW][T PW][b FW][b2 FW][qd, ld, n, nblue]
     static constexpr int NMOM = 2 * PW + 2 * FW + 4;

@@ -125,8 +125,8 @@ __device__ __forceinline__ void prep_pgt_body(int bid, const float *__restrict__
         else if (j < 80 && ZP.on() && px < Nb) {
             const float4 q = ZP.at(px);
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
-        } else if (GT::F16S1 && j >= 80 && j < 112) v = tsc[j & 15][j < 96 ? 1 : 2];
-        else if (GT::F16S3 && j >= 112) v = f16_weight_scale(px < Npix ? Psi[px] : 1.f);       // beta <= 1 / Psi (qfa_common.h)
+        } else if (GT::F16S1 && j >= GT::PAR_IT2 && j < GT::PAR_SBETA) v = tsc[j & 15][j < GT::PAR_IT1 ? 1 : 2];
+        else if (GT::F16S3 && j >= GT::PAR_SBETA) v = f16_weight_scale(px < Npix ? Psi[px] : 1.f);       // beta <= 1 / Psi (qfa_common.h)
         reinterpret_cast<float *>(tile + GT::OFF_PAR)[j] = v;
     }
     float *fr = reinterpret_cast<float *>(tile + GT::OFF_F);
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(512, 2) void k_grads_t(qfa_params_t p, qfa_batch_t 
         }
         const float *par = reinterpret_cast<const float *>(tile[j] + GT::OFF_PAR);
         Psi[j] = par[lo]; om[j] = par[16 + lo];
-        it2[j] = GT::F16S1 ? par[80 + lo] : 1.f; it1[j] = GT::F16S1 ? par[96 + lo] : 1.f;
-        sbeta[j] = GT::F16S3 ? par[112 + lo] : 1.f;
+        it2[j] = GT::F16S1 ? par[GT::PAR_IT2 + lo] : 1.f; it1[j] = GT::F16S1 ? par[GT::PAR_IT1 + lo] : 1.f;
+        sbeta[j] = GT::F16S3 ? par[GT::PAR_SBETA + lo] : 1.f;
         ti[j] = ZF ? par[32 + lo] : 0.f; pwi[j] = ZF ? par[48 + lo] : 0.f; l2i[j] = ZF ? par[64 + lo] : 0.f;
         // factored-z form: a red pixel of the tile that holds the boundary has omega = ti = pwi = 0 in its image
         // (prep_pgt_body) and offset 0 here: A = exp2(0) = 1 and omega zd = 0 come out of the blue arithmetic without a select

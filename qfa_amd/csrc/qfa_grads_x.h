@@ -61,6 +61,7 @@ struct GXT {                                             // KP = 16 (N_h = 9..16
     static constexpr bool F16 = QFA_GX_F16 != 0;
     static constexpr int NP = F16 ? 2 : 3;               // pieces per K-step
     static constexpr int KS_B = NP * 1024;
+    static constexpr int PAR_IT1 = 80, PAR_IT2 = 96;     // float index in a half's parameter KiB: 1 / t, 1 / t^2 of pixel 2 lo + h
     static constexpr int S1_HALF = NKS * KS_B;           // bytes of the stage-1 image of one 16-pixel half
     static constexpr int HALF_B = S1_HALF + 1024;        // ring slot: + float32 Psi[16], omega[16] of its pixels (19 / 10 KiB)
     static constexpr int OFF_FP = 2 * HALF_B;            // F as bf16 pieces, A operand of stage 3: [piece][lane][8 a]
@@ -186,7 +187,7 @@ __device__ __forceinline__ void prep_pgx_body(int bid, const float *__restrict__
         else if (j < 80 && ZP.on() && px < Nb) {            // factored-z form: ti | pwi | l2i of the half's pixels
             const float4 q = ZP.at(px);
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
-        } else if (GX::F16 && j >= 80 && j < 112) v = tsc[2 * (j & 15) + h][j < 96 ? 1 : 2];
+        } else if (GX::F16 && j >= GX::PAR_IT1 && j < GX::PAR_IT2 + 16) v = tsc[2 * (j & 15) + h][j < GX::PAR_IT2 ? 1 : 2];
         po[j] = v;
     }
     if (wform) {       // stage 3 in its W form (role B, TERMS = 6): F of the tile as float32 rows [pixel 0..31][FROW]
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void k_grads_x(qfa_params_t p, qfa_batch_t 
             }
             const float *po = reinterpret_cast<const float *>(img + GX::S1_HALF);
             if constexpr (GX::F16) {           // the powers of two back in: element r <-> spectrum 4 g + r, the lane's pixel
-                const float it1 = po[80 + lo], it2 = po[96 + lo];
+                const float it1 = po[GX::PAR_IT1 + lo], it2 = po[GX::PAR_IT2 + lo];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     afy[r] = (afy[r] * is0[r]) * it1;

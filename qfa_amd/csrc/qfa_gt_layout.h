@@ -34,6 +34,7 @@ struct GTT {
     // float Psi[16] | omega[16] | ti[16] | pwi[16] | l2i[16] | F16S1: 1 / t^2 [16] | 1 / t [16] (t = the pixel's power of two:
     // the image holds t^2 f_a f_b and t f_a)
     static constexpr int OFF_PAR = IMG_B;
+    static constexpr int PAR_IT2 = 80, PAR_IT1 = 96, PAR_SBETA = 112;      // float index in the parameter block: 1 / t^2, 1 / t, s_beta of pixel lo
     static constexpr int OFF_F = IMG_B + 512;                // float F[16 px][KP]
     static constexpr int TILE_B = (OFF_F + 16 * KP * 4 + 1023) / 1024 * 1024;
     // per group of 16 spectra in global memory (k_prep_pst)

@@ -44,6 +44,7 @@ struct S12 {
     static constexpr bool F16 = QFA_S12_F16 != 0;
     static constexpr int NP = F16 ? 2 : 3;                     // pieces per K-step
     static constexpr int KS_B = NP * 1024;
+    static constexpr int PAR_IT1 = 80, PAR_IT2 = 96;           // float index in a half's parameter KiB: 1 / t, 1 / t^2 of pixel 2 lo + h
     static constexpr int Q_B = NKQ * KS_B;                     // bytes of a quarter image (18 KiB; bf16 pieces: 27)
     static constexpr int SLOT_B = Q_B + 1024;                  // ring slot: + Psi[16], omega[16] of the half (float32, one KiB)
     static constexpr int HALF_B = 2 * Q_B + 1024;              // global: [quarter 0 | Psi/omega KiB | quarter 1]
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void k_prep_s12(const float *__restrict__ F, c
         else if (j < 80 && ZP && px < Nb) {                 // factored-z form: ti | pwi | l2i of the half's pixels
             const float4 q = ZP[px];
             v = j < 48 ? q.x : (j < 64 ? q.y : q.z);
-        } else if (X::F16 && j >= 80 && j < 112) v = tsc[2 * (j & 15) + h][j < 96 ? 1 : 2];
+        } else if (X::F16 && j >= X::PAR_IT1 && j < X::PAR_IT2 + 16) v = tsc[2 * (j & 15) + h][j < X::PAR_IT2 ? 1 : 2];
         po[j] = v;
     }
 }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void k_s12_x(qfa_params_t p, qfa_batch_t bt
             const float *po = reinterpret_cast<const float *>(img + X::Q_B);
             PsiH = po[lo];
             omH = po[16 + lo];
-            if (X::F16) { it1H = po[80 + lo]; it2H = po[96 + lo]; }
+            if (X::F16) { it1H = po[X::PAR_IT1 + lo]; it2H = po[X::PAR_IT2 + lo]; }
             if (ZF) { tiH = po[32 + lo]; pwiH = po[48 + lo]; l2iH = po[64 + lo]; }
         }
         constexpr int NP = X::NP;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(256, 1) void k_predict_x32(int B, int Npix, int nti
             afy = f32x4{0.f, 0.f, 0.f, 0.f};
             aq = f32x4{0.f, 0.f, 0.f, 0.f};
             muH = reinterpret_cast<const float *>(img + X::Q_B)[lo];
-            if (X::F16) { it1H = reinterpret_cast<const float *>(img + X::Q_B)[80 + lo]; it2H = reinterpret_cast<const float *>(img + X::Q_B)[96 + lo]; }
+            if (X::F16) { it1H = reinterpret_cast<const float *>(img + X::Q_B)[X::PAR_IT1 + lo]; it2H = reinterpret_cast<const float *>(img + X::Q_B)[X::PAR_IT2 + lo]; }
         }
         constexpr int NP = X::NP;
         u32x4 bq[2][NP];
@@ -889,9 +890,9 @@ __global__ __launch_bounds__(256, 2) void k_grads_s3(int B, int Npix, int Nh, in
         glds16a(ggw, o, dst + 1024);
         const float *fg = uniform_ptr(PFT + (size_t)tg * C::TILE_PFT + C::PFT_MAIN);
         if constexpr (F16) {                    // float16 pieces h, m and the KiB with 1 / t_px
-            glds16a(fg + 768, (unsigned)lane * 16u, dst + 2048);
-            glds16a(fg + 1024, (unsigned)lane * 16u, dst + 3072);
-            glds16a(fg + 1280, (unsigned)lane * 16u, dst + 4096);
+            glds16a(fg + C::PFT_F16H, (unsigned)lane * 16u, dst + 2048);
+            glds16a(fg + C::PFT_F16M, (unsigned)lane * 16u, dst + 3072);
+            glds16a(fg + C::PFT_F16IT, (unsigned)lane * 16u, dst + 4096);
         } else {
             glds16a(fg, (unsigned)lane * 16u, dst + 2048);
             glds16a(fg + 256, (unsigned)lane * 16u, dst + 3072);

@@ -98,8 +98,8 @@ __global__ void k_prep_pf(const float *__restrict__ F, const float *__restrict__
                 u32x4 h4, m4;
                 split8h(x, h4, m4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { fp[768 + q] = h4[q]; fp[1024 + q] = m4[q]; }
-                if (g == 0) reinterpret_cast<float *>(PFT + (size_t)(i >> 4) * C::TILE_PFT + C::PFT_MAIN)[1280 + (i & 15)] = it;
+                for (int q = 0; q < 4; ++q) { fp[C::PFT_F16H + q] = h4[q]; fp[C::PFT_F16M + q] = m4[q]; }
+                if (g == 0) reinterpret_cast<float *>(PFT + (size_t)(i >> 4) * C::TILE_PFT + C::PFT_MAIN)[C::PFT_F16IT + (i & 15)] = it;
             }
         }
     } else if constexpr (C::XS3) {
