@@ -113,7 +113,9 @@ def test_config3_100k_one_launch_vs_float64_oracle(dev, tmp_path):
             e[k] = float(np.linalg.norm(g[k].cpu().numpy().astype(np.float64)[ok] - ref[ok]) / np.linalg.norm(ref[ok]))
         e["loss"] = abs(loss.item() - ol) / abs(ol)
         print("100 000 x 4000, N_h = 16, one launch vs float64 oracle:", name, e)
-        # achieved: F 6.4e-5, Psi 6.3e-6, omega 1.3e-5, loss 1.9e-7
-        assert e["F"] < 1e-4 and e["Psi"] < 2e-5 and e["omega"] < 2e-5 and e["loss"] < 2e-6, (name, e)
+        # achieved: F 6.4e-5, Psi 6.3e-6, omega 1.3e-5, loss 1.9e-7 (unchanged by the float16 stages of pass 2; 6.9e-5 with pass 1 on
+        # float16 pieces, the option that is off).  The tolerance of the table is 1e-4 for F; the bar here sits where a change of the
+        # arithmetic shows (deterministic at this size)
+        assert e["F"] < 8e-5 and e["Psi"] < 1e-5 and e["omega"] < 2e-5 and e["loss"] < 6e-7, (name, e)
     del batch
     torch.cuda.empty_cache()

@@ -159,16 +159,19 @@ def test_headline_shape_24613_spectra_normalised_gradients_vs_float64_oracle(dev
         out[name] = e
     print("24613 x 4000, N_h = 16 vs float64 oracle:", out)
     six = out["six"]
-    assert six["loss"] < 2e-6
-    # achieved (round 5, fresh accumulators per tile in pass 1): F 1.6e-5 (6.7e-7 of the cancelling sums, which are 24x the gradient);
-    # 3.2e-5 with pass 1's chains of rounds 1-4; round 2's three-product form (no longer in the shipped library) was at 5.5e-5
-    assert six["F"] < 6e-5 and six["F_over_terms"] < 3e-6, six
-    assert six["Psi"] < 2e-5 and six["omega"] < 2e-5, six
+    assert six["loss"] < 6e-7
+    # achieved (round 5: fresh accumulators per tile in pass 1, float16 pieces in stages 1 and 3 of pass 2): k_grads_t F 1.61e-5
+    # (6.8e-7 of the cancelling sums, which are 24x the gradient), k_grads_x 1.78e-5 / 7.5e-7; Psi 3.1e-6, omega 6.7e-6, loss 1.8e-7.
+    # (3.2e-5 with pass 1's chains of rounds 1-4 -- and again with pass 1 on float16 pieces, QFA_P1_F16, which is why that
+    # option is off; round 2's three-product form was at 5.5e-5.)  The bars sit 40-60 % above what is achieved: the arithmetic is
+    # deterministic at this size (no atomics), so a change of these numbers is a change of the code.
+    assert six["F"] < 2.5e-5 and six["F_over_terms"] < 1.1e-6, six
+    assert six["Psi"] < 8e-6 and six["omega"] < 1.2e-5, six
     # the pixel-resident form (k_grads_t: W accumulated in float32 MFMA registers over 2 500 spectra per range, F applied once
     # at the end) meets the same bars
     for name in ("pixres", "default"):
         t = out[name]
-        assert t["loss"] < 2e-6 and t["F"] < 6e-5 and t["F_over_terms"] < 3e-6 and t["Psi"] < 2e-5 and t["omega"] < 2e-5, (name, t)
+        assert t["loss"] < 6e-7 and t["F"] < 2.5e-5 and t["F_over_terms"] < 1.1e-6 and t["Psi"] < 8e-6 and t["omega"] < 1.2e-5, (name, t)
     # flags = 0 took the pixel-resident form: bit for bit the forced launch (its sums leave through slab rows in fixed order)
     assert out["default"] == out["pixres"]
     del batch
