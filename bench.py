@@ -588,7 +588,7 @@ def main():
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         xdl_form = not (fl & 0x1)
         # ... and pass2_use_pixres: the pixel-resident form (k_grads_t) from 96 spectra per CU on (N_h <= 8, N_pix >= 1024: 36)
-        auto_t = B >= 96 * ncu or (nh <= 8 and B >= 36 * ncu and npix >= 1024)
+        auto_t = B >= 96 * ncu or (npix >= 1024 and B >= (512 if nh <= 8 else 128))      # qfa_host.h, pass2_use_pixres
         pixres = xdl_form and npix >= 16 and not (fl & (0x1 | 0x10 | 0x4)) and (bool(fl & 0x40) or (not (fl & 0x2) and auto_t))
         p2_name = ("k_grads_t" if pixres else "k_grads_x") if xdl_form else "k_grads"
     dominant = p2_name if ms_p2 >= ms_p1 else "k_moments_x"

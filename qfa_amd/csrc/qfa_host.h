@@ -277,7 +277,14 @@ inline bool pass2_use_pixres(int KP, int B, int Npix, unsigned flags) {
     if (flags & QFA_F_PASS2_XDL) return false;
     const int ncu = cu_count();
     if (B >= 96 * ncu) return true;
-    return KP == 8 && B >= 36 * ncu && Npix >= 1024;
+    // Round 5, after the float16 stages (18 + 35 MFMAs per group instead of 36 + 51) and the reworked walk: the pixel-resident form
+    // wins from a few hundred spectra on wherever the pixel axis gives every CU work (tools/pass2_crossover.sh,
+    // profiles/r5_pass2_crossover.txt; step k_grads_x / k_grads_t in ms): N_h = 16, N_pix = 4000: 0.102 / 0.096 at 128 spectra,
+    // 0.127 / 0.109 at 500, 0.206 / 0.149 at 2 000, 0.51 / 0.30 at 8 000; N_h = 8, N_pix = 2000: 0.080 / 0.088 at 256, 0.086 / 0.085
+    // at 500, 0.095 / 0.083 at 1 000, 0.195 / 0.134 at 8 000; N_pix = 9243: 0.106 / 0.102 at 256, 0.182 / 0.148 at 1 000.
+    // (Short pixel axes keep the rule of round 3: 96 spectra per CU.)
+    if (Npix < 1024) return false;
+    return KP == 16 ? B >= 128 : B >= 512;
 }
 
 // launch errors of the calls just made; with QFA_F_SYNC also the asynchronous ones (the stream is drained first)
