@@ -18,7 +18,7 @@ no masks).
 `python bench.py --gpus N` without a launcher starts the N ranks itself (fresh child processes, before this process
 touches the GPU) and relays rank 0's line.  Rank 0 prints ONE JSON line.
 
-`roofline` describes the dominant kernel (pass 2: at N_h = 9..16 k_grads_t from 96 spectra per CU on and k_grads_x below,
+`roofline` describes the dominant kernel (pass 2: at N_h <= 16 k_grads_t from 128 (N_h <= 8: 512) spectra on and k_grads_x below,
 k_grads / k_grads_x at N_h <= 8, the three launches k_s12_x + 2 k_grads_s3 at N_h = 17..32; its mean duration is measured with HIP events recorded by the library on the
 launch stream inside the timed region).  The contractions are float32 products ISSUED as 16-bit piece products on the XDL
 pipe (pass 1 and stage 3 of pass 2: operands split into three bf16 pieces, six products per float32 product; stage 1 of pass 2
@@ -587,7 +587,7 @@ def main():
     else:                                     # the same rule as pass2_use_xdl (qfa_host.h)
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         xdl_form = not (fl & 0x1)
-        # ... and pass2_use_pixres: the pixel-resident form (k_grads_t) from 96 spectra per CU on (N_h <= 8, N_pix >= 1024: 36)
+        # ... and pass2_use_pixres: the pixel-resident form (k_grads_t) from 128 (N_h <= 8: 512) spectra on for N_pix >= 1024, else 96 per CU
         auto_t = B >= 96 * ncu or (npix >= 1024 and B >= (512 if nh <= 8 else 128))      # qfa_host.h, pass2_use_pixres
         pixres = xdl_form and npix >= 16 and not (fl & (0x1 | 0x10 | 0x4)) and (bool(fl & 0x40) or (not (fl & 0x2) and auto_t))
         p2_name = ("k_grads_t" if pixres else "k_grads_x") if xdl_form else "k_grads"

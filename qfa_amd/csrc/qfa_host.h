@@ -257,7 +257,8 @@ inline int check_shape(int B, int Npix, int Nb, int Nh) {
 //   k_grads never: k_grads_x is as fast or faster at every batch size measured, N_h = 8: 0.072 / 0.083 at 500 spectra x 2000 px,
 //     0.104 / 0.117 at 2 000, 0.192 / 0.220 at 8 000, 2.82 / 3.25 at 40 000 x 9243 (the one exception, 10 000 x 2000 --
 //     157 blocks on 256 CUs, 0.281 / 0.258 -- goes to k_grads_t); N_h = 16: 2.5 - 2.6 against 3.2 ms at c3;
-//   k_grads_t once the batch gives every workgroup a walk long enough to pay for its prologue and epilogue:
+//   k_grads_t once the batch gives every workgroup a walk long enough to pay for its prologue and epilogue (the figures of ROUND 3 --
+//     superseded for N_pix >= 1024 by the round-5 sweep quoted in pass2_use_pixres below):
 //     N_h = 9..16 from 96 spectra per CU (24 576) on: N_pix = 4000: 0.146 / 0.166 at 1 000 spectra, 0.42 / 0.44 at 8 000,
 //       1.43 / 1.35 at 32 000, 4.31 / 3.98 at 100 000 (k_grads_x / k_grads_t); N_pix = 640: 0.161 / 0.183 at 8 000, 1.085 / 0.971 at 100 000;
 //     N_h <= 8 (a wave owns two 16-pixel tiles there) from 96 spectra per CU on, and from 36 per CU (9 216) on for N_pix >= 1024:
